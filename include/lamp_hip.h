@@ -1,0 +1,228 @@
+/*
+ * lamp_hip.h -- C ABI of liblamp_hip.so, the MI355X (gfx950) native library behind the
+ * LaMP label-graph message-passing forward path.
+ *
+ * The reference (QData/LaMP) is pure Python on PyTorch: it owns no native code and no FFI.  The
+ * "FFI for this path" is therefore the set of nn.Module.forward methods on the path; each entry
+ * point below replaces one of them and cites it (paths relative to the reference root).  The
+ * Python side (lamp_amd/_native.py) binds these with ctypes and raw data_ptr()s; INTEGRATION.md
+ * shows the stub.
+ *
+ * Conventions
+ *   - plain C99 types only; no torch / HIP types in signatures (a stream is a void* holding a
+ *     hipStream_t; NULL = the default stream).
+ *   - all tensors are fp32, row-major, device-resident; indices are int64; masks are uint8.
+ *   - mask convention everywhere (as in the reference): NONZERO = BLOCKED.
+ *   - the caller owns every byte: inputs, outputs, weights, workspace.  The library never
+ *     allocates or frees device memory and keeps no pointer after return.
+ *   - every call only enqueues work on `stream` (asynchronous w.r.t. the host) and is re-entrant;
+ *     the device is the one current for the calling thread.
+ *   - return value: 0 = ok, > 0 = a hipError_t from a launch, < 0 = lamp_status below.  Nothing
+ *     throws or aborts across the boundary.  NaN produced by fully masked attention rows is data,
+ *     not an error (reference behaviour).
+ */
+#ifndef LAMP_HIP_H
+#define LAMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAMP_HIP_ABI_VERSION 1
+
+typedef void* lamp_stream_t; /* hipStream_t */
+
+enum lamp_status {
+    LAMP_OK = 0,
+    LAMP_E_DIMS = -1,        /* non-positive or inconsistent dimensions */
+    LAMP_E_ALIGN = -2,       /* pointer / leading dimension not 16-byte aligned where required */
+    LAMP_E_WORKSPACE = -3,   /* workspace too small */
+    LAMP_E_UNSUPPORTED = -4, /* valid request this build has no kernel for (e.g. d_k > 128) */
+    LAMP_E_NULL = -5         /* required pointer is NULL */
+};
+
+/* Attention mask descriptor.  One code path covers the reference's three mask uses:
+ *   key padding  (lamp/utils.py:26-34)      : U8, stride_q = 0, stride_b = lk      [B, lk]
+ *                                             or KEY_TOKENS_I64 straight from src_seq
+ *   label graph  (lamp/Decoders.py:109-116) : U8, stride_b = 0, stride_q = lk      [lq, lk]
+ *   arbitrary    (module-level callers)     : U8, stride_b = lq*lk, stride_q = lk  [B, lq, lk]
+ * The same mask is applied to every head (lamp/SubLayers.py:102 repeats it n_head times). */
+enum lamp_mask_kind {
+    LAMP_MASK_NONE = 0,
+    LAMP_MASK_U8 = 1,            /* uint8, nonzero = blocked; element (b,q,k) at ptr[b*stride_b + q*stride_q + k] */
+    LAMP_MASK_KEY_TOKENS_I64 = 2 /* int64 token ids [B, stride_b]; key k of sample b is blocked iff token == 0 (PAD) */
+};
+
+typedef struct lamp_mask {
+    int32_t kind;
+    int32_t reserved;
+    const void* ptr;
+    int64_t stride_b;
+    int64_t stride_q;
+} lamp_mask;
+
+/* Element strides of the four attention operands, so that one kernel serves both the
+ * reference's head-major (h*B, l, d_k) batches (lamp/SubLayers.py:96-98) and the fused
+ * [B, l, h*d_k] projections written by lamp_mha_fwd without any permute copy. */
+typedef struct lamp_attn_layout {
+    int64_t q_b, q_h, q_r;
+    int64_t k_b, k_h, k_r;
+    int64_t v_b, v_h, v_r;
+    int64_t o_b, o_h, o_r;
+} lamp_attn_layout;
+
+/* Weights of one MultiHeadAttention (lamp/SubLayers.py:46-74), in nn.Linear's native [out, in] layout. */
+typedef struct lamp_mha_weights {
+    const float* w_qs; /* [n_head*d_k, d_model] */
+    const float* w_ks; /* [n_head*d_k, d_model] */
+    const float* w_vs; /* [n_head*d_v, d_model] */
+    const float* fc;   /* [d_model, n_head*d_v]; NULL when n_head == 1 (lamp/SubLayers.py:72-74) */
+    const float* ln_g; /* [d_model] */
+    const float* ln_b; /* [d_model] */
+    int32_t n_head;
+    int32_t present;   /* 0 = this attention block does not exist (no_dec_self_att) */
+} lamp_mha_weights;
+
+/* Weights of one PositionwiseFeedForward (lamp/SubLayers.py:125-131); Conv1d(k=1) weights
+ * [out, in, 1] are read as [out, in]. */
+typedef struct lamp_ffn_weights {
+    const float* w1;   /* [d_inner, d_model] */
+    const float* b1;   /* [d_inner] */
+    const float* w2;   /* [d_model, d_inner] */
+    const float* b2;   /* [d_model] */
+    const float* ln_g; /* [d_model] */
+    const float* ln_b; /* [d_model] */
+} lamp_ffn_weights;
+
+typedef struct lamp_enc_layer {  /* lamp/Layers.py:9-20 */
+    lamp_mha_weights slf_attn;   /* dead compute unless attention maps are requested */
+    lamp_ffn_weights pos_ffn;
+} lamp_enc_layer;
+
+typedef struct lamp_dec_layer {  /* lamp/Layers.py:22-48 */
+    lamp_mha_weights enc_attn;
+    lamp_ffn_weights pos_ffn1;
+    lamp_mha_weights slf_attn;   /* .present == 0 under no_dec_self_att */
+    lamp_ffn_weights pos_ffn2;
+} lamp_dec_layer;
+
+/* The whole graph-encoder / graph-decoder model (lamp/Models.py:18-94).  Host-side struct of
+ * device pointers; enc_layers / dec_layers are host arrays. */
+typedef struct lamp_model {
+    int32_t n_src_vocab, n_position, n_labels;
+    int32_t d_model, d_inner, d_k, d_v;
+    int32_t n_layers_enc, n_layers_dec;
+    int32_t reserved;
+    const float* src_word_emb;  /* [n_src_vocab, d_model]  encoder.src_word_emb.weight */
+    const float* position_enc;  /* [n_position, d_model] or NULL (no_enc_pos_embedding) */
+    const float* tgt_word_emb;  /* [n_labels, d_model]     decoder.tgt_word_emb.weight */
+    const float* w_out;         /* [n_labels, d_model]     tgt_word_proj.linear.weight */
+    const uint8_t* label_mask;  /* [n_labels, n_labels] nonzero = blocked, or NULL ('none') */
+    const lamp_enc_layer* enc_layers;
+    const lamp_dec_layer* dec_layers;
+} lamp_model;
+
+/* Optional extra outputs of lamp_forward (return_attns / int_preds, lamp/Models.py:127-135).
+ * Any pointer (or the whole struct) may be NULL.  Attention maps are (n_head*B, lq, lk) with
+ * index head*B + b, exactly the reference's layout. */
+typedef struct lamp_aux {
+    float* const* enc_self_attn; /* n_layers_enc pointers, each (h*B, T, T) */
+    float* const* dec_self_attn; /* n_layers_dec pointers, each (h2*B, L, L) */
+    float* const* dec_enc_attn;  /* n_layers_dec pointers, each (h*B, L, T) */
+    float* const* int_preds;     /* lamp/Models.py:128-133: one (B, L) per intermediate output but the last */
+    int32_t n_int_preds;
+    int32_t reserved;
+} lamp_aux;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int lamp_version(void);                 /* LAMP_HIP_ABI_VERSION the library was built with */
+const char* lamp_strerror(int status);  /* text for lamp_status / hipError_t values */
+
+/* ---- building blocks ---------------------------------------------------------------------- */
+
+/* nn.Linear / XavierLinear / Conv1d(k=1) (lamp/SubLayers.py:7-13, 91-93, 110, 127-128):
+ *   C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]      (bias, residual may be NULL)
+ * lda/ldw/ldc/ldr are leading dimensions in elements; K, lda, ldw must be multiples of 4. */
+int lamp_linear_fwd(const float* A, int64_t M, int32_t K, int64_t lda,
+                    const float* W, int32_t N, int64_t ldw, const float* bias,
+                    const float* residual, int64_t ldr, int32_t relu,
+                    float* C, int64_t ldc, lamp_stream_t stream);
+
+/* nn.LayerNorm over the last dim, biased variance, eps inside the sqrt (lamp/SubLayers.py:68,130).
+ * y may alias x.  d must be a multiple of 4. */
+int lamp_layernorm_fwd(const float* x, int64_t M, int32_t d, const float* gamma, const float* beta,
+                       float eps, float* y, lamp_stream_t stream);
+
+/* ScaledDotProductAttention.forward (lamp/SubLayers.py:27-43), eval mode:
+ *   S = (Q K^T) * inv_temperature ; S[blocked] = -inf ; P = softmax_k(S) ; O = P V
+ * for B samples x H heads.  `attn` (nullable) receives P as (H*B, lq, lk), index head*B + b.
+ * A fully blocked row yields NaN in O and P, as in the reference.  d_k, d_v <= 128, multiples of 4. */
+int lamp_sdpa_fwd(const float* q, const float* k, const float* v, float* out, float* attn,
+                  int32_t B, int32_t H, int32_t lq, int32_t lk, int32_t d_k, int32_t d_v,
+                  float inv_temperature, const lamp_mask* mask, const lamp_attn_layout* layout,
+                  lamp_stream_t stream);
+
+/* MultiHeadAttention.forward (lamp/SubLayers.py:77-121), eval mode:
+ *   out = LayerNorm( concat_heads(SDPA(xq Wq^T, xkv Wk^T, xkv Wv^T)) Wfc^T + xq )
+ * xq [B, lq, d_model], xkv [B, lk, d_model] (may alias xq), out [B, lq, d_model];
+ * attn nullable (n_head*B, lq, lk).  Workspace: lamp_mha_workspace_bytes(). */
+size_t lamp_mha_workspace_bytes(int32_t B, int32_t lq, int32_t lk, int32_t d_model, int32_t n_head,
+                                int32_t d_k, int32_t d_v);
+int lamp_mha_fwd(const float* xq, const float* xkv, int32_t B, int32_t lq, int32_t lk,
+                 int32_t d_model, int32_t d_k, int32_t d_v, const lamp_mha_weights* w,
+                 const lamp_mask* mask, float* out, float* attn,
+                 void* workspace, size_t workspace_bytes, lamp_stream_t stream);
+
+/* PositionwiseFeedForward.forward (lamp/SubLayers.py:133-142), eval mode:
+ *   out = LayerNorm( relu(x W1^T + b1) W2^T + b2 + x ),  x/out [M, d_model] (out may alias x).
+ * Workspace: M * d_inner floats. */
+size_t lamp_ffn_workspace_bytes(int64_t M, int32_t d_model, int32_t d_inner);
+int lamp_ffn_fwd(const float* x, int64_t M, int32_t d_model, int32_t d_inner,
+                 const lamp_ffn_weights* w, float* out,
+                 void* workspace, size_t workspace_bytes, lamp_stream_t stream);
+
+/* GraphEncoder's input stage (lamp/Encoders.py:66,75): out[t,:] = emb[src_seq[t],:] (+ pos[src_pos[t],:]).
+ * An index outside its table writes NaN into that row (PyTorch would raise; a kernel cannot). */
+int lamp_embed_fwd(const int64_t* src_seq, const int64_t* src_pos, int64_t n_tokens,
+                   const float* emb, int32_t n_vocab, const float* pos_table, int32_t n_position,
+                   int32_t d_model, float* out, lamp_stream_t stream);
+
+/* Label read-out (lamp/Models.py:124-126): logits[b,i] = <y[b,i,:], w_out[i,:]>, i.e. the diagonal
+ * of y . w_out^T without forming the (B, L, L) product. */
+int lamp_diag_logits_fwd(const float* y, const float* w_out, int32_t B, int32_t L, int32_t d_model,
+                         float* logits, lamp_stream_t stream);
+
+/* ---- the whole hot path ------------------------------------------------------------------- */
+
+/* Bytes of workspace lamp_forward needs to process `micro_batch` samples of padded length T at a
+ * time.  lamp_forward splits B into micro-batches of floor(workspace_bytes / bytes(1)) samples. */
+size_t lamp_forward_workspace_bytes(const lamp_model* m, int32_t micro_batch, int32_t T,
+                                    int32_t want_attn);
+
+/* LAMP.forward (lamp/Models.py:110-137) for encoder='graph', decoder='graph', eval mode:
+ *   src_seq, src_pos int64 [B, T]  ->  logits [B, n_labels], enc_output [B, T, d_model].
+ * The encoder self-attention, whose output the reference discards (lamp/Layers.py:16-18), is
+ * computed only when aux->enc_self_attn is given. */
+int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src_pos,
+                 int32_t B, int32_t T, float* logits, float* enc_output, const lamp_aux* aux,
+                 void* workspace, size_t workspace_bytes, lamp_stream_t stream);
+
+/* ---- per-kernel timing (HIP events on the launch stream; used by bench.py's roofline) ------ */
+enum lamp_kernel_class {
+    LAMP_K_EMBED = 0, LAMP_K_GEMM = 1, LAMP_K_ATTN = 2, LAMP_K_LAYERNORM = 3, LAMP_K_DIAG = 4,
+    LAMP_K_COUNT = 5
+};
+int lamp_prof_enable(int32_t on);  /* bracket every launch with a hipEvent pair while on */
+int lamp_prof_reset(void);
+/* Synchronises the recorded events and returns, per class: launches, summed milliseconds, and the
+ * summed algorithmic FLOPs and bytes of those launches (as the launcher computed them). */
+int lamp_prof_read(int32_t kernel_class, int64_t* launches, double* total_ms, double* flops,
+                   double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAMP_HIP_H */

@@ -1,0 +1,316 @@
+"""ctypes binding of liblamp_hip.so -- the only route from the Python modules to the GPU.
+
+There is no fallback: if the shared library is missing or a tensor is not on a HIP device the
+call raises.  PyTorch is used for device memory (``data_ptr()``), the current HIP stream and
+nothing else.  Signatures mirror include/lamp_hip.h one to one.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblamp_hip.so')
+
+LAMP_MASK_NONE, LAMP_MASK_U8, LAMP_MASK_KEY_TOKENS_I64 = 0, 1, 2
+K_EMBED, K_GEMM, K_ATTN, K_LAYERNORM, K_DIAG, K_COUNT = 0, 1, 2, 3, 4, 5
+KERNEL_CLASS_NAMES = ('embed', 'gemm', 'attention', 'layernorm', 'diag_readout')
+
+
+class LampError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = lib().lamp_strerror(status).decode() if _lib is not None else '?'
+        super().__init__('%s failed with status %d: %s' % (where, status, msg))
+
+
+_f32p = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+class Mask(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('reserved', C.c_int32), ('ptr', _vp),
+                ('stride_b', C.c_int64), ('stride_q', C.c_int64)]
+
+
+class AttnLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ('q_b', 'q_h', 'q_r', 'k_b', 'k_h', 'k_r',
+                                         'v_b', 'v_h', 'v_r', 'o_b', 'o_h', 'o_r')]
+
+
+class MhaWeights(C.Structure):
+    _fields_ = [('w_qs', _vp), ('w_ks', _vp), ('w_vs', _vp), ('fc', _vp), ('ln_g', _vp), ('ln_b', _vp),
+                ('n_head', C.c_int32), ('present', C.c_int32)]
+
+
+class FfnWeights(C.Structure):
+    _fields_ = [('w1', _vp), ('b1', _vp), ('w2', _vp), ('b2', _vp), ('ln_g', _vp), ('ln_b', _vp)]
+
+
+class EncLayer(C.Structure):
+    _fields_ = [('slf_attn', MhaWeights), ('pos_ffn', FfnWeights)]
+
+
+class DecLayer(C.Structure):
+    _fields_ = [('enc_attn', MhaWeights), ('pos_ffn1', FfnWeights), ('slf_attn', MhaWeights),
+                ('pos_ffn2', FfnWeights)]
+
+
+class Model(C.Structure):
+    _fields_ = [('n_src_vocab', C.c_int32), ('n_position', C.c_int32), ('n_labels', C.c_int32),
+                ('d_model', C.c_int32), ('d_inner', C.c_int32), ('d_k', C.c_int32), ('d_v', C.c_int32),
+                ('n_layers_enc', C.c_int32), ('n_layers_dec', C.c_int32), ('reserved', C.c_int32),
+                ('src_word_emb', _vp), ('position_enc', _vp), ('tgt_word_emb', _vp), ('w_out', _vp),
+                ('label_mask', _vp), ('enc_layers', C.POINTER(EncLayer)), ('dec_layers', C.POINTER(DecLayer))]
+
+
+class Aux(C.Structure):
+    _fields_ = [('enc_self_attn', C.POINTER(_vp)), ('dec_self_attn', C.POINTER(_vp)),
+                ('dec_enc_attn', C.POINTER(_vp)), ('int_preds', C.POINTER(_vp)),
+                ('n_int_preds', C.c_int32), ('reserved', C.c_int32)]
+
+
+# name -> (restype, argtypes); every function include/lamp_hip.h declares
+_i32, _i64, _sz, _f = C.c_int32, C.c_int64, C.c_size_t, C.c_float
+PROTOTYPES = {
+    'lamp_version': (C.c_int, []),
+    'lamp_strerror': (C.c_char_p, [C.c_int]),
+    'lamp_linear_fwd': (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
+    'lamp_layernorm_fwd': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _f, _vp, _vp]),
+    'lamp_sdpa_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f,
+                                C.POINTER(Mask), C.POINTER(AttnLayout), _vp]),
+    'lamp_mha_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    'lamp_mha_fwd': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(MhaWeights),
+                               C.POINTER(Mask), _vp, _vp, _vp, _sz, _vp]),
+    'lamp_ffn_workspace_bytes': (_sz, [_i64, _i32, _i32]),
+    'lamp_ffn_fwd': (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(FfnWeights), _vp, _vp, _sz, _vp]),
+    'lamp_embed_fwd': (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    'lamp_diag_logits_fwd': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'lamp_forward_workspace_bytes': (_sz, [C.POINTER(Model), _i32, _i32, _i32]),
+    'lamp_forward': (C.c_int, [C.POINTER(Model), _vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(Aux), _vp, _sz, _vp]),
+    'lamp_prof_enable': (C.c_int, [_i32]),
+    'lamp_prof_reset': (C.c_int, []),
+    'lamp_prof_read': (C.c_int, [_i32, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load liblamp_hip.so once.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        'lamp_amd: %s is missing -- build it with `python -m lamp_amd.build` '
+                        '(hipcc, gfx950).  There is no CPU or PyTorch fallback.' % LIB_PATH)
+                handle = C.CDLL(LIB_PATH)
+                for name, (res, args) in PROTOTYPES.items():
+                    fn = getattr(handle, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                if handle.lamp_version() != 1:
+                    raise RuntimeError('lamp_amd: ABI version mismatch in ' + LIB_PATH)
+                _lib = handle
+    return _lib
+
+
+def check(status, where):
+    if status != 0:
+        raise LampError(status, where)
+
+
+# ------------------------------------------------------------------ tensor plumbing
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('lamp_amd runs on an MI355X HIP device only; got a %s tensor (%s). '
+                               'There is no CPU path.' % (t.device, tuple(t.shape)))
+
+
+def f32c(t):
+    """fp32, contiguous view/copy of t (device resident)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_ws = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (the library itself never allocates)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def make_mask(mask, B, lq, lk):
+    """Torch bool/uint8 mask broadcastable to (B, lq, lk) -> (Mask struct, keepalive tensor)."""
+    if mask is None:
+        return None, None
+    require_device(mask)
+    m = mask
+    if m.dtype == torch.bool:
+        m = m.view(torch.uint8) if m.is_contiguous() or m.stride(-1) == 1 else m.contiguous().view(torch.uint8)
+    elif m.dtype != torch.uint8:
+        m = (m != 0).view(torch.uint8)
+    if m.dim() == 2:
+        m = m.unsqueeze(0)
+    if m.dim() != 3 or m.size(-1) != lk or m.size(1) not in (1, lq) or m.size(0) not in (1, B):
+        raise ValueError('attention mask of shape %s does not broadcast to (%d, %d, %d)' %
+                         (tuple(mask.shape), B, lq, lk))
+    if m.stride(-1) != 1 and lk > 1:
+        m = m.contiguous()
+    sb = 0 if m.size(0) == 1 else m.stride(0)
+    sq = 0 if m.size(1) == 1 else m.stride(1)
+    return Mask(LAMP_MASK_U8, 0, m.data_ptr(), sb, sq), m
+
+
+def key_token_mask(src_seq, T):
+    """Key-padding mask straight from the int64 token ids (blocked iff token == PAD == 0)."""
+    require_device(src_seq)
+    s = src_seq if src_seq.dtype == torch.int64 else src_seq.long()
+    if s.stride(-1) != 1:
+        s = s.contiguous()
+    return Mask(LAMP_MASK_KEY_TOKENS_I64, 0, s.data_ptr(), s.stride(0), 0), s
+
+
+# ------------------------------------------------------------------ thin wrappers
+def linear(x, weight, bias=None, residual=None, relu=False):
+    require_device(x, weight, bias, residual)
+    x2 = f32c(x).reshape(-1, x.size(-1))
+    w = f32c(weight).reshape(weight.size(0), -1)
+    M, K = x2.shape
+    N = w.size(0)
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    r = f32c(residual).reshape(M, N) if residual is not None else None
+    b = f32c(bias) if bias is not None else None
+    check(lib().lamp_linear_fwd(ptr(x2), M, K, K, ptr(w), N, K, ptr(b), ptr(r), N, int(relu), ptr(out), N,
+                                stream()), 'lamp_linear_fwd')
+    return out.view(*x.shape[:-1], N)
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    require_device(x, gamma, beta)
+    x2 = f32c(x).reshape(-1, x.size(-1))
+    out = torch.empty_like(x2)
+    check(lib().lamp_layernorm_fwd(ptr(x2), x2.size(0), x2.size(1), ptr(f32c(gamma)), ptr(f32c(beta)),
+                                   float(eps), ptr(out), stream()), 'lamp_layernorm_fwd')
+    return out.view(x.shape)
+
+
+def sdpa(q, k, v, mask, inv_temperature, need_attn=True):
+    """q (N, lq, dk), k (N, lk, dk), v (N, lk, dv) head-major batches as in the reference."""
+    require_device(q, k, v)
+    q, k, v = f32c(q), f32c(k), f32c(v)
+    N, lq, dk = q.shape
+    lk, dv = k.size(1), v.size(2)
+    out = torch.empty((N, lq, dv), dtype=torch.float32, device=q.device)
+    attn = torch.empty((N, lq, lk), dtype=torch.float32, device=q.device) if need_attn else None
+    mstruct, keep = make_mask(mask, N, lq, lk)
+    lay = AttnLayout(lq * dk, 0, dk, lk * dk, 0, dk, lk * dv, 0, dv, lq * dv, 0, dv)
+    check(lib().lamp_sdpa_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(attn), N, 1, lq, lk, dk, dv,
+                              float(inv_temperature), C.byref(mstruct) if mstruct is not None else None,
+                              C.byref(lay), stream()), 'lamp_sdpa_fwd')
+    del keep
+    return out, attn
+
+
+def mha_weights(mod):
+    """MhaWeights struct for a lamp_amd MultiHeadAttention module (pointers into its parameters)."""
+    fc = getattr(mod, 'fc', None)
+    return MhaWeights(ptr(mod.w_qs.weight), ptr(mod.w_ks.weight), ptr(mod.w_vs.weight),
+                      ptr(fc.weight) if fc is not None else 0, ptr(mod.layer_norm.weight),
+                      ptr(mod.layer_norm.bias), mod.n_head, 1)
+
+
+def ffn_weights(mod):
+    return FfnWeights(ptr(mod.w_1.weight), ptr(mod.w_1.bias), ptr(mod.w_2.weight), ptr(mod.w_2.bias),
+                      ptr(mod.layer_norm.weight), ptr(mod.layer_norm.bias))
+
+
+def mha(xq, xkv, weights, d_k, d_v, mask_struct, need_attn):
+    require_device(xq, xkv)
+    xq, xkv = f32c(xq), f32c(xkv)
+    B, lq, d = xq.shape
+    lk = xkv.size(1)
+    h = weights.n_head
+    out = torch.empty_like(xq)
+    attn = torch.empty((h * B, lq, lk), dtype=torch.float32, device=xq.device) if need_attn else None
+    nbytes = lib().lamp_mha_workspace_bytes(B, lq, lk, d, h, d_k, d_v)
+    ws = workspace(nbytes, xq.device)
+    check(lib().lamp_mha_fwd(ptr(xq), ptr(xkv), B, lq, lk, d, d_k, d_v, C.byref(weights),
+                             C.byref(mask_struct) if mask_struct is not None else None, ptr(out), ptr(attn),
+                             ptr(ws), ws.numel(), stream()), 'lamp_mha_fwd')
+    return out, attn
+
+
+def ffn(x, weights, d_inner):
+    require_device(x)
+    x2 = f32c(x).reshape(-1, x.size(-1))
+    M, d = x2.shape
+    out = torch.empty_like(x2)
+    nbytes = lib().lamp_ffn_workspace_bytes(M, d, d_inner)
+    ws = workspace(nbytes, x.device)
+    check(lib().lamp_ffn_fwd(ptr(x2), M, d, d_inner, C.byref(weights), ptr(out), ptr(ws), ws.numel(),
+                             stream()), 'lamp_ffn_fwd')
+    return out.view(x.shape)
+
+
+def embed(src_seq, src_pos, emb, pos_table):
+    require_device(src_seq, src_pos, emb, pos_table)
+    seq = src_seq.long().contiguous()
+    pos = src_pos.long().contiguous() if pos_table is not None else None
+    d = emb.size(1)
+    out = torch.empty(tuple(seq.shape) + (d,), dtype=torch.float32, device=emb.device)
+    check(lib().lamp_embed_fwd(ptr(seq), ptr(pos), seq.numel(), ptr(f32c(emb)), emb.size(0),
+                               ptr(f32c(pos_table)) if pos_table is not None else 0,
+                               pos_table.size(0) if pos_table is not None else 0, d, ptr(out), stream()),
+          'lamp_embed_fwd')
+    return out
+
+
+def diag_logits(y, w_out):
+    require_device(y, w_out)
+    y = f32c(y)
+    B, L, d = y.shape
+    out = torch.empty((B, L), dtype=torch.float32, device=y.device)
+    check(lib().lamp_diag_logits_fwd(ptr(y), ptr(f32c(w_out)), B, L, d, ptr(out), stream()),
+          'lamp_diag_logits_fwd')
+    return out
+
+
+# ------------------------------------------------------------------ profiling
+def prof_enable(on=True):
+    check(lib().lamp_prof_enable(int(bool(on))), 'lamp_prof_enable')
+
+
+def prof_reset():
+    check(lib().lamp_prof_reset(), 'lamp_prof_reset')
+
+
+def prof_read():
+    """-> {class_name: dict(launches, ms, flops, bytes)} for everything recorded since the last reset."""
+    out = {}
+    for cls, name in enumerate(KERNEL_CLASS_NAMES):
+        n, ms, fl, by = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        check(lib().lamp_prof_read(cls, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), 'lamp_prof_read')
+        out[name] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+    return out

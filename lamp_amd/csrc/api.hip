@@ -1,0 +1,499 @@
+// C-ABI entry points of liblamp_hip.so (see include/lamp_hip.h) and the whole-forward launcher.
+//
+// Host-side only: argument validation, workspace carving and the launch sequence.  No device
+// memory is allocated here, no pointer is retained, nothing synchronises (except lamp_prof_read).
+#include <mutex>
+#include <vector>
+
+#include "lamp_kernels.h"
+
+namespace lamp {
+
+// ------------------------------------------------------------------ profiling
+namespace {
+struct ProfRec {
+    int cls;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;          // records in use
+std::vector<hipEvent_t> g_event_pool; // recycled events
+constexpr size_t PROF_MAX = 1 << 16;
+
+hipEvent_t take_event() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+ProfScope::ProfScope(int kernel_class, double flops, double bytes, hipStream_t stream) : idx(-1), s(stream) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on || g_prof.size() >= PROF_MAX) return;
+    ProfRec r{kernel_class, flops, bytes, take_event(), take_event()};
+    if (!r.e0 || !r.e1) return;
+    (void)hipEventRecord(r.e0, s);
+    idx = int(g_prof.size());
+    g_prof.push_back(r);
+}
+
+ProfScope::~ProfScope() {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (idx < int(g_prof.size())) (void)hipEventRecord(g_prof[idx].e1, s);
+}
+
+// ------------------------------------------------------------------ helpers
+#define LAMP_CK(expr)            \
+    do {                         \
+        int _e = (expr);         \
+        if (_e != 0) return _e;  \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {
+    char* base;
+    size_t off, cap;
+    bool ok;
+    Carver(void* p, size_t bytes) : base(static_cast<char*>(p)), off(0), cap(bytes), ok(true) {}
+    float* take(size_t n_floats) {
+        const size_t b = align_up(n_floats * sizeof(float), 256);
+        if (off + b > cap) {
+            ok = false;
+            return nullptr;
+        }
+        float* r = reinterpret_cast<float*>(base + off);
+        off += b;
+        return r;
+    }
+};
+
+static int linear(const float* A, int64_t M, int K, int64_t lda, const float* const* W, int nseg, int N,
+                  int64_t ldw, const float* const* bias, const float* R, int64_t ldr, int64_t r_mod, int relu,
+                  float* const* C, int64_t ldc, hipStream_t s) {
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.M = M; p.K = K; p.N = N; p.nseg = nseg; p.ldw = ldw; p.ldc = ldc;
+    p.R = R; p.ldr = ldr; p.r_mod = r_mod; p.relu = relu;
+    for (int i = 0; i < nseg; ++i) {
+        p.W[i] = W[i];
+        p.bias[i] = bias ? bias[i] : nullptr;
+        p.C[i] = C[i];
+    }
+    return launch_gemm(p, s);
+}
+
+static int check_mask(const lamp_mask* m) {
+    if (!m) return 0;
+    if (m->kind != LAMP_MASK_NONE && m->kind != LAMP_MASK_U8 && m->kind != LAMP_MASK_KEY_TOKENS_I64)
+        return LAMP_E_UNSUPPORTED;
+    if (m->kind != LAMP_MASK_NONE && !m->ptr) return LAMP_E_NULL;
+    return 0;
+}
+
+// Scratch of one MultiHeadAttention call on B samples.
+struct MhaScratch {
+    float *Q, *K, *V, *A;
+};
+
+// MultiHeadAttention.forward (lamp/SubLayers.py:77-121).  `xq_shared`: xq is ONE [lq, d] block used
+// by every sample (decoder layer 0: the label embeddings) -- its projection is then
+// computed once, and the residual is read modulo lq.  `out` may alias xq unless xq_shared.
+// `out == nullptr` computes the attention map only (the reference's dead encoder self-attention).
+static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, int lq, int lk, int d, int dk,
+                    int dv, const lamp_mha_weights& w, const lamp_mask* mask, float* out, float* attn,
+                    const MhaScratch& sc, hipStream_t s) {
+    const int h = w.n_head;
+    if (h < 1 || dk < 1 || dv < 1) return LAMP_E_DIMS;
+    if (!w.w_qs || !w.w_ks || !w.w_vs || (out && (!w.ln_g || !w.ln_b))) return LAMP_E_NULL;
+    if (h == 1 && out && dv != d) return LAMP_E_DIMS;  // no fc: O is added to the residual directly
+    if (h > 1 && out && !w.fc) return LAMP_E_NULL;
+    const int hdk = h * dk, hdv = h * dv;
+    const int64_t Mq = xq_shared ? lq : int64_t(B) * lq;
+    const int64_t Mk = int64_t(B) * lk;
+    const bool self = (xq == xkv) && !xq_shared && lq == lk;
+    const bool need_v = out != nullptr;
+
+    if (self && hdk == hdv && need_v) {
+        const float* W[3] = {w.w_qs, w.w_ks, w.w_vs};
+        float* C[3] = {sc.Q, sc.K, sc.V};
+        LAMP_CK(linear(xq, Mq, d, d, W, 3, hdk, d, nullptr, nullptr, 0, 0, 0, C, hdk, s));
+    } else {
+        {
+            const float* W[1] = {w.w_qs};
+            float* C[1] = {sc.Q};
+            LAMP_CK(linear(xq, Mq, d, d, W, 1, hdk, d, nullptr, nullptr, 0, 0, 0, C, hdk, s));
+        }
+        if (need_v && hdk == hdv) {
+            const float* W[2] = {w.w_ks, w.w_vs};
+            float* C[2] = {sc.K, sc.V};
+            LAMP_CK(linear(xkv, Mk, d, d, W, 2, hdk, d, nullptr, nullptr, 0, 0, 0, C, hdk, s));
+        } else {
+            const float* Wk[1] = {w.w_ks};
+            float* Ck[1] = {sc.K};
+            LAMP_CK(linear(xkv, Mk, d, d, Wk, 1, hdk, d, nullptr, nullptr, 0, 0, 0, Ck, hdk, s));
+            if (need_v) {
+                const float* Wv[1] = {w.w_vs};
+                float* Cv[1] = {sc.V};
+                LAMP_CK(linear(xkv, Mk, d, d, Wv, 1, hdv, d, nullptr, nullptr, 0, 0, 0, Cv, hdv, s));
+            }
+        }
+    }
+
+    AttnParams a{};
+    a.Q = sc.Q; a.K = sc.K; a.V = need_v ? sc.V : nullptr; a.O = need_v ? sc.A : nullptr; a.P = attn;
+    a.B = B; a.H = h; a.lq = lq; a.lk = lk; a.dk = dk; a.dv = dv;
+    a.lay.q_b = xq_shared ? 0 : int64_t(lq) * hdk; a.lay.q_h = dk; a.lay.q_r = hdk;
+    a.lay.k_b = int64_t(lk) * hdk; a.lay.k_h = dk; a.lay.k_r = hdk;
+    a.lay.v_b = int64_t(lk) * hdv; a.lay.v_h = dv; a.lay.v_r = hdv;
+    a.lay.o_b = int64_t(lq) * hdv; a.lay.o_h = dv; a.lay.o_r = hdv;
+    a.scale_log2e = float(1.4426950408889634 / sqrt(double(dk)));
+    a.mask_kind = mask ? mask->kind : LAMP_MASK_NONE;
+    a.mask = mask ? mask->ptr : nullptr;
+    a.m_sb = mask ? mask->stride_b : 0;
+    a.m_sq = mask ? mask->stride_q : 0;
+    LAMP_CK(launch_attn(a, s));
+    if (!out) return 0;
+
+    const int64_t M = int64_t(B) * lq;
+    const int64_t r_mod = xq_shared ? lq : 0;
+    if (h > 1) {
+        const float* W[1] = {w.fc};
+        float* C[1] = {out};
+        LAMP_CK(linear(sc.A, M, hdv, hdv, W, 1, d, hdv, nullptr, xq, d, r_mod, 0, C, d, s));
+        return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, out, s);
+    }
+    return launch_layernorm(sc.A, M, d, w.ln_g, w.ln_b, 1e-5f, xq, r_mod, out, s);
+}
+
+// PositionwiseFeedForward.forward (lamp/SubLayers.py:133-142); out may alias x.
+static int ffn_core(const float* x, int64_t M, int d, int dff, const lamp_ffn_weights& w, float* out,
+                    float* hidden, hipStream_t s) {
+    if (!w.w1 || !w.b1 || !w.w2 || !w.b2 || !w.ln_g || !w.ln_b) return LAMP_E_NULL;
+    {
+        const float* W[1] = {w.w1};
+        const float* b[1] = {w.b1};
+        float* C[1] = {hidden};
+        LAMP_CK(linear(x, M, d, d, W, 1, dff, d, b, nullptr, 0, 0, 1, C, dff, s));
+    }
+    {
+        const float* W[1] = {w.w2};
+        const float* b[1] = {w.b2};
+        float* C[1] = {out};
+        LAMP_CK(linear(hidden, M, dff, dff, W, 1, d, dff, b, x, d, 0, 0, C, d, s));
+    }
+    return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, out, s);
+}
+
+static size_t mha_ws_floats(int64_t B, int64_t lq, int64_t lk, int hdk, int hdv) {
+    // Q, K, V, A -- each rounded to 256 bytes by the carver
+    auto r = [](size_t n) { return align_up(n * sizeof(float), 256) / sizeof(float); };
+    return r(size_t(B) * lq * hdk) + r(size_t(B) * lk * hdk) + r(size_t(B) * lk * hdv) + r(size_t(B) * lq * hdv);
+}
+
+}  // namespace lamp
+
+using namespace lamp;
+
+// ================================================================== C ABI
+extern "C" {
+
+int lamp_version(void) { return LAMP_HIP_ABI_VERSION; }
+
+const char* lamp_strerror(int status) {
+    switch (status) {
+        case LAMP_OK: return "ok";
+        case LAMP_E_DIMS: return "lamp: non-positive or inconsistent dimensions";
+        case LAMP_E_ALIGN: return "lamp: pointer or leading dimension not 16-byte aligned";
+        case LAMP_E_WORKSPACE: return "lamp: workspace too small";
+        case LAMP_E_UNSUPPORTED: return "lamp: configuration not supported by this build";
+        case LAMP_E_NULL: return "lamp: required pointer is NULL";
+        default: break;
+    }
+    if (status > 0) return hipGetErrorString(hipError_t(status));
+    return "lamp: unknown status";
+}
+
+int lamp_linear_fwd(const float* A, int64_t M, int32_t K, int64_t lda, const float* W, int32_t N, int64_t ldw,
+                    const float* bias, const float* residual, int64_t ldr, int32_t relu, float* C, int64_t ldc,
+                    lamp_stream_t stream) {
+    const float* Ws[1] = {W};
+    const float* bs[1] = {bias};
+    float* Cs[1] = {C};
+    if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return LAMP_E_DIMS;
+    return linear(A, M, K, lda, Ws, 1, N, ldw, bs, residual, ldr, 0, relu, Cs, ldc, hipStream_t(stream));
+}
+
+int lamp_layernorm_fwd(const float* x, int64_t M, int32_t d, const float* gamma, const float* beta, float eps,
+                       float* y, lamp_stream_t stream) {
+    return launch_layernorm(x, M, d, gamma, beta, eps, nullptr, 0, y, hipStream_t(stream));
+}
+
+int lamp_sdpa_fwd(const float* q, const float* k, const float* v, float* out, float* attn, int32_t B, int32_t H,
+                  int32_t lq, int32_t lk, int32_t d_k, int32_t d_v, float inv_temperature, const lamp_mask* mask,
+                  const lamp_attn_layout* layout, lamp_stream_t stream) {
+    if (!layout) return LAMP_E_NULL;
+    LAMP_CK(check_mask(mask));
+    AttnParams a{};
+    a.Q = q; a.K = k; a.V = v; a.O = out; a.P = attn;
+    a.B = B; a.H = H; a.lq = lq; a.lk = lk; a.dk = d_k; a.dv = d_v;
+    a.lay = *layout;
+    a.scale_log2e = float(double(inv_temperature) * 1.4426950408889634);
+    a.mask_kind = mask ? mask->kind : LAMP_MASK_NONE;
+    a.mask = mask ? mask->ptr : nullptr;
+    a.m_sb = mask ? mask->stride_b : 0;
+    a.m_sq = mask ? mask->stride_q : 0;
+    return launch_attn(a, hipStream_t(stream));
+}
+
+size_t lamp_mha_workspace_bytes(int32_t B, int32_t lq, int32_t lk, int32_t d_model, int32_t n_head, int32_t d_k,
+                                int32_t d_v) {
+    (void)d_model;
+    if (B <= 0 || lq <= 0 || lk <= 0 || n_head <= 0 || d_k <= 0 || d_v <= 0) return 0;
+    return mha_ws_floats(B, lq, lk, n_head * d_k, n_head * d_v) * sizeof(float);
+}
+
+int lamp_mha_fwd(const float* xq, const float* xkv, int32_t B, int32_t lq, int32_t lk, int32_t d_model,
+                 int32_t d_k, int32_t d_v, const lamp_mha_weights* w, const lamp_mask* mask, float* out,
+                 float* attn, void* workspace, size_t workspace_bytes, lamp_stream_t stream) {
+    if (!xq || !xkv || !w || !out || !workspace) return LAMP_E_NULL;
+    if (B <= 0 || lq <= 0 || lk <= 0 || d_model <= 0 || d_k <= 0 || d_v <= 0 || w->n_head <= 0) return LAMP_E_DIMS;
+    if (d_model & 3) return LAMP_E_UNSUPPORTED;
+    LAMP_CK(check_mask(mask));
+    const int hdk = w->n_head * d_k, hdv = w->n_head * d_v;
+    Carver c(workspace, workspace_bytes);
+    MhaScratch sc;
+    sc.Q = c.take(size_t(B) * lq * hdk);
+    sc.K = c.take(size_t(B) * lk * hdk);
+    sc.V = c.take(size_t(B) * lk * hdv);
+    sc.A = c.take(size_t(B) * lq * hdv);
+    if (!c.ok) return LAMP_E_WORKSPACE;
+    return mha_core(xq, false, xkv, B, lq, lk, d_model, d_k, d_v, *w, mask, out, attn, sc, hipStream_t(stream));
+}
+
+size_t lamp_ffn_workspace_bytes(int64_t M, int32_t d_model, int32_t d_inner) {
+    (void)d_model;
+    if (M <= 0 || d_inner <= 0) return 0;
+    return align_up(size_t(M) * d_inner * sizeof(float), 256);
+}
+
+int lamp_ffn_fwd(const float* x, int64_t M, int32_t d_model, int32_t d_inner, const lamp_ffn_weights* w,
+                 float* out, void* workspace, size_t workspace_bytes, lamp_stream_t stream) {
+    if (!x || !w || !out || !workspace) return LAMP_E_NULL;
+    if (M <= 0 || d_model <= 0 || d_inner <= 0) return LAMP_E_DIMS;
+    if ((d_model & 3) || (d_inner & 3)) return LAMP_E_UNSUPPORTED;
+    if (workspace_bytes < size_t(M) * d_inner * sizeof(float)) return LAMP_E_WORKSPACE;
+    return ffn_core(x, M, d_model, d_inner, *w, out, static_cast<float*>(workspace), hipStream_t(stream));
+}
+
+int lamp_embed_fwd(const int64_t* src_seq, const int64_t* src_pos, int64_t n_tokens, const float* emb,
+                   int32_t n_vocab, const float* pos_table, int32_t n_position, int32_t d_model, float* out,
+                   lamp_stream_t stream) {
+    return launch_embed(src_seq, src_pos, n_tokens, emb, n_vocab, pos_table, n_position, d_model, out,
+                        hipStream_t(stream));
+}
+
+int lamp_diag_logits_fwd(const float* y, const float* w_out, int32_t B, int32_t L, int32_t d_model,
+                         float* logits, lamp_stream_t stream) {
+    return launch_diag(y, w_out, B, L, d_model, logits, hipStream_t(stream));
+}
+
+// ------------------------------------------------------------------ whole forward
+static int model_heads(const lamp_model* m, int* h_max) {
+    int h = 1;
+    for (int i = 0; i < m->n_layers_enc; ++i) h = h > m->enc_layers[i].slf_attn.n_head ? h : m->enc_layers[i].slf_attn.n_head;
+    for (int i = 0; i < m->n_layers_dec; ++i) {
+        const lamp_dec_layer& l = m->dec_layers[i];
+        h = h > l.enc_attn.n_head ? h : l.enc_attn.n_head;
+        if (l.slf_attn.present) h = h > l.slf_attn.n_head ? h : l.slf_attn.n_head;
+    }
+    *h_max = h;
+    return 0;
+}
+
+struct FwdPlan {
+    size_t fixed_floats;       // independent of the micro-batch
+    size_t per_sample_floats;  // times micro-batch
+    int R;                     // rows per sample of the widest activation
+    int hdk, hdv;
+};
+
+static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
+    if (!m) return LAMP_E_NULL;
+    if (m->d_model <= 0 || m->d_inner <= 0 || m->d_k <= 0 || m->d_v <= 0 || m->n_labels <= 0 || T <= 0 ||
+        m->n_layers_enc < 0 || m->n_layers_dec < 0)
+        return LAMP_E_DIMS;
+    if ((m->n_layers_enc && !m->enc_layers) || (m->n_layers_dec && !m->dec_layers)) return LAMP_E_NULL;
+    int h = 1;
+    model_heads(m, &h);
+    const int L = m->n_labels;
+    const int R = T > L ? T : L;
+    pl->R = R;
+    pl->hdk = h * m->d_k;
+    pl->hdv = h * m->d_v;
+    const int Rq = want_attn ? R : L;  // the Q / A buffers only see encoder rows when maps are wanted
+    // + 64 floats of slack per region for the carver's 256-byte rounding
+    pl->fixed_floats = 64 * 8;
+    pl->per_sample_floats = size_t(R) * m->d_inner + size_t(Rq) * pl->hdk + size_t(R) * pl->hdk +
+                            size_t(R) * pl->hdv + size_t(Rq) * pl->hdv + size_t(L) * m->d_model;
+    return 0;
+}
+
+size_t lamp_forward_workspace_bytes(const lamp_model* m, int32_t micro_batch, int32_t T, int32_t want_attn) {
+    FwdPlan pl;
+    if (micro_batch <= 0 || make_plan(m, T, want_attn, &pl) != 0) return 0;
+    return (pl.fixed_floats + pl.per_sample_floats * size_t(micro_batch)) * sizeof(float);
+}
+
+int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src_pos, int32_t B, int32_t T,
+                 float* logits, float* enc_output, const lamp_aux* aux, void* workspace, size_t workspace_bytes,
+                 lamp_stream_t stream) {
+    hipStream_t s = hipStream_t(stream);
+    if (!m || !src_seq || !logits || !enc_output || !workspace) return LAMP_E_NULL;
+    if (B <= 0 || T <= 0) return LAMP_E_DIMS;
+    if (!m->src_word_emb || !m->tgt_word_emb || !m->w_out) return LAMP_E_NULL;
+    if (m->position_enc && !src_pos) return LAMP_E_NULL;
+    const bool want_enc_attn = aux && aux->enc_self_attn;
+    FwdPlan pl;
+    LAMP_CK(make_plan(m, T, want_enc_attn, &pl));
+    const int d = m->d_model, dff = m->d_inner, dk = m->d_k, dv = m->d_v, L = m->n_labels;
+    if ((d & 3) || (dff & 3) || (dk & 3) || (dv & 3)) return LAMP_E_UNSUPPORTED;
+
+    const size_t ws_floats = workspace_bytes / sizeof(float);
+    if (ws_floats < pl.fixed_floats + pl.per_sample_floats) return LAMP_E_WORKSPACE;
+    int64_t mb = int64_t((ws_floats - pl.fixed_floats) / pl.per_sample_floats);
+    if (mb > B) mb = B;
+    if (mb > 65535) mb = 65535;  // grid.z of the attention launch
+
+    Carver c(workspace, workspace_bytes);
+    const int Rq = want_enc_attn ? pl.R : L;
+    float* H = c.take(size_t(mb) * pl.R * dff);
+    MhaScratch sc;
+    sc.Q = c.take(size_t(mb) * Rq * pl.hdk);
+    sc.K = c.take(size_t(mb) * pl.R * pl.hdk);
+    sc.V = c.take(size_t(mb) * pl.R * pl.hdv);
+    sc.A = c.take(size_t(mb) * Rq * pl.hdv);
+    float* Y = c.take(size_t(mb) * L * d);
+    if (!c.ok) {
+        // rounding slack exhausted: retry with one sample fewer
+        if (mb <= 1) return LAMP_E_WORKSPACE;
+        --mb;
+        c = Carver(workspace, workspace_bytes);
+        H = c.take(size_t(mb) * pl.R * dff);
+        sc.Q = c.take(size_t(mb) * Rq * pl.hdk);
+        sc.K = c.take(size_t(mb) * pl.R * pl.hdk);
+        sc.V = c.take(size_t(mb) * pl.R * pl.hdv);
+        sc.A = c.take(size_t(mb) * Rq * pl.hdv);
+        Y = c.take(size_t(mb) * L * d);
+        if (!c.ok) return LAMP_E_WORKSPACE;
+    }
+
+    for (int64_t b0 = 0; b0 < B; b0 += mb) {
+        const int nb = int(B - b0 < mb ? B - b0 : mb);
+        const int64_t* seq = src_seq + b0 * T;
+        const int64_t* pos = src_pos ? src_pos + b0 * T : nullptr;
+        float* x = enc_output + b0 * int64_t(T) * d;  // encoder state lives in the output buffer
+        const int64_t Me = int64_t(nb) * T;
+
+        // ---- GraphEncoder.forward (lamp/Encoders.py:64-110) ----
+        LAMP_CK(launch_embed(seq, pos, Me, m->src_word_emb, m->n_src_vocab, m->position_enc, m->n_position, d, x, s));
+        lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq, T, 0};
+        for (int i = 0; i < m->n_layers_enc; ++i) {
+            const lamp_enc_layer& l = m->enc_layers[i];
+            if (want_enc_attn && aux->enc_self_attn[i]) {
+                // lamp/Layers.py:16 -- only the attention map of this block is ever observable
+                float* P = aux->enc_self_attn[i];
+                // maps are (h*B, T, T) over the WHOLE batch: write this micro-batch's samples in place
+                if (nb != B) return LAMP_E_UNSUPPORTED;  // maps need the batch in one micro-batch
+                LAMP_CK(mha_core(x, false, x, nb, T, T, d, dk, dv, l.slf_attn, &pad_mask, nullptr, P, sc, s));
+            }
+            LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s));  // lamp/Layers.py:18
+        }
+
+        // ---- GraphDecoder.forward (lamp/Decoders.py:127-163) ----
+        lamp_mask label_mask{m->label_mask ? LAMP_MASK_U8 : LAMP_MASK_NONE, 0, m->label_mask, 0, L};
+        const int64_t Md = int64_t(nb) * L;
+        int n_int = 0;
+        auto int_pred = [&](void) -> int {
+            if (aux && aux->int_preds && n_int < aux->n_int_preds && aux->int_preds[n_int])
+                LAMP_CK(launch_diag(Y, m->w_out, nb, L, d, aux->int_preds[n_int] + b0 * L, s));
+            ++n_int;
+            return 0;
+        };
+        for (int i = 0; i < m->n_layers_dec; ++i) {
+            const lamp_dec_layer& l = m->dec_layers[i];
+            float* Penc = (aux && aux->dec_enc_attn) ? aux->dec_enc_attn[i] : nullptr;
+            float* Pslf = (aux && aux->dec_self_attn) ? aux->dec_self_attn[i] : nullptr;
+            if ((Penc || Pslf) && nb != B) return LAMP_E_UNSUPPORTED;
+            // input->label messages (lamp/Layers.py:35); layer 0's query is the label table itself
+            if (i == 0)
+                LAMP_CK(mha_core(m->tgt_word_emb, true, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sc, s));
+            else
+                LAMP_CK(mha_core(Y, false, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sc, s));
+            LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn1, Y, H, s));  // lamp/Layers.py:36
+            if (l.slf_attn.present) {
+                LAMP_CK(int_pred());  // dec_output_int, lamp/Decoders.py:149-151
+                // label->label messages over the label graph (lamp/Layers.py:40)
+                LAMP_CK(mha_core(Y, false, Y, nb, L, L, d, dk, dv, l.slf_attn, &label_mask, Y, Pslf, sc, s));
+            }
+            LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn2, Y, H, s));  // lamp/Layers.py:45
+            if (i + 1 < m->n_layers_dec) LAMP_CK(int_pred());       // all but the last (lamp/Models.py:130)
+        }
+        if (m->n_layers_dec == 0) return LAMP_E_DIMS;
+
+        // ---- read-out (lamp/Models.py:124-126) ----
+        LAMP_CK(launch_diag(Y, m->w_out, nb, L, d, logits + b0 * L, s));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ profiling ABI
+int lamp_prof_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int lamp_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) {
+        (void)hipEventSynchronize(r.e1);
+        g_event_pool.push_back(r.e0);
+        g_event_pool.push_back(r.e1);
+    }
+    g_prof.clear();
+    return 0;
+}
+
+int lamp_prof_read(int32_t kernel_class, int64_t* launches, double* total_ms, double* flops, double* bytes) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int64_t n = 0;
+    double ms = 0, fl = 0, by = 0;
+    for (auto& r : g_prof) {
+        if (r.cls != kernel_class) continue;
+        hipError_t e = hipEventSynchronize(r.e1);
+        if (e != hipSuccess) return int(e);
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, r.e0, r.e1);
+        if (e != hipSuccess) return int(e);
+        ms += t;
+        fl += r.flops;
+        by += r.bytes;
+        ++n;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (flops) *flops = fl;
+    if (bytes) *bytes = by;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+// fp32 GEMM  C = act(A . W^T + bias) + R  on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Both operands are K-contiguous ("NT"): A is [M, K] activations, W is nn.Linear's native
+// [N, K].  A BMxBNxBK block tile is staged global -> registers -> LDS (double buffered, one
+// barrier per K step, next tile's global loads in flight under the MFMAs); each 64-lane wave owns
+// a (MI*32)x(NI*32) sub-tile held in MI*NI 32x32 accumulators.
+//
+// Fragment trick: the 32x32x2 MFMA takes ONE f32 per lane for A and B -- lane l supplies
+// A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31].  Any permutation of k is legal as long as A and B use
+// the same one, so each lane reads 4 CONSECUTIVE k of its row with one ds_read_b128
+// (k = 8c + 4*(l>>5) + j) and feeds component j to MFMA step j: one 16-byte LDS read per four
+// MFMAs per operand instead of four 4-byte reads.  LDS rows are padded by 4 floats, which makes
+// the b128 fragment reads and the b128 staging writes bank-conflict free (row stride 36 floats =
+// 9 sixteen-byte slots, odd => the 16 rows of a lane group land on 16 distinct slots).
+//
+// The k-accumulation order of every output element is fixed by (K, BK) alone -- never by M, the
+// grid or the batch -- so a sample's result is bit-identical however the batch is sharded.
+#include "lamp_kernels.h"
+
+namespace lamp {
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+struct GemmTile {
+    static constexpr int NT = WAVES_M * WAVES_N * 64;
+    static constexpr int WTM = BM / WAVES_M;
+    static constexpr int WTN = BN / WAVES_N;
+    static constexpr int MI = WTM / 32;
+    static constexpr int NI = WTN / 32;
+    static constexpr int LDS_STRIDE = BK + 4;
+    static constexpr int A_LD = BM * BK / 4 / NT;  // float4 loads per thread per tile
+    static constexpr int B_LD = BN * BK / 4 / NT;
+    static constexpr size_t LDS_BYTES = size_t(2) * (BM + BN) * LDS_STRIDE * sizeof(float);
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
+    static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "staging must divide evenly");
+    static_assert(BK % 8 == 0, "BK must be a multiple of 8");
+};
+
+// Workgroup id -> tile id such that each XCD (block b runs on XCD b % 8) works on a contiguous
+// range of tiles: tiles that share an A row-panel hit the same 4 MiB L2.  Bijective for any count.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
+                                                                          int tiles_n) {
+    using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N>;
+    constexpr int S = T::LDS_STRIDE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                // [2][BM][S]
+    float* Bs = smem + 2 * BM * S;   // [2][BN][S]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n;
+    const int tn_all = tile - tm * tiles_n;
+    const int seg = tn_all / tiles_n_seg;
+    const int tn = tn_all - seg * tiles_n_seg;
+    const int64_t m0 = int64_t(tm) * BM;
+    const int n0 = tn * BN;
+
+    const float* __restrict__ A = p.A;
+    const float* __restrict__ W = p.W[seg];
+
+    f32x16 acc[T::MI][T::NI];
+#pragma unroll
+    for (int i = 0; i < T::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < T::NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[T::A_LD], rb[T::B_LD];
+    constexpr int C4 = BK / 4;  // float4 per tile row
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < T::A_LD; ++i) {
+            const int idx = tid + i * T::NT;
+            const int row = idx / C4, c4 = idx - row * C4;
+            const int64_t m = m0 + row;
+            const int k = k0 + c4 * 4;
+            ra[i] = (m < p.M && k < p.K) ? *reinterpret_cast<const float4*>(A + m * p.lda + k)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < T::B_LD; ++i) {
+            const int idx = tid + i * T::NT;
+            const int row = idx / C4, c4 = idx - row * C4;
+            const int n = n0 + row;
+            const int k = k0 + c4 * 4;
+            rb[i] = (n < p.N && k < p.K) ? *reinterpret_cast<const float4*>(W + int64_t(n) * p.ldw + k)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* a = As + buf * BM * S;
+        float* b = Bs + buf * BN * S;
+#pragma unroll
+        for (int i = 0; i < T::A_LD; ++i) {
+            const int idx = tid + i * T::NT;
+            const int row = idx / C4, c4 = idx - row * C4;
+            *reinterpret_cast<float4*>(a + row * S + c4 * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < T::B_LD; ++i) {
+            const int idx = tid + i * T::NT;
+            const int row = idx / C4, c4 = idx - row * C4;
+            *reinterpret_cast<float4*>(b + row * S + c4 * 4) = rb[i];
+        }
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const float* a = As + buf * BM * S + (wm * T::WTM + l31) * S + hi * 4;
+        const float* b = Bs + buf * BN * S + (wn * T::WTN + l31) * S + hi * 4;
+#pragma unroll
+        for (int c = 0; c < BK / 8; ++c) {
+            float4 fa[T::MI], fb[T::NI];
+#pragma unroll
+            for (int i = 0; i < T::MI; ++i) fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * S + c * 8);
+#pragma unroll
+            for (int j = 0; j < T::NI; ++j) fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * S + c * 8);
+#pragma unroll
+            for (int i = 0; i < T::MI; ++i)
+#pragma unroll
+                for (int j = 0; j < T::NI; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    float* __restrict__ C = p.C[seg];
+    const float* __restrict__ bias = p.bias[seg];
+    const float* __restrict__ R = p.R;
+#pragma unroll
+    for (int j = 0; j < T::NI; ++j) {
+        const int n = n0 + wn * T::WTN + j * 32 + l31;
+        if (n >= p.N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < T::MI; ++i) {
+            const int64_t mb = m0 + wm * T::WTM + i * 32 + 4 * hi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < p.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (R) v += R[(p.r_mod > 0 ? m % p.r_mod : m) * p.ldr + n];
+                    C[m * p.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+static int launch_cfg(const GemmParams& p, hipStream_t s) {
+    using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N>;
+    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N>;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(T::LDS_BYTES));
+        if (e != hipSuccess) return int(e);
+        attr_done[dev] = true;
+    }
+    const int64_t tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n_seg = (p.N + BN - 1) / BN;
+    const int tiles_n = tiles_n_seg * p.nseg;
+    const int64_t nwg = tiles_m * tiles_n;
+    if (nwg > 0x7fffffffLL) return LAMP_E_DIMS;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(T::NT), T::LDS_BYTES, s, p, tiles_n_seg, tiles_n);
+    return int(hipGetLastError());
+}
+
+int launch_gemm(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.nseg < 1 || p.nseg > GEMM_MAX_SEG) return LAMP_E_DIMS;
+    if ((p.K & 3) || (p.lda & 3) || (p.ldw & 3)) return LAMP_E_ALIGN;
+    if (!p.A) return LAMP_E_NULL;
+    if (!aligned16(p.A)) return LAMP_E_ALIGN;
+    for (int i = 0; i < p.nseg; ++i) {
+        if (!p.W[i] || !p.C[i]) return LAMP_E_NULL;
+        if (!aligned16(p.W[i])) return LAMP_E_ALIGN;
+    }
+    const double flops = 2.0 * double(p.M) * p.N * p.nseg * p.K;
+    const double bytes = 4.0 * (double(p.M) * p.K + double(p.N) * p.nseg * p.K +
+                                double(p.M) * p.N * p.nseg * (p.R ? 2 : 1));
+    ProfScope prof(LAMP_K_GEMM, flops, bytes, s);
+    // Tile choice: the big 128x128 tile (4 waves x 64x64, 64 accumulator VGPRs) when it still
+    // yields >= ~2 workgroups per CU; otherwise 64x64 tiles to keep all 256 CUs busy.
+    const int64_t big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nseg;
+    if (big_tiles >= 512) return launch_cfg<128, 128, 32, 2, 2>(p, s);
+    return launch_cfg<64, 64, 32, 2, 2>(p, s);
+}
+
+}  // namespace lamp

@@ -1,0 +1,167 @@
+// Bandwidth-bound pieces of the path: embedding gather (+ position add), LayerNorm, diagonal
+// label read-out.  One 64-lane wave per row, 16-byte accesses per lane, four rows per workgroup.
+#include "lamp_kernels.h"
+
+namespace lamp {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// out[t, :] = emb[seq[t], :] (+ pos_table[pos[t], :])          lamp/Encoders.py:66,75
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ seq,
+                                                    const int64_t* __restrict__ pos, int64_t n_tok,
+                                                    const float* __restrict__ emb, int n_vocab,
+                                                    const float* __restrict__ pos_table, int n_position,
+                                                    int d, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (t >= n_tok) return;
+    const int64_t tok = seq[t];
+    const int64_t ps = pos_table ? pos[t] : 0;
+    const bool ok = tok >= 0 && tok < n_vocab && ps >= 0 && (!pos_table || ps < n_position);
+    const float4* e = reinterpret_cast<const float4*>(emb + (ok ? tok : 0) * d);
+    const float4* q = pos_table ? reinterpret_cast<const float4*>(pos_table + (ok ? ps : 0) * d) : nullptr;
+    float4* o = reinterpret_cast<float4*>(out + t * d);
+    const float nan = __builtin_nanf("");
+    for (int c = lane; c < d / 4; c += 64) {
+        float4 v = e[c];
+        if (q) {
+            const float4 w = q[c];
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        if (!ok) v = make_float4(nan, nan, nan, nan);
+        o[c] = v;
+    }
+}
+
+// y = (x - mean) / sqrt(var_biased + eps) * g + b over the last dim.  Two-pass (mean, then centred
+// sum of squares) on a register-resident row; NV float4 per lane.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t M, int d,
+                                                        const float* __restrict__ g,
+                                                        const float* __restrict__ bta, float eps,
+                                                        const float* __restrict__ res, int64_t r_mod,
+                                                        float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * d);
+    const float4* rr = res ? reinterpret_cast<const float4*>(res + (r_mod > 0 ? row % r_mod : row) * d) : nullptr;
+    const int nv = d / 4;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr && c < nv) {
+            const float4 w = rr[c];
+            v[i].x += w.x; v[i].y += w.y; v[i].z += w.z; v[i].w += w.w;
+        }
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / float(d);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+            ss += (a * a + b * b) + (cc * cc + dd * dd);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / float(d) + eps);
+    float4* yr = reinterpret_cast<float4*>(y + row * d);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const float4* b4 = reinterpret_cast<const float4*>(bta);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float4 gg = g4[c], bb = b4[c];
+            yr[c] = make_float4((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
+                                (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
+        }
+    }
+}
+
+// logits[b, i] = <y[b, i, :], w[i, :]>        lamp/Models.py:124-126 (diagonal of y . w^T)
+__global__ __launch_bounds__(256) void diag_kernel(const float* __restrict__ y, const float* __restrict__ w,
+                                                   int64_t n_rows, int L, int d, float* __restrict__ logits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int i = int(row % L);
+    const float4* yr = reinterpret_cast<const float4*>(y + row * d);
+    const float4* wr = reinterpret_cast<const float4*>(w + int64_t(i) * d);
+    float s = 0.f;
+    for (int c = lane; c < d / 4; c += 64) {
+        const float4 a = yr[c], b = wr[c];
+        s += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) logits[row] = s;
+}
+
+static inline int grid4(int64_t rows, unsigned* g) {
+    const int64_t n = (rows + 3) / 4;
+    if (n > 0x7fffffffLL) return LAMP_E_DIMS;
+    *g = unsigned(n);
+    return 0;
+}
+
+int launch_embed(const int64_t* seq, const int64_t* pos, int64_t n_tok, const float* emb, int n_vocab,
+                 const float* pos_table, int n_position, int d, float* out, hipStream_t s) {
+    if (n_tok <= 0 || d <= 0 || n_vocab <= 0) return LAMP_E_DIMS;
+    if (d & 3) return LAMP_E_UNSUPPORTED;
+    if (!seq || !emb || !out || (pos_table && !pos)) return LAMP_E_NULL;
+    if (!aligned16(emb) || !aligned16(out) || (pos_table && !aligned16(pos_table))) return LAMP_E_ALIGN;
+    unsigned g;
+    if (int e = grid4(n_tok, &g)) return e;
+    ProfScope prof(LAMP_K_EMBED, 0.0, double(n_tok) * (16.0 + 4.0 * d * (pos_table ? 3 : 2)), s);
+    hipLaunchKernelGGL(embed_kernel, dim3(g), dim3(256), 0, s, seq, pos, n_tok, emb, n_vocab, pos_table,
+                       n_position, d, out);
+    return int(hipGetLastError());
+}
+
+int launch_layernorm(const float* x, int64_t M, int d, const float* g, const float* b, float eps,
+                     const float* residual, int64_t r_mod, float* y, hipStream_t s) {
+    if (M <= 0 || d <= 0) return LAMP_E_DIMS;
+    if ((d & 3) || d > 4096) return LAMP_E_UNSUPPORTED;
+    if (!x || !g || !b || !y) return LAMP_E_NULL;
+    if (!aligned16(x) || !aligned16(y) || !aligned16(g) || !aligned16(b) || (residual && !aligned16(residual)))
+        return LAMP_E_ALIGN;
+    unsigned grid;
+    if (int e = grid4(M, &grid)) return e;
+    ProfScope prof(LAMP_K_LAYERNORM, 0.0, 8.0 * double(M) * d, s);
+    const int nv = (d / 4 + 63) / 64;
+    if (nv <= 1)
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y);
+    else if (nv <= 2)
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y);
+    else if (nv <= 4)
+        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y);
+    else if (nv <= 8)
+        hipLaunchKernelGGL(layernorm_kernel<8>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y);
+    return int(hipGetLastError());
+}
+
+int launch_diag(const float* y, const float* w, int B, int L, int d, float* logits, hipStream_t s) {
+    if (B <= 0 || L <= 0 || d <= 0) return LAMP_E_DIMS;
+    if (d & 3) return LAMP_E_UNSUPPORTED;
+    if (!y || !w || !logits) return LAMP_E_NULL;
+    if (!aligned16(y) || !aligned16(w)) return LAMP_E_ALIGN;
+    unsigned g;
+    const int64_t rows = int64_t(B) * L;
+    if (int e = grid4(rows, &g)) return e;
+    ProfScope prof(LAMP_K_DIAG, 2.0 * rows * d, 4.0 * (double(rows) * d + double(L) * d + rows), s);
+    hipLaunchKernelGGL(diag_kernel, dim3(g), dim3(256), 0, s, y, w, rows, L, d, logits);
+    return int(hipGetLastError());
+}
+
+}  // namespace lamp

@@ -1,0 +1,148 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every declared symbol, the
+nn.Module surface mirrors the reference (constructor kwargs, state_dict keys/shapes, mask
+construction), and the product refuses -- loudly -- to run anywhere but on a HIP device."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, golden_names, load_golden
+
+import lamp_amd
+from lamp_amd import _native as N
+from lamp_amd.Models import LAMP
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'lamp_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(lamp_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    assert os.path.exists(N.LIB_PATH), 'run python -m lamp_amd.build'
+    lib = ctypes.CDLL(N.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(N.PROTOTYPES) == names  # the ctypes binding covers the whole header
+    assert N.lib().lamp_version() == 1
+    assert b'workspace' in N.lib().lamp_strerror(-3)
+
+
+def test_struct_layouts_match_header_sizes():
+    # sizes the C compiler produces for the same declarations (x86-64 SysV)
+    assert ctypes.sizeof(N.Mask) == 32
+    assert ctypes.sizeof(N.AttnLayout) == 96
+    assert ctypes.sizeof(N.MhaWeights) == 56
+    assert ctypes.sizeof(N.FfnWeights) == 48
+    assert ctypes.sizeof(N.EncLayer) == 104
+    assert ctypes.sizeof(N.DecLayer) == 208
+    assert ctypes.sizeof(N.Model) == 96
+    assert ctypes.sizeof(N.Aux) == 40
+
+
+def build_from_fixture(name):
+    d, sd = load_golden(name)
+    L, dm = sd['decoder.tgt_word_emb.weight'].shape
+    V = sd['encoder.src_word_emb.weight'].size(0)
+    h = d['n_head']
+    n_enc = len({k.split('.')[2] for k in sd if k.startswith('encoder.layer_stack.')})
+    n_dec = len({k.split('.')[2] for k in sd if k.startswith('decoder.layer_stack.')})
+    pos = 'encoder.position_enc.weight' in sd
+    n_max = sd['encoder.position_enc.weight'].size(0) - 1 if pos else 12
+    dff = sd['encoder.layer_stack.0.pos_ffn.w_1.weight'].size(0)
+    adj = d.get('label_adj_matrix')
+    m = LAMP(V, L, n_max, L, n_layers_enc=n_enc, n_layers_dec=n_dec, n_head=h, n_head2=h, d_word_vec=dm,
+             d_model=dm, d_inner_hid=dff, d_k=dm // h, d_v=dm // h, dropout=0.1, dec_dropout=0.1,
+             dec_dropout2=False, proj_share_weight=True, embs_share_weight=True, encoder='graph',
+             decoder='graph', enc_transform='', onehot=False, no_enc_pos_embedding=not pos,
+             no_dec_self_att='decoder.layer_stack.0.slf_attn.w_qs.weight' not in sd, loss='ce',
+             label_adj_matrix=adj.clone() if adj is not None else None, label_mask=d['label_mask'],
+             matching_mlp=False, graph_conv=False, attn_type='softmax', int_preds=False)
+    return m, d, sd
+
+
+@pytest.mark.parametrize('name', golden_names('model_'))
+def test_state_dict_layout_equals_reference(name):
+    m, d, sd = build_from_fixture(name)
+    own = m.state_dict()
+    assert sorted(own) == sorted(sd)
+    for k in sd:
+        assert tuple(own[k].shape) == tuple(sd[k].shape), k
+    m.load_state_dict(sd)  # strict
+    # the accidental non-tie of the read-out is reproduced
+    assert m.tgt_word_proj.weight is m.decoder.tgt_word_emb.weight
+    assert m.tgt_word_proj.linear.weight is not m.decoder.tgt_word_emb.weight
+    # label mask: same tensor as the reference built, in the reference's own format
+    if 'ref_label_mask' in d:
+        assert torch.equal(m.decoder.label_mask, d['ref_label_mask'])
+        L = own['decoder.tgt_word_emb.weight'].size(0)
+        assert torch.equal(m.decoder.label_mask_u8, (d['ref_label_mask'].view(L, L) != 0).to(torch.uint8))
+    elif d['label_mask'] == 'none':
+        assert m.decoder.label_mask is None and m.decoder.label_mask_u8 is None
+    assert 'decoder.label_mask_u8' not in own
+    # the sinusoid table is frozen out of the optimiser's parameter list only
+    n_train = sum(1 for _ in m.get_trainable_parameters())
+    assert n_train == len(list(m.parameters())) - (1 if 'encoder.position_enc.weight' in sd else 0)
+
+
+def test_position_table_bitwise():
+    _, sd = load_golden('model_prior_pos1_h4')
+    ref = sd['encoder.position_enc.weight']
+    assert torch.equal(lamp_amd.utils.position_encoding_init(ref.size(0), ref.size(1)), ref)
+
+
+def test_padding_mask_helper_and_swap():
+    seq = torch.tensor([[5, 6, 0], [7, 0, 0]])
+    m = lamp_amd.utils.get_attn_padding_mask(seq, seq)
+    assert m.shape == (2, 3, 3) and m[0, :, 2].all() and not m[0, :, :2].any() and m[1, :, 1:].all()
+    t = torch.tensor([[0., 2.], [3., 0.]])
+    assert torch.equal(lamp_amd.utils.swap_0_1(t, 1, 0), torch.tensor([[1., 0.], [0., 1.]]))
+
+
+def test_product_has_no_cpu_path():
+    m, d, sd = build_from_fixture('model_prior_pos1_h4')
+    m.load_state_dict(sd)
+    m.eval()
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        m((d['src_seq'], d['src_pos']), None, None, None)
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        m.encoder.layer_stack[0].pos_ffn(torch.zeros(1, 2, 64))
+    m.train()
+    with pytest.raises(NotImplementedError, match='eval-mode'):
+        m((d['src_seq'], d['src_pos']), None, None, None)
+
+
+def test_out_of_scope_models_raise_at_construction():
+    with pytest.raises(NotImplementedError):
+        LAMP(10, 5, 4, 5, encoder='mlp', decoder='graph', label_mask='none')
+    with pytest.raises(NotImplementedError):
+        LAMP(10, 5, 4, 5, encoder='graph', decoder='rnn_m', label_mask='none')
+
+
+def test_argument_errors_come_back_as_status_codes_without_a_gpu():
+    lib = N.lib()
+    # validation happens before any launch, so these are safe on a GPU-less host
+    assert lib.lamp_linear_fwd(None, 4, 8, 8, None, 4, 8, None, None, 0, 0, None, 4, None) == -5
+    assert lib.lamp_linear_fwd(16, 4, 6, 6, 16, 4, 6, None, None, 0, 0, 16, 4, None) == -2   # K % 4
+    assert lib.lamp_linear_fwd(16, 0, 8, 8, 16, 4, 8, None, None, 0, 0, 16, 4, None) == -1
+    assert lib.lamp_layernorm_fwd(16, 4, 6, 16, 16, 1e-5, 16, None) == -4
+    lay = N.AttnLayout(*([4] * 12))
+    assert lib.lamp_sdpa_fwd(16, 16, 16, 16, None, 1, 1, 4, 4, 256, 256, 1.0, None, ctypes.byref(lay), None) == -4
+    assert lib.lamp_forward_workspace_bytes(None, 1, 4, 0) == 0
+
+
+def test_dropin_package_aliases_reference_import_paths():
+    import subprocess, sys
+    code = ("import lamp.Constants as C, lamp.Models, lamp.Translator, lamp.Beam, lamp.Layers, lamp.SubLayers;"
+            "from lamp.Models import LAMP; from lamp.Translator import translate;"
+            "from lamp.Attention import ScaledDotProductAttention as S; import lamp_amd;"
+            "assert LAMP is lamp_amd.Models.LAMP and S is lamp_amd.SubLayers.ScaledDotProductAttention;"
+            "assert C.PAD == 0 and C.EOS == 3; print('ok')")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, 'dropin'), ROOT]))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd='/tmp')
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
