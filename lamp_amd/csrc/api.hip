@@ -78,11 +78,11 @@ struct Carver {
 };
 
 static int linear(const float* A, int64_t M, int K, int64_t lda, const float* const* W, int nseg, int N,
-                  int64_t ldw, const float* const* bias, const float* R, int64_t ldr, int64_t r_mod, int relu,
+                  int64_t ldw, const float* const* bias, const float* R, int64_t ldr, int relu,
                   float* const* C, int64_t ldc, hipStream_t s) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.M = M; p.K = K; p.N = N; p.nseg = nseg; p.ldw = ldw; p.ldc = ldc;
-    p.R = R; p.ldr = ldr; p.r_mod = r_mod; p.relu = relu;
+    p.R = R; p.ldr = ldr; p.relu = relu;
     for (int i = 0; i < nseg; ++i) {
         p.W[i] = W[i];
         p.bias[i] = bias ? bias[i] : nullptr;
@@ -125,25 +125,25 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     if (self && hdk == hdv && need_v) {
         const float* W[3] = {w.w_qs, w.w_ks, w.w_vs};
         float* C[3] = {sc.Q, sc.K, sc.V};
-        LAMP_CK(linear(xq, Mq, d, d, W, 3, hdk, d, nullptr, nullptr, 0, 0, 0, C, hdk, s));
+        LAMP_CK(linear(xq, Mq, d, d, W, 3, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
     } else {
         {
             const float* W[1] = {w.w_qs};
             float* C[1] = {sc.Q};
-            LAMP_CK(linear(xq, Mq, d, d, W, 1, hdk, d, nullptr, nullptr, 0, 0, 0, C, hdk, s));
+            LAMP_CK(linear(xq, Mq, d, d, W, 1, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
         }
         if (need_v && hdk == hdv) {
             const float* W[2] = {w.w_ks, w.w_vs};
             float* C[2] = {sc.K, sc.V};
-            LAMP_CK(linear(xkv, Mk, d, d, W, 2, hdk, d, nullptr, nullptr, 0, 0, 0, C, hdk, s));
+            LAMP_CK(linear(xkv, Mk, d, d, W, 2, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
         } else {
             const float* Wk[1] = {w.w_ks};
             float* Ck[1] = {sc.K};
-            LAMP_CK(linear(xkv, Mk, d, d, Wk, 1, hdk, d, nullptr, nullptr, 0, 0, 0, Ck, hdk, s));
+            LAMP_CK(linear(xkv, Mk, d, d, Wk, 1, hdk, d, nullptr, nullptr, 0, 0, Ck, hdk, s));
             if (need_v) {
                 const float* Wv[1] = {w.w_vs};
                 float* Cv[1] = {sc.V};
-                LAMP_CK(linear(xkv, Mk, d, d, Wv, 1, hdv, d, nullptr, nullptr, 0, 0, 0, Cv, hdv, s));
+                LAMP_CK(linear(xkv, Mk, d, d, Wv, 1, hdv, d, nullptr, nullptr, 0, 0, Cv, hdv, s));
             }
         }
     }
@@ -168,7 +168,12 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     if (h > 1) {
         const float* W[1] = {w.fc};
         float* C[1] = {out};
-        LAMP_CK(linear(sc.A, M, hdv, hdv, W, 1, d, hdv, nullptr, xq, d, r_mod, 0, C, d, s));
+        if (xq_shared) {
+            // residual = the shared [lq, d] block: added (row modulo lq) by the LayerNorm kernel
+            LAMP_CK(linear(sc.A, M, hdv, hdv, W, 1, d, hdv, nullptr, nullptr, 0, 0, C, d, s));
+            return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, xq, r_mod, out, s);
+        }
+        LAMP_CK(linear(sc.A, M, hdv, hdv, W, 1, d, hdv, nullptr, xq, d, 0, C, d, s));
         return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, out, s);
     }
     return launch_layernorm(sc.A, M, d, w.ln_g, w.ln_b, 1e-5f, xq, r_mod, out, s);
@@ -182,13 +187,13 @@ static int ffn_core(const float* x, int64_t M, int d, int dff, const lamp_ffn_we
         const float* W[1] = {w.w1};
         const float* b[1] = {w.b1};
         float* C[1] = {hidden};
-        LAMP_CK(linear(x, M, d, d, W, 1, dff, d, b, nullptr, 0, 0, 1, C, dff, s));
+        LAMP_CK(linear(x, M, d, d, W, 1, dff, d, b, nullptr, 0, 1, C, dff, s));
     }
     {
         const float* W[1] = {w.w2};
         const float* b[1] = {w.b2};
         float* C[1] = {out};
-        LAMP_CK(linear(hidden, M, dff, dff, W, 1, d, dff, b, x, d, 0, 0, C, d, s));
+        LAMP_CK(linear(hidden, M, dff, dff, W, 1, d, dff, b, x, d, 0, C, d, s));
     }
     return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, out, s);
 }
@@ -229,7 +234,7 @@ int lamp_linear_fwd(const float* A, int64_t M, int32_t K, int64_t lda, const flo
     const float* bs[1] = {bias};
     float* Cs[1] = {C};
     if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return LAMP_E_DIMS;
-    return linear(A, M, K, lda, Ws, 1, N, ldw, bs, residual, ldr, 0, relu, Cs, ldc, hipStream_t(stream));
+    return linear(A, M, K, lda, Ws, 1, N, ldw, bs, residual, ldr, relu, Cs, ldc, hipStream_t(stream));
 }
 
 int lamp_layernorm_fwd(const float* x, int64_t M, int32_t d, const float* gamma, const float* beta, float eps,

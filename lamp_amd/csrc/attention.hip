@@ -46,18 +46,25 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     const bool wave_active = q0 < p.lq;  // wave-uniform
     const int qc = qi < p.lq ? qi : p.lq - 1;  // clamped row for mask reads
 
-    const float* __restrict__ Kg = p.K + int64_t(b) * p.lay.k_b + int64_t(h) * p.lay.k_h;
-    const float* __restrict__ Vg = p.V + int64_t(b) * p.lay.v_b + int64_t(h) * p.lay.v_h;
+    // Per-(sample, head) buffer descriptors: keys past lk read as 0 through the hardware range check.
+    const int k_r = int(p.lay.k_r), v_r = int(p.lay.v_r);
+    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K + int64_t(b) * p.lay.k_b + int64_t(h) * p.lay.k_h,
+                                                 (uint64_t(p.lk - 1) * k_r + p.dk) * 4u);
+    const bool has_v = p.V != nullptr;
+    const __amdgpu_buffer_rsrc_t rsV =
+        make_rsrc(has_v ? p.V + int64_t(b) * p.lay.v_b + int64_t(h) * p.lay.v_h : p.K,
+                  has_v ? (uint64_t(p.lk - 1) * v_r + p.dv) * 4u : 0);
 
     // ---- Q fragments: lane holds Q[qi][8c + 4hi .. +3], pre-multiplied by scale*log2(e) ----
     float4 qf[DKC];
     {
-        const float* Qrow = p.Q + int64_t(b) * p.lay.q_b + int64_t(h) * p.lay.q_h + int64_t(qc) * p.lay.q_r;
+        const int q_r = int(p.lay.q_r);
+        const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q + int64_t(b) * p.lay.q_b + int64_t(h) * p.lay.q_h,
+                                                     (uint64_t(p.lq - 1) * q_r + p.dk) * 4u);
 #pragma unroll
         for (int c = 0; c < DKC; ++c) {
             const int kd = c * 8 + hi * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qi < p.lq && kd < p.dk) v = *reinterpret_cast<const float4*>(Qrow + kd);
+            const float4 v = bload4(rsQ, (qi < p.lq && kd < p.dk) ? unsigned(qi * q_r + kd) * 4u : OOB, 0);
             qf[c] = make_float4(v.x * p.scale_log2e, v.y * p.scale_log2e, v.z * p.scale_log2e,
                                 v.w * p.scale_log2e);
         }
@@ -67,20 +74,23 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     float4 rk[LD], rv[LD];
     constexpr int C4 = DP / 4;
 
+    // This thread's float4s of a 32 x DP tile: row = key within the tile, c = first column.
+    unsigned vok[LD], vov[LD];
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / C4, c = (idx - row * C4) * 4;
+        vok[i] = c < p.dk ? unsigned(row * k_r + c) * 4u : OOB;  // padding columns read as 0
+        vov[i] = c < p.dv ? unsigned(row * v_r + c) * 4u : OOB;
+    }
     auto gload = [&](int kt, bool with_v) {
+        // tile base: key = kt*32 -> byte offset kt*32*stride*4, added on the VGPR side so that keys
+        // past lk fail the range check and come back as 0
+        const unsigned kb = unsigned(kt * 32 * k_r) * 4u, vb = unsigned(kt * 32 * v_r) * 4u;
 #pragma unroll
         for (int i = 0; i < LD; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / C4, c4 = idx - row * C4;
-            const int key = kt * 32 + row;
-            const int c = c4 * 4;
-            rk[i] = (key < p.lk && c < p.dk)
-                        ? *reinterpret_cast<const float4*>(Kg + int64_t(key) * p.lay.k_r + c)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (with_v)
-                rv[i] = (key < p.lk && c < p.dv)
-                            ? *reinterpret_cast<const float4*>(Vg + int64_t(key) * p.lay.v_r + c)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            rk[i] = bload4(rsK, vok[i] == OOB ? OOB : vok[i] + kb, 0);
+            if (with_v) rv[i] = bload4(rsV, vov[i] == OOB ? OOB : vov[i] + vb, 0);
         }
     };
     auto lstore = [&](int buf, bool with_v) {
@@ -93,26 +103,30 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         }
     };
 
+    // Mask descriptor: uint8 rows [qc*m_sq + key] of sample b, or the sample's int64 token row.
+    const __amdgpu_buffer_rsrc_t rsM =
+        p.mask_kind == LAMP_MASK_U8
+            ? make_rsrc(static_cast<const unsigned char*>(p.mask) + int64_t(b) * p.m_sb,
+                        uint64_t(p.lq - 1) * uint64_t(p.m_sq) + p.lk)
+            : make_rsrc(p.mask_kind == LAMP_MASK_KEY_TOKENS_I64
+                            ? static_cast<const void*>(static_cast<const long long*>(p.mask) + int64_t(b) * p.m_sb)
+                            : static_cast<const void*>(p.K),
+                        p.mask_kind == LAMP_MASK_KEY_TOKENS_I64 ? uint64_t(p.lk) * 8u : 0);
+
     // S^T tile for this wave's 32 queries vs keys [kt*32, kt*32+32), masked, in the log2 domain.
     auto scores = [&](int kt, int buf, f32x16& s) {
         // mask bytes first, so their latency hides under the MFMAs
         unsigned blocked = 0;  // bit r set = blocked
         const int kbase = kt * 32 + 4 * hi;
         if (p.mask_kind == LAMP_MASK_U8) {
-            const unsigned char* mrow = static_cast<const unsigned char*>(p.mask) + int64_t(b) * p.m_sb +
-                                        int64_t(qc) * p.m_sq;
+            const unsigned mo = unsigned(int64_t(qc) * p.m_sq) + unsigned(kbase);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kbase + (r & 3) + 8 * (r >> 2);
-                if (key < p.lk && mrow[key] != 0) blocked |= 1u << r;
-            }
+            for (int r = 0; r < 16; ++r)
+                blocked |= (bload_u8(rsM, mo + (r & 3) + 8 * (r >> 2)) != 0 ? 1u : 0u) << r;
         } else if (p.mask_kind == LAMP_MASK_KEY_TOKENS_I64) {
-            const long long* trow = static_cast<const long long*>(p.mask) + int64_t(b) * p.m_sb;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kbase + (r & 3) + 8 * (r >> 2);
-                if (key < p.lk && trow[key] == 0) blocked |= 1u << r;
-            }
+            for (int r = 0; r < 16; ++r)  // past lk: reads 0 == PAD == blocked (and is forced to -inf below anyway)
+                blocked |= (bload_u64(rsM, unsigned(kbase + (r & 3) + 8 * (r >> 2)) * 8u) == 0 ? 1u : 0u) << r;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -278,6 +292,317 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Register-streaming variant with key splitting, for problems too small to fill the chip with one
+// workgroup per 128 queries (reuters: 90 labels x 128 (sample, head) pairs).
+//
+// The four waves of a workgroup cover QB = 4/KSPLIT query blocks of 32; the KSPLIT waves of one block
+// take interleaved 32-key tiles (flash-decoding style) and are merged at the end.  There is NO shared
+// K/V tile and NO barrier in the main loop: every wave pulls its own MFMA fragments straight from
+// global/L2 into registers --
+//   K (A operand of S^T = K Q^T): lane (key = l&31, hi) reads 16 B at K[key][8c + 4hi], c = 0..DP/8-1
+//   V (A operand of O^T = V^T P^T): lane (col = l&31, hi) reads V[key_r(hi)][32cb + col]: two fully
+//     coalesced 128-byte rows per instruction
+// -- and software-prefetches the next tile's K right after the QK^T MFMAs and the next V right after
+// the PV MFMAs, so the loads fly under 4096 cycles of matrix work each.  (fp32 MFMA is slow enough,
+// 64 cycles per 32x32x2, that the L2 traffic of four unsynchronised waves is a non-issue.)
+// Q is staged once in LDS, pre-scaled.  The merge is lane-local: all partial (m, l, O^T) of a query
+// sit at the same lane position in every wave.
+template <int DP, int KSPLIT, bool WRITE_P>
+__global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
+    static_assert(!WRITE_P || KSPLIT == 1, "probability write-out uses unsplit keys");
+    constexpr int DKC = DP / 8, DVB = DP / 32, QB = 4 / KSPLIT, QS = DP + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int qb = wave / KSPLIT, ks = wave % KSPLIT;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = (blockIdx.x * QB + qb) * 32;
+    const int qi = q0 + l31;
+    const bool wave_active = q0 < p.lq;
+    const int qc = qi < p.lq ? qi : p.lq - 1;
+
+    const int q_r = int(p.lay.q_r), k_r = int(p.lay.k_r), v_r = int(p.lay.v_r);
+    const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q + int64_t(b) * p.lay.q_b + int64_t(h) * p.lay.q_h,
+                                                 (uint64_t(p.lq - 1) * q_r + p.dk) * 4u);
+    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K + int64_t(b) * p.lay.k_b + int64_t(h) * p.lay.k_h,
+                                                 (uint64_t(p.lk - 1) * k_r + p.dk) * 4u);
+    const bool has_v = p.V != nullptr;
+    const __amdgpu_buffer_rsrc_t rsV =
+        make_rsrc(has_v ? p.V + int64_t(b) * p.lay.v_b + int64_t(h) * p.lay.v_h : p.K,
+                  has_v ? (uint64_t(p.lk - 1) * v_r + p.dv) * 4u : 0);
+    const __amdgpu_buffer_rsrc_t rsM =
+        p.mask_kind == LAMP_MASK_U8
+            ? make_rsrc(static_cast<const unsigned char*>(p.mask) + int64_t(b) * p.m_sb,
+                        uint64_t(p.lq - 1) * uint64_t(p.m_sq) + p.lk)
+            : make_rsrc(p.mask_kind == LAMP_MASK_KEY_TOKENS_I64
+                            ? static_cast<const void*>(static_cast<const long long*>(p.mask) + int64_t(b) * p.m_sb)
+                            : static_cast<const void*>(p.K),
+                        p.mask_kind == LAMP_MASK_KEY_TOKENS_I64 ? uint64_t(p.lk) * 8u : 0);
+
+    // ---- Q block -> LDS (pre-scaled); the KSPLIT waves of a block share the copy work ----
+    float* Qs = smem + qb * 32 * QS;
+    {
+        constexpr int C4 = DP / 4;
+        constexpr int PER_WAVE = 32 * C4 / KSPLIT;  // float4 per wave
+#pragma unroll
+        for (int i = 0; i < PER_WAVE / 64; ++i) {
+            const int idx = ks * PER_WAVE + i * 64 + lane;
+            const int row = idx / C4, c = (idx - row * C4) * 4;
+            const int q = q0 + row;
+            const float4 v = bload4(rsQ, (q < p.lq && c < p.dk) ? unsigned(q * q_r + c) * 4u : OOB, 0);
+            *reinterpret_cast<float4*>(Qs + row * QS + c) =
+                make_float4(v.x * p.scale_log2e, v.y * p.scale_log2e, v.z * p.scale_log2e, v.w * p.scale_log2e);
+        }
+    }
+    __syncthreads();
+
+    const int nt = (p.lk + 31) / 32;
+    float4 kf[DKC];
+    float vf[DVB][16];
+
+    auto load_k = [&](int kt) {
+        const unsigned base = unsigned((kt * 32 + l31) * k_r + hi * 4) * 4u;
+#pragma unroll
+        for (int c = 0; c < DKC; ++c)
+            kf[c] = bload4(rsK, (c * 8 + hi * 4 < p.dk) ? base + unsigned(c) * 32u : OOB, 0);
+    };
+    auto load_v = [&](int kt) {
+        const unsigned base = unsigned((kt * 32 + 4 * hi) * v_r + l31) * 4u;
+#pragma unroll
+        for (int cb = 0; cb < DVB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                vf[cb][r] = bload1(rsV, (cb * 32 + l31 < p.dv)
+                                            ? base + unsigned(((r & 3) + 8 * (r >> 2)) * v_r + cb * 32) * 4u
+                                            : OOB);
+    };
+    auto scores = [&](int kt, f32x16& s) {
+        unsigned blocked = 0;
+        const int kbase = kt * 32 + 4 * hi;
+        if (p.mask_kind == LAMP_MASK_U8) {
+            const unsigned mo = unsigned(int64_t(qc) * p.m_sq) + unsigned(kbase);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                blocked |= (bload_u8(rsM, mo + (r & 3) + 8 * (r >> 2)) != 0 ? 1u : 0u) << r;
+        } else if (p.mask_kind == LAMP_MASK_KEY_TOKENS_I64) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                blocked |= (bload_u64(rsM, unsigned(kbase + (r & 3) + 8 * (r >> 2)) * 8u) == 0 ? 1u : 0u) << r;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float* qp = Qs + l31 * QS + hi * 4;
+#pragma unroll
+        for (int c = 0; c < DKC; ++c) {
+            const float4 qf = *reinterpret_cast<const float4*>(qp + c * 8);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].x, qf.x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].y, qf.y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].z, qf.z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].w, qf.w, s, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kbase + (r & 3) + 8 * (r >> 2);
+            if (key >= p.lk || ((blocked >> r) & 1u)) s[r] = -INFINITY;
+        }
+    };
+    auto pv = [&](const f32x16& pr, f32x16 (&o)[DVB]) {
+#pragma unroll
+        for (int cb = 0; cb < DVB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                o[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cb][r], pr[r], o[cb], 0, 0, 0);
+    };
+
+    f32x16 o[DVB];
+#pragma unroll
+    for (int cb = 0; cb < DVB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    if constexpr (WRITE_P) {
+        if (wave_active) {
+            // pass 1: exact row max / row sum
+            for (int kt = 0; kt < nt; ++kt) {
+                load_k(kt);
+                f32x16 s;
+                scores(kt, s);
+                float tmax = s[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+                tmax = fmaxf(tmax, xor32(tmax));
+                const float m_new = fmaxf(m_run, tmax);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) psum += exp2f(s[r] - m_use);
+                psum += xor32(psum);
+                l_run = l_run * exp2f(m_run - m_use) + psum;
+                m_run = m_new;
+            }
+            // pass 2: normalised probabilities out, O = P V
+            const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+            const float inv_l = 1.0f / l_run;
+            float* Prow = p.P + (int64_t(h) * p.B + b) * int64_t(p.lq) * p.lk + int64_t(qc) * p.lk;
+            for (int kt = 0; kt < nt; ++kt) {
+                load_k(kt);
+                if (has_v) load_v(kt);
+                f32x16 s;
+                scores(kt, s);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = exp2f(s[r] - m_use) * inv_l;
+                    const int key = kt * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                    if (qi < p.lq && key < p.lk) Prow[key] = s[r];
+                    if (key >= p.lk) s[r] = 0.f;
+                }
+                if (has_v) pv(s, o);
+            }
+            if (l_run == 0.f) {
+#pragma unroll
+                for (int cb = 0; cb < DVB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[cb][r] = __builtin_nanf("");
+            }
+        }
+    } else {
+        if (wave_active && ks < nt) {
+            load_k(ks);
+            load_v(ks);
+            for (int kt = ks; kt < nt; kt += KSPLIT) {
+                f32x16 s;
+                scores(kt, s);
+                if (kt + KSPLIT < nt) load_k(kt + KSPLIT);  // flies under softmax + PV
+                float tmax = s[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+                tmax = fmaxf(tmax, xor32(tmax));
+                const float m_new = fmaxf(m_run, tmax);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = exp2f(m_run - m_use);
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = exp2f(s[r] - m_use);
+                    psum += s[r];
+                }
+                psum += xor32(psum);
+                l_run = l_run * alpha + psum;
+                m_run = m_new;
+#pragma unroll
+                for (int cb = 0; cb < DVB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+                pv(s, o);
+                if (kt + KSPLIT < nt) load_v(kt + KSPLIT);  // flies under the next QK^T
+            }
+        }
+        if constexpr (KSPLIT > 1) {
+            // ---- merge the KSPLIT partial results of each query block (lane-local positions) ----
+            constexpr int CW = (DP + 2) * 32;  // floats per wave: O^T [DP][32], m [32], l [32]
+            __syncthreads();                   // every wave is done reading Qs: the region is reused
+            float* mine = smem + wave * CW;
+#pragma unroll
+            for (int cb = 0; cb < DVB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    mine[(cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = o[cb][r];
+            if (hi == 0) {
+                mine[DP * 32 + l31] = m_run;
+                mine[(DP + 1) * 32 + l31] = l_run;
+            }
+            __syncthreads();
+            if (ks == 0 && wave_active) {
+                float m_all = m_run;
+#pragma unroll
+                for (int s2 = 1; s2 < KSPLIT; ++s2) m_all = fmaxf(m_all, smem[(wave + s2) * CW + DP * 32 + l31]);
+                const float m_use = (m_all == -INFINITY) ? 0.f : m_all;
+                const float w0 = exp2f(m_run - m_use);
+                l_run *= w0;
+#pragma unroll
+                for (int cb = 0; cb < DVB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[cb][r] *= w0;
+#pragma unroll
+                for (int s2 = 1; s2 < KSPLIT; ++s2) {
+                    const float* other = smem + (wave + s2) * CW;
+                    const float ws = exp2f(other[DP * 32 + l31] - m_use);
+                    l_run += other[(DP + 1) * 32 + l31] * ws;
+#pragma unroll
+                    for (int cb = 0; cb < DVB; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            o[cb][r] += other[(cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] * ws;
+                }
+            }
+        }
+        const float inv_l = 1.0f / l_run;
+#pragma unroll
+        for (int cb = 0; cb < DVB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[cb][r] *= inv_l;
+    }
+
+    if (wave_active && ks == 0 && qi < p.lq && p.O != nullptr) {
+        float* Orow = p.O + int64_t(b) * p.lay.o_b + int64_t(h) * p.lay.o_h + int64_t(qi) * p.lay.o_r;
+        const bool vec = ((p.lay.o_b | p.lay.o_h | p.lay.o_r) & 3) == 0 &&
+                         (reinterpret_cast<uintptr_t>(p.O) & 15u) == 0;
+#pragma unroll
+        for (int cb = 0; cb < DVB; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = cb * 32 + g * 8 + hi * 4;
+                if (col >= p.dv) continue;
+                if (vec) {
+                    *reinterpret_cast<float4*>(Orow + col) =
+                        make_float4(o[cb][4 * g], o[cb][4 * g + 1], o[cb][4 * g + 2], o[cb][4 * g + 3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Orow[col + e] = o[cb][4 * g + e];
+                }
+            }
+    }
+}
+
+template <int DP, int KSPLIT, bool WRITE_P>
+static int launch_attn_reg(const AttnParams& p, hipStream_t s) {
+    constexpr int QB = 4 / KSPLIT;
+    constexpr size_t lds_q = size_t(QB) * 32 * (DP + 4) * sizeof(float);
+    constexpr size_t lds_c = KSPLIT > 1 ? size_t(4) * (DP + 2) * 32 * sizeof(float) : 0;
+    constexpr size_t lds = lds_q > lds_c ? lds_q : lds_c;
+    auto kern = attn_reg_kernel<DP, KSPLIT, WRITE_P>;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds > 65536 && dev >= 0 && dev < 64 && !attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return int(e);
+        attr_done[dev] = true;
+    }
+    dim3 grid((p.lq + 32 * QB - 1) / (32 * QB), p.H, p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return int(hipGetLastError());
+}
+
+template <int DP>
+static int launch_attn_reg_dp(const AttnParams& p, int ksplit, hipStream_t s) {
+    if (p.P) return launch_attn_reg<DP, 1, true>(p, s);
+    if (ksplit >= 4) return launch_attn_reg<DP, 4, false>(p, s);
+    if (ksplit == 2) return launch_attn_reg<DP, 2, false>(p, s);
+    return launch_attn_reg<DP, 1, false>(p, s);
+}
+
+// Debug/tuning hook (not part of the ABI header): 0 = heuristic, 1 = LDS-tiled kernel,
+// 2/3/4 = register-streaming kernel with KSPLIT 1/2/4.
+static int g_force_attn = 0;
+extern "C" void lamp_debug_force_attn(int v) { g_force_attn = v; }
+
 template <int DP, bool WRITE_P>
 static int launch_attn_cfg(const AttnParams& p, hipStream_t s) {
     constexpr size_t lds = size_t(2) * 32 * ((DP + 4) + DP) * sizeof(float);
@@ -314,6 +639,25 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     ProfScope prof(LAMP_K_ATTN, flops, bytes, s);
     const int dmax = p.dk > p.dv ? p.dk : p.dv;
     const bool wp = p.P != nullptr;
+    if (int64_t(p.lq) * L.q_r * 4 >= 0x7fffffffLL || int64_t(p.lk) * L.k_r * 4 >= 0x7fffffffLL ||
+        int64_t(p.lk) * L.v_r * 4 >= 0x7fffffffLL || int64_t(p.lq) * p.m_sq + p.lk >= 0x7fffffffLL)
+        return LAMP_E_UNSUPPORTED;  // 32-bit offsets inside one (sample, head) slice
+    // Small grids: split the keys over the four waves of a workgroup until there are ~2 workgroups per CU.
+    const int nt = (p.lk + 31) / 32;
+    const int64_t bh = int64_t(p.B) * p.H;
+    int mode = g_force_attn;
+    if (mode == 0) {
+        if (bh * ((p.lq + 127) / 128) >= 512) mode = 1;
+        else if (bh * ((p.lq + 63) / 64) >= 512 || nt < 4) mode = (nt >= 2 ? 3 : 2);
+        else mode = 4;
+    }
+    if (mode == 1 && p.O == nullptr) mode = 2;
+    if (mode >= 2) {
+        const int ksplit = wp ? 1 : (mode == 2 ? 1 : mode == 3 ? 2 : 4);
+        if (dmax <= 32) return launch_attn_reg_dp<32>(p, ksplit, s);
+        if (dmax <= 64) return launch_attn_reg_dp<64>(p, ksplit, s);
+        return launch_attn_reg_dp<128>(p, ksplit, s);
+    }
     if (dmax <= 32) return wp ? launch_attn_cfg<32, true>(p, s) : launch_attn_cfg<32, false>(p, s);
     if (dmax <= 64) return wp ? launch_attn_cfg<64, true>(p, s) : launch_attn_cfg<64, false>(p, s);
     return wp ? launch_attn_cfg<128, true>(p, s) : launch_attn_cfg<128, false>(p, s);

@@ -13,6 +13,11 @@
 // the b128 fragment reads and the b128 staging writes bank-conflict free (row stride 36 floats =
 // 9 sixteen-byte slots, odd => the 16 rows of a lane group land on 16 distinct slots).
 //
+// All global traffic goes through per-tile buffer descriptors (buffer_load/store ... offen): the
+// hardware range check returns 0 for rows past M / N and drops stores to them, so the hot loop has
+// no bounds branches, no clamps and only 32-bit offsets (guarded plain loads compile to one branch
+// plus a full vmcnt(0) drain per element; 64-bit per-element addresses spill).
+//
 // The k-accumulation order of every output element is fixed by (K, BK) alone -- never by M, the
 // grid or the batch -- so a sample's result is bit-identical however the batch is sharded.
 #include "lamp_kernels.h"
@@ -43,14 +48,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
                                                                           int tiles_n) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N>;
     constexpr int S = T::LDS_STRIDE;
+    constexpr int C4 = BK / 4;  // float4 per tile row
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                // [2][BM][S]
-    float* Bs = smem + 2 * BM * S;   // [2][BN][S]
+    float* As = smem;               // [2][BM][S]
+    float* Bs = smem + 2 * BM * S;  // [2][BN][S]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -65,9 +71,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     const int tn = tn_all - seg * tiles_n_seg;
     const int64_t m0 = int64_t(tm) * BM;
     const int n0 = tn * BN;
+    const int rows_m = int(p.M - m0 < BM ? p.M - m0 : BM);  // valid rows / columns of this tile
+    const int rows_n = p.N - n0 < BN ? p.N - n0 : BN;
 
-    const float* __restrict__ A = p.A;
-    const float* __restrict__ W = p.W[seg];
+    const int lda = int(p.lda), ldw = int(p.ldw);
+    const __amdgpu_buffer_rsrc_t rsA =
+        make_rsrc(p.A + m0 * p.lda, (uint64_t(rows_m - 1) * lda + p.K) * 4u);
+    const __amdgpu_buffer_rsrc_t rsW =
+        make_rsrc(p.W[seg] + int64_t(n0) * p.ldw, (uint64_t(rows_n - 1) * ldw + p.K) * 4u);
 
     f32x16 acc[T::MI][T::NI];
 #pragma unroll
@@ -78,26 +89,39 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[T::A_LD], rb[T::B_LD];
-    constexpr int C4 = BK / 4;  // float4 per tile row
+    unsigned voa[T::A_LD], vob[T::B_LD];  // byte offsets of this thread's float4s inside the tile
+#pragma unroll
+    for (int i = 0; i < T::A_LD; ++i) {
+        const int idx = tid + i * T::NT;
+        const int row = idx / C4, c4 = idx - row * C4;
+        voa[i] = unsigned(row * lda + c4 * 4) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < T::B_LD; ++i) {
+        const int idx = tid + i * T::NT;
+        const int row = idx / C4, c4 = idx - row * C4;
+        vob[i] = unsigned(row * ldw + c4 * 4) * 4u;
+    }
 
     auto gload = [&](int k0) {
+        if constexpr (KTAIL) {
+            // K is not a multiple of BK: columns past K must read as 0 (the row range check cannot see them)
 #pragma unroll
-        for (int i = 0; i < T::A_LD; ++i) {
-            const int idx = tid + i * T::NT;
-            const int row = idx / C4, c4 = idx - row * C4;
-            const int64_t m = m0 + row;
-            const int k = k0 + c4 * 4;
-            ra[i] = (m < p.M && k < p.K) ? *reinterpret_cast<const float4*>(A + m * p.lda + k)
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+            for (int i = 0; i < T::A_LD; ++i) {
+                const int k = k0 + ((tid + i * T::NT) % C4) * 4;
+                ra[i] = bload4(rsA, k < p.K ? voa[i] + unsigned(k0) * 4u : OOB, 0);
+            }
 #pragma unroll
-        for (int i = 0; i < T::B_LD; ++i) {
-            const int idx = tid + i * T::NT;
-            const int row = idx / C4, c4 = idx - row * C4;
-            const int n = n0 + row;
-            const int k = k0 + c4 * 4;
-            rb[i] = (n < p.N && k < p.K) ? *reinterpret_cast<const float4*>(W + int64_t(n) * p.ldw + k)
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < T::B_LD; ++i) {
+                const int k = k0 + ((tid + i * T::NT) % C4) * 4;
+                rb[i] = bload4(rsW, k < p.K ? vob[i] + unsigned(k0) * 4u : OOB, 0);
+            }
+        } else {
+            const unsigned so = unsigned(k0) * 4u;  // uniform -> soffset
+#pragma unroll
+            for (int i = 0; i < T::A_LD; ++i) ra[i] = bload4(rsA, voa[i], so);
+#pragma unroll
+            for (int i = 0; i < T::B_LD; ++i) rb[i] = bload4(rsW, vob[i], so);
         }
     };
     auto lstore = [&](int buf) {
@@ -149,35 +173,49 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     }
 
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    float* __restrict__ C = p.C[seg];
-    const float* __restrict__ bias = p.bias[seg];
-    const float* __restrict__ R = p.R;
+    // Stores to rows past M fall outside the descriptor and are dropped by the hardware; columns past
+    // N are steered to an out-of-range offset.
+    const int ldc = int(p.ldc), ldr = int(p.ldr);
+    const __amdgpu_buffer_rsrc_t rsC =
+        make_rsrc(p.C[seg] + m0 * p.ldc + n0, (uint64_t(rows_m - 1) * ldc + rows_n) * 4u);
+    const bool has_r = p.R != nullptr;
+    const __amdgpu_buffer_rsrc_t rsR =
+        make_rsrc(has_r ? p.R + m0 * p.ldr + n0 : p.A, has_r ? (uint64_t(rows_m - 1) * ldr + rows_n) * 4u : 0);
+    const float* bias = p.bias[seg];
+    const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias ? bias + n0 : p.A, bias ? uint64_t(rows_n) * 4u : 0);
+    const int lrow0 = wm * T::WTM + 4 * hi;
+    const int lcol0 = wn * T::WTN + l31;
 #pragma unroll
     for (int j = 0; j < T::NI; ++j) {
-        const int n = n0 + wn * T::WTN + j * 32 + l31;
-        if (n >= p.N) continue;
-        const float bv = bias ? bias[n] : 0.f;
+        const int lcol = lcol0 + j * 32;
+        const bool col_ok = lcol < rows_n;
+        const float bv = bload1(rsBias, col_ok ? unsigned(lcol) * 4u : OOB);
 #pragma unroll
         for (int i = 0; i < T::MI; ++i) {
-            const int64_t mb = m0 + wm * T::WTM + i * 32 + 4 * hi;
+            float res[16];
+            if (has_r) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lrow = lrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    res[r] = bload1(rsR, col_ok ? unsigned(lrow * ldr + lcol) * 4u : OOB);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < p.M) {
-                    float v = acc[i][j][r] + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (R) v += R[(p.r_mod > 0 ? m % p.r_mod : m) * p.ldr + n];
-                    C[m * p.ldc + n] = v;
-                }
+                const int lrow = lrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (has_r) v += res[r];
+                bstore1(rsC, col_ok ? unsigned(lrow * ldc + lcol) * 4u : OOB, v);
             }
         }
     }
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
-static int launch_cfg(const GemmParams& p, hipStream_t s) {
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL>
+static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N>;
-    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N>;
+    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL>;
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -187,6 +225,10 @@ static int launch_cfg(const GemmParams& p, hipStream_t s) {
         if (e != hipSuccess) return int(e);
         attr_done[dev] = true;
     }
+    // 32-bit in-tile byte offsets
+    const int64_t ldmax = p.lda > p.ldw ? (p.lda > p.ldc ? p.lda : p.ldc) : (p.ldw > p.ldc ? p.ldw : p.ldc);
+    if (ldmax * (BM > BN ? BM : BN) * 4 >= 0x7fffffffLL || (p.R && p.ldr * BM * 4 >= 0x7fffffffLL))
+        return LAMP_E_UNSUPPORTED;
     const int64_t tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n_seg = (p.N + BN - 1) / BN;
     const int tiles_n = tiles_n_seg * p.nseg;
@@ -195,6 +237,16 @@ static int launch_cfg(const GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(T::NT), T::LDS_BYTES, s, p, tiles_n_seg, tiles_n);
     return int(hipGetLastError());
 }
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+static int launch_cfg(const GemmParams& p, hipStream_t s) {
+    if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true>(p, s);
+    return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false>(p, s);
+}
+
+// Debug/tuning hook (not part of the ABI header): force a tile configuration.  0 = heuristic.
+static int g_force_tile = 0;
+extern "C" void lamp_debug_force_gemm_tile(int cfg) { g_force_tile = cfg; }
 
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.nseg < 1 || p.nseg > GEMM_MAX_SEG) return LAMP_E_DIMS;
@@ -209,10 +261,25 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     const double bytes = 4.0 * (double(p.M) * p.K + double(p.N) * p.nseg * p.K +
                                 double(p.M) * p.N * p.nseg * (p.R ? 2 : 1));
     ProfScope prof(LAMP_K_GEMM, flops, bytes, s);
-    // Tile choice: the big 128x128 tile (4 waves x 64x64, 64 accumulator VGPRs) when it still
-    // yields >= ~2 workgroups per CU; otherwise 64x64 tiles to keep all 256 CUs busy.
-    const int64_t big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nseg;
-    if (big_tiles >= 512) return launch_cfg<128, 128, 32, 2, 2>(p, s);
+    switch (g_force_tile) {
+        case 1: return launch_cfg<128, 128, 32, 2, 2>(p, s);
+        case 2: return launch_cfg<64, 64, 32, 2, 2>(p, s);
+        case 3: return launch_cfg<128, 64, 32, 2, 2>(p, s);
+        case 4: return launch_cfg<64, 128, 32, 2, 2>(p, s);
+        case 5: return launch_cfg<128, 128, 16, 2, 2>(p, s);
+        case 6: return launch_cfg<64, 64, 16, 2, 2>(p, s);
+        case 7: return launch_cfg<128, 64, 16, 2, 2>(p, s);
+        case 8: return launch_cfg<256, 128, 16, 4, 2>(p, s);
+        default: break;
+    }
+    // Tile choice, from tools/bench_kernels.py on MI355X (profiles/r01_gemm_tiles.txt).  Large
+    // problems want the 128x128x32 tile (141 TF at 4096^3); the batch-32 shapes of the benchmark are
+    // quantisation bound (a few hundred tiles on 256 CUs), where smaller tiles with BK=16 (more
+    // co-resident workgroups, finer tail) win.
+    auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nseg; };
+    if (tiles(128, 128) >= 1024) return launch_cfg<128, 128, 32, 2, 2>(p, s);
+    if (tiles(128, 64) >= 1024) return launch_cfg<128, 64, 16, 2, 2>(p, s);
+    if (tiles(64, 64) >= 512) return launch_cfg<64, 64, 16, 2, 2>(p, s);
     return launch_cfg<64, 64, 32, 2, 2>(p, s);
 }
 

@@ -28,7 +28,6 @@ struct GemmParams {
     int64_t ldc;
     const float* R;  // residual, same for every segment (only meaningful with nseg == 1)
     int64_t ldr;
-    int64_t r_mod;   // > 0: residual row = m % r_mod (one [r_mod, N] block shared by every sample)
     int relu;
 };
 
@@ -63,6 +62,35 @@ struct ProfScope {
     ProfScope(int kernel_class, double flops, double bytes, hipStream_t s);
     ~ProfScope();
 };
+
+// ---- buffer-descriptor helpers (device) ----
+// Raw buffer loads return 0 and raw buffer stores are dropped when voffset >= num_records (the
+// scalar soffset is NOT range checked), which replaces every bounds branch in the kernels.
+constexpr unsigned OOB = 0x80000000u;  // an offset no descriptor of ours covers (num_records <= 0x7fffffff)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint64_t bytes) {
+    const unsigned n = bytes >= 0x7fffffffull ? 0x7fffffffu : unsigned(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    // NB: convert the WHOLE vector with one bit_cast.  Subscripting the builtin's result (v[0], v.x ...)
+    // is miscompiled by hipcc 7.2 into a buffer_load_dword splatted over the four lanes.
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+__device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, unsigned voff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
+}
+
+__device__ __forceinline__ unsigned bload_u8(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b8(r, voff, 0, 0);
+}
+__device__ __forceinline__ unsigned long long bload_u64(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+}
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

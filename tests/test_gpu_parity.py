@@ -97,6 +97,32 @@ def test_sdpa_vs_oracle_shapes(dev, lq, lk, dk):
     assert max_abs_diff(o2, ref_o) < 2e-5
 
 
+@pytest.mark.parametrize('mode', [1, 2, 3, 4])
+@pytest.mark.parametrize('lq,lk,dk', [(90, 302, 128), (70, 33, 64), (200, 513, 32), (5, 1, 16)])
+def test_sdpa_every_kernel_variant(dev, mode, lq, lk, dk):
+    """The LDS-tiled kernel (1) and the register-streaming kernel with 1/2/4-way key split (2/3/4)
+    must all agree with the oracle, masks and dead rows included."""
+    import ctypes
+    from lamp_amd import _native as N
+    force = N.lib().lamp_debug_force_attn
+    force.argtypes = [ctypes.c_int]
+    g = torch.Generator().manual_seed(lq + lk + mode)
+    n = 3
+    q, k, v = (torch.randn(n, l, dk, generator=g) for l in (lq, lk, lk))
+    mask = torch.rand(n, lq, lk, generator=g) < 0.4
+    mask[:, :, 0] = False
+    mask[1, lq // 2, :] = True  # a dead row
+    ref_o, ref_a = R.sdpa(q.double(), k.double(), v.double(), mask)
+    try:
+        force(mode)
+        o, _ = N.sdpa(q.to(dev), k.to(dev), v.to(dev), mask.to(dev), 1.0 / dk ** 0.5, need_attn=False)
+        o2, a2 = N.sdpa(q.to(dev), k.to(dev), v.to(dev), mask.to(dev), 1.0 / dk ** 0.5, need_attn=True)
+    finally:
+        force(0)
+    assert max_abs_diff(o, ref_o) < 2e-5
+    assert max_abs_diff(o2, ref_o) < 2e-5 and max_abs_diff(a2, ref_a) < 5e-6
+
+
 def test_sdpa_online_rescale_is_forced(dev):
     """A key in a LATE tile dominates every earlier one, so the running max jumps and the online
     rescale branch really runs (guide rule: a rare data-dependent branch needs its own test)."""

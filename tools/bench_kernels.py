@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the individual HIP kernels at the shapes one forward issues (GPU box only).
+
+    python tools/bench_kernels.py gemm      # every tile configuration x every GEMM shape
+    python tools/bench_kernels.py attn
+"""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lamp_amd import _native as N  # noqa: E402
+
+TILES = {0: 'heuristic', 1: '128x128x32', 2: '64x64x32', 3: '128x64x32', 4: '64x128x32', 5: '128x128x16',
+         6: '64x64x16', 7: '128x64x16', 8: '256x128x16(8w)'}
+
+
+def time_fn(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def gemm():
+    lib = N.lib()
+    force = lib.lamp_debug_force_gemm_tile
+    force.argtypes = [ctypes.c_int]
+    force.restype = None
+    dev = torch.device('cuda:0')
+    shapes = [('encFFN 9664x512x512', 9664, 512, 512), ('encKV 9664x1024x512', 9664, 1024, 512),
+              ('encKVx2 9664x2048x512', 9664, 2048, 512), ('dec 2880x512x512', 2880, 512, 512),
+              ('decQKV 2880x1536x512', 2880, 1536, 512), ('Q0 90x512x512', 90, 512, 512),
+              ('bibtex ffn 5088x1024x512', 5088, 1024, 512), ('delic ffn1 31456x2048x1024', 31456, 2048, 1024),
+              ('delic ffn2 31456x1024x2048', 31456, 1024, 2048), ('sq 4096^3', 4096, 4096, 4096)]
+    print('%-28s' % 'shape' + ''.join('%16s' % TILES[t] for t in sorted(TILES)))
+    for name, M, Nn, K in shapes:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(Nn, K, device=dev) / K ** 0.5
+        b = torch.randn(Nn, device=dev)
+        r = torch.randn(M, Nn, device=dev)
+        out = torch.empty(M, Nn, device=dev)
+        row = '%-28s' % name
+        for t in sorted(TILES):
+            force(t)
+
+            def fn():
+                N.check(lib.lamp_linear_fwd(x.data_ptr(), M, K, K, w.data_ptr(), Nn, K, b.data_ptr(),
+                                            r.data_ptr(), Nn, 1, out.data_ptr(), Nn, N.stream()), 'linear')
+            us = time_fn(fn, iters=10 if M * Nn * K > 1e11 else 30)
+            row += '%9.1f/%5.1fT' % (us, 2.0 * M * Nn * K / us / 1e6)
+        force(0)
+        print(row)
+
+
+def attn():
+    dev = torch.device('cuda:0')
+    cases = [('reuters enc-attn', 32, 4, 90, 302, 128), ('reuters self', 32, 4, 90, 90, 128),
+             ('bibtex self', 32, 4, 159, 159, 128), ('delicious self', 32, 8, 983, 983, 128),
+             ('synthetic self', 4, 8, 4096, 4096, 128), ('synthetic enc', 4, 8, 4096, 512, 128)]
+    for name, B, H, lq, lk, dk in cases:
+        q = torch.randn(B, lq, H * dk, device=dev)
+        k = torch.randn(B, lk, H * dk, device=dev)
+        v = torch.randn(B, lk, H * dk, device=dev)
+        o = torch.empty(B, lq, H * dk, device=dev)
+        mask = (torch.rand(lq, lk, device=dev) < 0.9).to(torch.uint8)
+        mask[:, 0] = 0
+        lay = N.AttnLayout(lq * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lk * H * dk, dk, H * dk,
+                           lq * H * dk, dk, H * dk)
+        force = N.lib().lamp_debug_force_attn
+        force.argtypes = [ctypes.c_int]
+        for mode in (0, 1, 2, 3, 4):
+          for mname, ms in (('none', None), ('shared-u8', N.Mask(N.LAMP_MASK_U8, 0, mask.data_ptr(), 0, lk))):
+            force(mode)
+
+            def fn():
+                N.check(N.lib().lamp_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), None, B, H,
+                                              lq, lk, dk, dk, dk ** -0.5,
+                                              ctypes.byref(ms) if ms is not None else None, ctypes.byref(lay),
+                                              N.stream()), 'sdpa')
+            us = time_fn(fn, iters=10)
+            force(0)
+            fl = 4.0 * B * H * lq * lk * dk
+            print('%-20s mode=%d mask=%-10s %9.1f us  %6.1f TFLOP/s' % (name, mode, mname, us, fl / us / 1e6))
+
+
+if __name__ == '__main__':
+    which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
+    {'gemm': gemm, 'attn': attn}[which]()
