@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
             for (int kt = ks; kt < nt; kt += KSPLIT) {
                 f32x16 s;
                 scores(kt, s);
-                if (kt + KSPLIT < nt) load_k(kt + KSPLIT);  // flies under softmax + PV
+                load_k(kt + KSPLIT);  // unconditional (past lk: range-checked zeros); flies under softmax + PV
                 float tmax = s[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
                 pv(s, o);
-                if (kt + KSPLIT < nt) load_v(kt + KSPLIT);  // flies under the next QK^T
+                load_v(kt + KSPLIT);  // flies under the next QK^T
             }
         }
         if constexpr (KSPLIT > 1) {
@@ -647,9 +647,11 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     const int64_t bh = int64_t(p.B) * p.H;
     int mode = g_force_attn;
     if (mode == 0) {
-        if (bh * ((p.lq + 127) / 128) >= 512) mode = 1;
-        else if (bh * ((p.lq + 63) / 64) >= 512 || nt < 4) mode = (nt >= 2 ? 3 : 2);
-        else mode = 4;
+        // Measured on MI355X (profiles/r01_attn_variants.txt): the LDS-tiled kernel wins whenever its
+        // grid fills the chip; the 2-way key split wins for grids of <= 256 workgroups with >= 4 key tiles
+        // (one resident workgroup per CU at 1 wave/SIMD, so a 4-way split's 384 workgroups take two rounds).
+        const int64_t wg2 = bh * ((p.lq + 63) / 64);
+        mode = (wg2 <= 256 && nt >= 4) ? 3 : 1;
     }
     if (mode == 1 && p.O == nullptr) mode = 2;
     if (mode >= 2) {

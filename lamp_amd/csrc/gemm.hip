@@ -20,22 +20,29 @@
 //
 // The k-accumulation order of every output element is fixed by (K, BK) alone -- never by M, the
 // grid or the batch -- so a sample's result is bit-identical however the batch is sharded.
+#include <type_traits>
+
 #include "lamp_kernels.h"
 
 namespace lamp {
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+// MF = edge of the MFMA block a wave tile is built from: 32 (v_mfma_f32_32x32x2_f32, 16 accumulator
+// registers per block) or 16 (v_mfma_f32_16x16x4_f32, 4 registers per block; finer tiles for shapes that
+// would otherwise leave CUs idle -- needs >= 2 independent blocks per wave to cover its 40-cycle latency).
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF = 32>
 struct GemmTile {
     static constexpr int NT = WAVES_M * WAVES_N * 64;
     static constexpr int WTM = BM / WAVES_M;
     static constexpr int WTN = BN / WAVES_N;
-    static constexpr int MI = WTM / 32;
-    static constexpr int NI = WTN / 32;
+    static constexpr int MI = WTM / MF;
+    static constexpr int NI = WTN / MF;
     static constexpr int LDS_STRIDE = BK + 4;
     static constexpr int A_LD = BM * BK / 4 / NT;  // float4 loads per thread per tile
     static constexpr int B_LD = BN * BK / 4 / NT;
     static constexpr size_t LDS_BYTES = size_t(2) * (BM + BN) * LDS_STRIDE * sizeof(float);
-    static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
+    static_assert(MF == 32 || MF == 16, "MFMA block edge");
+    static_assert(WTM % MF == 0 && WTN % MF == 0, "wave tile must be a multiple of the MFMA block");
+    static_assert(BK % (MF == 32 ? 8 : 16) == 0, "BK must cover whole fragment reads");
     static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "staging must divide evenly");
     static_assert(BK % 8 == 0, "BK must be a multiple of 8");
 };
@@ -48,10 +55,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
                                                                           int tiles_n) {
-    using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N>;
+    using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
+    // lane -> (row within an MFMA block, which group of 4 consecutive k this lane's b128 read covers)
+    constexpr int KQ = 64 / MF;             // 2 for 32x32x2, 4 for 16x16x4
+    constexpr int KCH = 4 * KQ;             // k covered by one round of fragment reads: 8 or 16
+    constexpr int NACC = MF == 32 ? 16 : 4; // accumulator registers per block
+    using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
     constexpr int S = T::LDS_STRIDE;
     constexpr int C4 = BK / 4;  // float4 per tile row
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -62,7 +74,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int l31 = lane & 31, hi = lane >> 5;
+    const int l31 = lane & (MF - 1), hi = lane / MF;  // row-in-block, k-group
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = tile / tiles_n;
@@ -80,13 +92,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     const __amdgpu_buffer_rsrc_t rsW =
         make_rsrc(p.W[seg] + int64_t(n0) * p.ldw, (uint64_t(rows_n - 1) * ldw + p.K) * 4u);
 
-    f32x16 acc[T::MI][T::NI];
+    acc_t acc[T::MI][T::NI];
 #pragma unroll
     for (int i = 0; i < T::MI; ++i)
 #pragma unroll
         for (int j = 0; j < T::NI; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < NACC; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[T::A_LD], rb[T::B_LD];
     unsigned voa[T::A_LD], vob[T::B_LD];  // byte offsets of this thread's float4s inside the tile
@@ -152,20 +164,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         const float* a = As + buf * BM * S + (wm * T::WTM + l31) * S + hi * 4;
         const float* b = Bs + buf * BN * S + (wn * T::WTN + l31) * S + hi * 4;
 #pragma unroll
-        for (int c = 0; c < BK / 8; ++c) {
+        for (int c = 0; c < BK / KCH; ++c) {
             float4 fa[T::MI], fb[T::NI];
 #pragma unroll
-            for (int i = 0; i < T::MI; ++i) fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * S + c * 8);
+            for (int i = 0; i < T::MI; ++i) fa[i] = *reinterpret_cast<const float4*>(a + i * MF * S + c * KCH);
 #pragma unroll
-            for (int j = 0; j < T::NI; ++j) fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * S + c * 8);
+            for (int j = 0; j < T::NI; ++j) fb[j] = *reinterpret_cast<const float4*>(b + j * MF * S + c * KCH);
 #pragma unroll
             for (int i = 0; i < T::MI; ++i)
 #pragma unroll
                 for (int j = 0; j < T::NI; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    if constexpr (MF == 32) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    }
                 }
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
@@ -183,26 +202,29 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         make_rsrc(has_r ? p.R + m0 * p.ldr + n0 : p.A, has_r ? (uint64_t(rows_m - 1) * ldr + rows_n) * 4u : 0);
     const float* bias = p.bias[seg];
     const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias ? bias + n0 : p.A, bias ? uint64_t(rows_n) * 4u : 0);
+    // C/D layouts: 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16;
+    //              16x16 block: col = lane&15, row = 4*(lane>>4) + r,            r < 4.
+    auto blk_row = [&](int r) { return MF == 32 ? (r & 3) + 8 * (r >> 2) : r; };
     const int lrow0 = wm * T::WTM + 4 * hi;
     const int lcol0 = wn * T::WTN + l31;
 #pragma unroll
     for (int j = 0; j < T::NI; ++j) {
-        const int lcol = lcol0 + j * 32;
+        const int lcol = lcol0 + j * MF;
         const bool col_ok = lcol < rows_n;
         const float bv = bload1(rsBias, col_ok ? unsigned(lcol) * 4u : OOB);
 #pragma unroll
         for (int i = 0; i < T::MI; ++i) {
-            float res[16];
+            float res[NACC];
             if (has_r) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lrow = lrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                for (int r = 0; r < NACC; ++r) {
+                    const int lrow = lrow0 + i * MF + blk_row(r);
                     res[r] = bload1(rsR, col_ok ? unsigned(lrow * ldr + lcol) * 4u : OOB);
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lrow = lrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+            for (int r = 0; r < NACC; ++r) {
+                const int lrow = lrow0 + i * MF + blk_row(r);
                 float v = acc[i][j][r] + bv;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (has_r) v += res[r];
@@ -212,10 +234,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     }
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF>
 static int launch_cfg2(const GemmParams& p, hipStream_t s) {
-    using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N>;
-    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL>;
+    using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
+    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF>;
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -238,10 +260,10 @@ static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     return int(hipGetLastError());
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF = 32>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
-    if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true>(p, s);
-    return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false>(p, s);
+    if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF>(p, s);
+    return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF>(p, s);
 }
 
 // Debug/tuning hook (not part of the ABI header): force a tile configuration.  0 = heuristic.
@@ -270,6 +292,11 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
         case 6: return launch_cfg<64, 64, 16, 2, 2>(p, s);
         case 7: return launch_cfg<128, 64, 16, 2, 2>(p, s);
         case 8: return launch_cfg<256, 128, 16, 4, 2>(p, s);
+        case 9: return launch_cfg<32, 64, 32, 1, 4, 16>(p, s);   // waves 32x16 (2 blocks of 16x16)
+        case 10: return launch_cfg<64, 32, 32, 4, 1, 16>(p, s);  // waves 16x32
+        case 11: return launch_cfg<64, 64, 16, 2, 2, 16>(p, s);
+        case 12: return launch_cfg<64, 64, 32, 2, 2, 16>(p, s);  // waves 32x32 as 2x2 blocks of 16x16
+        case 13: return launch_cfg<32, 128, 32, 1, 4, 16>(p, s); // waves 32x32 as 2x2 blocks
         default: break;
     }
     // Tile choice, from tools/bench_kernels.py on MI355X (profiles/r01_gemm_tiles.txt).  Large
@@ -280,7 +307,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     if (tiles(128, 128) >= 1024) return launch_cfg<128, 128, 32, 2, 2>(p, s);
     if (tiles(128, 64) >= 1024) return launch_cfg<128, 64, 16, 2, 2>(p, s);
     if (tiles(64, 64) >= 512) return launch_cfg<64, 64, 16, 2, 2>(p, s);
-    return launch_cfg<64, 64, 32, 2, 2>(p, s);
+    return launch_cfg<32, 64, 32, 1, 4, 16>(p, s);  // 16x16x4 MFMA, 4 waves of 32x16
 }
 
 }  // namespace lamp

@@ -39,6 +39,29 @@ def test_linear_vs_torch_fp64(dev, M, K, N_):
     assert max_abs_diff(N.linear(x.to(dev), w.to(dev)), ref2) < 2e-5
 
 
+@pytest.mark.parametrize('cfg', list(range(1, 14)))
+def test_linear_every_tile_config(dev, cfg):
+    """Every GEMM tile configuration (32x32x2 and 16x16x4 MFMA variants) against fp64, on shapes with
+    ragged M / N edges and a K that is not a multiple of BK."""
+    import ctypes
+    from lamp_amd import _native as N
+    force = N.lib().lamp_debug_force_gemm_tile
+    force.argtypes = [ctypes.c_int]
+    try:
+        force(cfg)
+        for M, K, N_ in ((300, 512, 200), (67, 72, 130), (1, 4, 1)):
+            g = torch.Generator().manual_seed(cfg * 100 + M)
+            x = torch.randn(M, K, generator=g)
+            w = torch.randn(N_, K, generator=g) / K ** 0.5
+            b = torch.randn(N_, generator=g)
+            r = torch.randn(M, N_, generator=g)
+            ref = (x.double() @ w.double().t() + b.double()).clamp_min(0) + r.double()
+            out = N.linear(x.to(dev), w.to(dev), b.to(dev), residual=r.to(dev), relu=True)
+            assert max_abs_diff(out, ref) < 2e-5, (cfg, M, K, N_)
+    finally:
+        force(0)
+
+
 def test_linear_detects_transposed_or_shifted_tiles(dev):
     """Asymmetric operands: a swapped row/column mapping in the MFMA epilogue cannot pass."""
     from lamp_amd import _native as N

@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lamp_amd import _native as N  # noqa: E402
 
 TILES = {0: 'heuristic', 1: '128x128x32', 2: '64x64x32', 3: '128x64x32', 4: '64x128x32', 5: '128x128x16',
-         6: '64x64x16', 7: '128x64x16', 8: '256x128x16(8w)'}
+         6: '64x64x16', 7: '128x64x16', 8: '256x128x16(8w)', 9: 'm16:32x64x32',
+         10: 'm16:64x32x32', 11: 'm16:64x64x16', 12: 'm16:64x64x32', 13: 'm16:32x128x32'}
 
 
 def time_fn(fn, iters=30, warm=5):
