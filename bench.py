@@ -108,6 +108,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     ap.add_argument('--graph', action='store_true', help='replay the step from a captured HIP graph')
+    ap.add_argument('--streams', type=int, default=1, choices=[1, 2],
+                    help='HIP streams one forward spreads its batch over (lamp_set_forward_streams)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -126,6 +128,7 @@ def main():
 
     from lamp_amd import _native as N
     N.lib()
+    N.set_forward_streams(args.streams)
     w = WORKLOADS[args.workload]
     model, sd, blocked, seq, pos = build(w, args.batch, device, seed=rank)
     src = (seq.to(device), pos.to(device))
@@ -210,7 +213,8 @@ def main():
                                'layers, %d heads, label_mask=%s, fp32' %
                                (args.workload, args.batch, w['T'], w['L'], w['d'], w['dff'], w['h'], w['mask']),
                    'batch_per_gpu': args.batch, 'parallelism': 'batch-sharded x%d, no collectives' % n_gpus,
-                   'launch': 'hip-graph replay' if args.graph else 'eager (one lamp_forward call per step)'},
+                   'launch': 'hip-graph replay' if args.graph else 'eager (one lamp_forward call per step)',
+                   'streams_per_forward': args.streams},
         'roofline': {
             'bound': 'mfma', 'kernel': 'gemm_nt_kernel (fp32 MFMA 32x32x2), all launches of a forward',
             'achieved': gemm_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',

@@ -89,6 +89,7 @@ PROTOTYPES = {
     'lamp_diag_logits_fwd': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     'lamp_forward_workspace_bytes': (_sz, [C.POINTER(Model), _i32, _i32, _i32]),
     'lamp_forward': (C.c_int, [C.POINTER(Model), _vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(Aux), _vp, _sz, _vp]),
+    'lamp_set_forward_streams': (C.c_int, [_i32]),
     'lamp_prof_enable': (C.c_int, [_i32]),
     'lamp_prof_reset': (C.c_int, []),
     'lamp_prof_read': (C.c_int, [_i32, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -295,6 +296,11 @@ def diag_logits(y, w_out):
     check(lib().lamp_diag_logits_fwd(ptr(y), ptr(f32c(w_out)), B, L, d, ptr(out), stream()),
           'lamp_diag_logits_fwd')
     return out
+
+
+def set_forward_streams(n):
+    """1 or 2 HIP streams per lamp_forward call (see include/lamp_hip.h)."""
+    check(lib().lamp_set_forward_streams(int(n)), 'lamp_set_forward_streams')
 
 
 # ------------------------------------------------------------------ profiling

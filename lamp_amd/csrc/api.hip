@@ -358,51 +358,36 @@ size_t lamp_forward_workspace_bytes(const lamp_model* m, int32_t micro_batch, in
     return (pl.fixed_floats + pl.per_sample_floats * size_t(micro_batch)) * sizeof(float);
 }
 
-int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src_pos, int32_t B, int32_t T,
-                 float* logits, float* enc_output, const lamp_aux* aux, void* workspace, size_t workspace_bytes,
-                 lamp_stream_t stream) {
-    hipStream_t s = hipStream_t(stream);
-    if (!m || !src_seq || !logits || !enc_output || !workspace) return LAMP_E_NULL;
-    if (B <= 0 || T <= 0) return LAMP_E_DIMS;
-    if (!m->src_word_emb || !m->tgt_word_emb || !m->w_out) return LAMP_E_NULL;
-    if (m->position_enc && !src_pos) return LAMP_E_NULL;
+// Samples [b_lo, b_hi) of the batch, in micro-batches that fit `workspace`, all on stream `s`.
+static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* src_seq, const int64_t* src_pos,
+                         int32_t B, int32_t b_lo, int32_t b_hi, int32_t T, float* logits, float* enc_output,
+                         const lamp_aux* aux, void* workspace, size_t workspace_bytes, hipStream_t s) {
     const bool want_enc_attn = aux && aux->enc_self_attn;
-    FwdPlan pl;
-    LAMP_CK(make_plan(m, T, want_enc_attn, &pl));
     const int d = m->d_model, dff = m->d_inner, dk = m->d_k, dv = m->d_v, L = m->n_labels;
-    if ((d & 3) || (dff & 3) || (dk & 3) || (dv & 3)) return LAMP_E_UNSUPPORTED;
-
     const size_t ws_floats = workspace_bytes / sizeof(float);
     if (ws_floats < pl.fixed_floats + pl.per_sample_floats) return LAMP_E_WORKSPACE;
     int64_t mb = int64_t((ws_floats - pl.fixed_floats) / pl.per_sample_floats);
-    if (mb > B) mb = B;
+    if (mb > b_hi - b_lo) mb = b_hi - b_lo;
     if (mb > 65535) mb = 65535;  // grid.z of the attention launch
 
-    Carver c(workspace, workspace_bytes);
     const int Rq = want_enc_attn ? pl.R : L;
-    float* H = c.take(size_t(mb) * pl.R * dff);
-    MhaScratch sc;
-    sc.Q = c.take(size_t(mb) * Rq * pl.hdk);
-    sc.K = c.take(size_t(mb) * pl.R * pl.hdk);
-    sc.V = c.take(size_t(mb) * pl.R * pl.hdv);
-    sc.A = c.take(size_t(mb) * Rq * pl.hdv);
-    float* Y = c.take(size_t(mb) * L * d);
-    if (!c.ok) {
-        // rounding slack exhausted: retry with one sample fewer
-        if (mb <= 1) return LAMP_E_WORKSPACE;
-        --mb;
-        c = Carver(workspace, workspace_bytes);
+    float *H = nullptr, *Y = nullptr;
+    MhaScratch sc{};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        Carver c(workspace, workspace_bytes);
         H = c.take(size_t(mb) * pl.R * dff);
         sc.Q = c.take(size_t(mb) * Rq * pl.hdk);
         sc.K = c.take(size_t(mb) * pl.R * pl.hdk);
         sc.V = c.take(size_t(mb) * pl.R * pl.hdv);
         sc.A = c.take(size_t(mb) * Rq * pl.hdv);
         Y = c.take(size_t(mb) * L * d);
-        if (!c.ok) return LAMP_E_WORKSPACE;
+        if (c.ok) break;
+        if (attempt == 1 || mb <= 1) return LAMP_E_WORKSPACE;
+        --mb;  // rounding slack exhausted: one sample fewer
     }
 
-    for (int64_t b0 = 0; b0 < B; b0 += mb) {
-        const int nb = int(B - b0 < mb ? B - b0 : mb);
+    for (int64_t b0 = b_lo; b0 < b_hi; b0 += mb) {
+        const int nb = int(b_hi - b0 < mb ? b_hi - b0 : mb);
         const int64_t* seq = src_seq + b0 * T;
         const int64_t* pos = src_pos ? src_pos + b0 * T : nullptr;
         float* x = enc_output + b0 * int64_t(T) * d;  // encoder state lives in the output buffer
@@ -414,11 +399,11 @@ int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src
         for (int i = 0; i < m->n_layers_enc; ++i) {
             const lamp_enc_layer& l = m->enc_layers[i];
             if (want_enc_attn && aux->enc_self_attn[i]) {
-                // lamp/Layers.py:16 -- only the attention map of this block is ever observable
-                float* P = aux->enc_self_attn[i];
-                // maps are (h*B, T, T) over the WHOLE batch: write this micro-batch's samples in place
-                if (nb != B) return LAMP_E_UNSUPPORTED;  // maps need the batch in one micro-batch
-                LAMP_CK(mha_core(x, false, x, nb, T, T, d, dk, dv, l.slf_attn, &pad_mask, nullptr, P, sc, s));
+                // lamp/Layers.py:16 -- only the attention map of this block is ever observable.  Maps are
+                // (h*B, T, T) over the WHOLE batch, so they need the batch in one micro-batch.
+                if (nb != B) return LAMP_E_UNSUPPORTED;
+                LAMP_CK(mha_core(x, false, x, nb, T, T, d, dk, dv, l.slf_attn, &pad_mask, nullptr,
+                                 aux->enc_self_attn[i], sc, s));
             }
             LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s));  // lamp/Layers.py:18
         }
@@ -452,12 +437,85 @@ int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src
             LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn2, Y, H, s));  // lamp/Layers.py:45
             if (i + 1 < m->n_layers_dec) LAMP_CK(int_pred());       // all but the last (lamp/Models.py:130)
         }
-        if (m->n_layers_dec == 0) return LAMP_E_DIMS;
 
         // ---- read-out (lamp/Models.py:124-126) ----
         LAMP_CK(launch_diag(Y, m->w_out, nb, L, d, logits + b0 * L, s));
     }
     return 0;
+}
+
+// Side streams for lamp_set_forward_streams(2): one per device, created on first use and kept (an
+// immutable handle, like the kernels' attributes); fork/join with the caller's stream through events.
+namespace {
+std::mutex g_side_mu;
+hipStream_t g_side_stream[64] = {};
+hipEvent_t g_fork_ev[64] = {}, g_join_ev[64] = {};
+int g_forward_streams = 1;
+
+int side_stream(hipStream_t* st, hipEvent_t* fork, hipEvent_t* join) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return int(e);
+    if (dev < 0 || dev >= 64) return LAMP_E_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    if (!g_side_stream[dev]) {
+        if ((e = hipStreamCreateWithFlags(&g_side_stream[dev], hipStreamNonBlocking)) != hipSuccess) return int(e);
+        if ((e = hipEventCreateWithFlags(&g_fork_ev[dev], hipEventDisableTiming)) != hipSuccess) return int(e);
+        if ((e = hipEventCreateWithFlags(&g_join_ev[dev], hipEventDisableTiming)) != hipSuccess) return int(e);
+    }
+    *st = g_side_stream[dev];
+    *fork = g_fork_ev[dev];
+    *join = g_join_ev[dev];
+    return 0;
+}
+}  // namespace
+
+int lamp_set_forward_streams(int32_t n) {
+    if (n < 1 || n > 2) return LAMP_E_UNSUPPORTED;
+    g_forward_streams = n;
+    return 0;
+}
+
+int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src_pos, int32_t B, int32_t T,
+                 float* logits, float* enc_output, const lamp_aux* aux, void* workspace, size_t workspace_bytes,
+                 lamp_stream_t stream) {
+    hipStream_t s = hipStream_t(stream);
+    if (!m || !src_seq || !logits || !enc_output || !workspace) return LAMP_E_NULL;
+    if (B <= 0 || T <= 0) return LAMP_E_DIMS;
+    if (!m->src_word_emb || !m->tgt_word_emb || !m->w_out) return LAMP_E_NULL;
+    if (m->position_enc && !src_pos) return LAMP_E_NULL;
+    if (m->n_layers_dec <= 0) return LAMP_E_DIMS;
+    const bool want_maps = aux && (aux->enc_self_attn || aux->dec_self_attn || aux->dec_enc_attn);
+    FwdPlan pl;
+    LAMP_CK(make_plan(m, T, aux && aux->enc_self_attn, &pl));
+    if ((m->d_model & 3) || (m->d_inner & 3) || (m->d_k & 3) || (m->d_v & 3)) return LAMP_E_UNSUPPORTED;
+
+    // Samples are independent: with two streams the halves of the batch run concurrently, so that one
+    // half's launch gaps, ramp-up and tail hide under the other half's kernels (the batch-32 kernels
+    // are a few tens of microseconds each).  Results are bit-identical to the one-stream order.
+    const size_t half_ws = (workspace_bytes / 2) & ~size_t(255);
+    const size_t need1 = (pl.fixed_floats + pl.per_sample_floats) * sizeof(float);
+    if (g_forward_streams == 2 && B >= 2 && !want_maps && half_ws >= need1) {
+        hipStream_t side;
+        hipEvent_t fork, join;
+        LAMP_CK(side_stream(&side, &fork, &join));
+        const int32_t mid = B / 2;
+        hipError_t e;
+        if ((e = hipEventRecord(fork, s)) != hipSuccess) return int(e);
+        if ((e = hipStreamWaitEvent(side, fork, 0)) != hipSuccess) return int(e);
+        int rc = forward_range(m, pl, src_seq, src_pos, B, mid, B, T, logits, enc_output, aux,
+                               static_cast<char*>(workspace) + half_ws, half_ws, side);
+        // always join, even on error, so the caller's stream stays ordered after the side work
+        hipError_t e1 = hipEventRecord(join, side);
+        int rc0 = forward_range(m, pl, src_seq, src_pos, B, 0, mid, T, logits, enc_output, aux, workspace, half_ws, s);
+        hipError_t e2 = hipStreamWaitEvent(s, join, 0);
+        if (rc) return rc;
+        if (rc0) return rc0;
+        if (e1 != hipSuccess) return int(e1);
+        if (e2 != hipSuccess) return int(e2);
+        return 0;
+    }
+    return forward_range(m, pl, src_seq, src_pos, B, 0, B, T, logits, enc_output, aux, workspace, workspace_bytes, s);
 }
 
 // ------------------------------------------------------------------ profiling ABI

@@ -644,14 +644,15 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
         return LAMP_E_UNSUPPORTED;  // 32-bit offsets inside one (sample, head) slice
     // Small grids: split the keys over the four waves of a workgroup until there are ~2 workgroups per CU.
     const int nt = (p.lk + 31) / 32;
-    const int64_t bh = int64_t(p.B) * p.H;
     int mode = g_force_attn;
     if (mode == 0) {
-        // Measured on MI355X (profiles/r01_attn_variants.txt): the LDS-tiled kernel wins whenever its
-        // grid fills the chip; the 2-way key split wins for grids of <= 256 workgroups with >= 4 key tiles
-        // (one resident workgroup per CU at 1 wave/SIMD, so a 4-way split's 384 workgroups take two rounds).
-        const int64_t wg2 = bh * ((p.lq + 63) / 64);
-        mode = (wg2 <= 256 && nt >= 4) ? 3 : 1;
+        // The variant must NOT depend on the batch size (a 2-way key split sums in a different order than
+        // the sequential online softmax, and samples must come out bit-identical for every batch / shard):
+        // choose by the per-sample shape only.  Few queries (<= 128: at most one workgroup per (sample,
+        // head) in the LDS-tiled kernel, e.g. reuters' 90 labels) and >= 4 key tiles -> 2-way key split in
+        // the register-streaming kernel (41-45 us vs 55-67 us at batch 32, profiles/r01_attn_variants.txt);
+        // otherwise the LDS-tiled kernel.
+        mode = (p.lq <= 128 && nt >= 4) ? 3 : 1;
     }
     if (mode == 1 && p.O == nullptr) mode = 2;
     if (mode >= 2) {

@@ -280,6 +280,9 @@ def test_samples_are_independent_bitwise(dev):
         part, enc_part, _ = m((seq[lo:hi], spos[lo:hi]), None, None, None)
         assert torch.equal(part, full[lo:hi])
         assert torch.equal(enc_part, enc_full[lo:hi])
+    # a batch twice as large (other tile / grid choices may apply) still reproduces every sample
+    big, _, _ = m((torch.cat([seq, seq]), torch.cat([spos, spos])), None, None, None)
+    assert torch.equal(big[:32], full) and torch.equal(big[32:], full)
     perm = torch.randperm(32, generator=torch.Generator().manual_seed(1)).to(dev)
     shuffled, _, _ = m((seq[perm], spos[perm]), None, None, None)
     assert torch.equal(shuffled, full[perm])
@@ -287,6 +290,36 @@ def test_samples_are_independent_bitwise(dev):
     m.workspace_limit_bytes = 96 << 20
     split, enc_split, _ = m((seq, spos), None, None, None)
     assert torch.equal(split, full) and torch.equal(enc_split, enc_full)
+
+
+def test_two_stream_forward_is_bit_identical(dev):
+    """lamp_set_forward_streams(2): the halves of the batch run concurrently on two HIP streams; the
+    results must not change by a bit, for odd batches, int_preds and micro-batched runs alike."""
+    from lamp_amd import _native as N
+    cfg = list(CONFIGS['reuters_ragged'])
+    cfg[8] = 7
+    cfg[10] = [302, 20, 150, 77, 201, 33, 9]
+    m, sd, blocked, seq, spos, h = make_case(tuple(cfg), dev)
+    src = (seq.to(dev), spos.to(dev))
+    one, enc_one, _ = m(src, None, None, None)
+    _, _, ips_one = m(src, None, None, None, int_preds=True)
+    try:
+        N.set_forward_streams(2)
+        for _ in range(3):
+            two, enc_two, _ = m(src, None, None, None)
+            assert torch.equal(two, one) and torch.equal(enc_two, enc_one)
+        _, _, ips_two = m(src, None, None, None, int_preds=True)
+        for a, b in zip(ips_one, ips_two):
+            assert torch.equal(a, b)
+        m.workspace_limit_bytes = 64 << 20
+        split, _, _ = m(src, None, None, None)
+        assert torch.equal(split, one)
+        # maps: falls back to one stream; the map-writing kernels use an exact two-pass softmax, so
+        # these logits agree with the default path to rounding, not bitwise
+        lg, _, _, _ = m(src, None, None, None, return_attns=True)
+        assert max_abs_diff(lg, one) < 1e-5
+    finally:
+        N.set_forward_streams(1)
 
 
 def test_trailing_padding_does_not_change_results(dev):

@@ -62,6 +62,30 @@ def gemm():
         print(row)
 
 
+def steady():
+    """K = 512 at growing M: separates per-tile efficiency from launch / tail / quantisation effects."""
+    lib = N.lib()
+    force = lib.lamp_debug_force_gemm_tile
+    force.argtypes = [ctypes.c_int]
+    dev = torch.device('cuda:0')
+    print('%-22s' % 'M x 512 x 512' + ''.join('%16s' % TILES[t] for t in (1, 2, 6, 7, 9, 12)))
+    for M in (2880, 9664, 19328, 38656, 77312, 154624):
+        x = torch.randn(M, 512, device=dev)
+        w = torch.randn(512, 512, device=dev) / 512 ** 0.5
+        out = torch.empty(M, 512, device=dev)
+        row = '%-22d' % M
+        for t in (1, 2, 6, 7, 9, 12):
+            force(t)
+
+            def fn():
+                N.check(lib.lamp_linear_fwd(x.data_ptr(), M, 512, 512, w.data_ptr(), 512, 512, None, None, 0, 0,
+                                            out.data_ptr(), 512, N.stream()), 'linear')
+            us = time_fn(fn, iters=20)
+            row += '%9.1f/%5.1fT' % (us, 2.0 * M * 512 * 512 / us / 1e6)
+        force(0)
+        print(row)
+
+
 def attn():
     dev = torch.device('cuda:0')
     cases = [('reuters enc-attn', 32, 4, 90, 302, 128), ('reuters self', 32, 4, 90, 90, 128),
@@ -95,4 +119,4 @@ def attn():
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
-    {'gemm': gemm, 'attn': attn}[which]()
+    {'gemm': gemm, 'attn': attn, 'steady': steady}[which]()
