@@ -157,10 +157,9 @@ class LAMP(nn.Module):
         lib = N.lib()
         per_sample = lib.lamp_forward_workspace_bytes(C.byref(model), 1, T, int(want_attn))
         fixed = 2 * per_sample - lib.lamp_forward_workspace_bytes(C.byref(model), 2, T, int(want_attn))
-        # enough for the whole batch in one pass -- also when lamp_forward splits it over two streams,
-        # each taking half of the workspace -- unless that exceeds the cap (then it micro-batches)
-        whole = 2 * (fixed + (per_sample - fixed) * ((B + 1) // 2)) + 4096
-        budget = max(2 * per_sample + 4096, min(whole, self.workspace_limit_bytes))
+        # enough for the whole batch in one pass unless that exceeds the cap (then it micro-batches)
+        whole = fixed + (per_sample - fixed) * B + 4096
+        budget = max(per_sample + 4096, min(whole, self.workspace_limit_bytes))
         if want_attn:  # attention maps need the whole batch in one micro-batch
             budget = whole
         ws = N.workspace(budget, dev)

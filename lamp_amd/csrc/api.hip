@@ -110,7 +110,7 @@ struct MhaScratch {
 // `out == nullptr` computes the attention map only (the reference's dead encoder self-attention).
 static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, int lq, int lk, int d, int dk,
                     int dv, const lamp_mha_weights& w, const lamp_mask* mask, float* out, float* attn,
-                    const MhaScratch& sc, hipStream_t s) {
+                    const MhaScratch& sc, hipStream_t s, bool kv_ready = false) {
     const int h = w.n_head;
     if (h < 1 || dk < 1 || dv < 1) return LAMP_E_DIMS;
     if (!w.w_qs || !w.w_ks || !w.w_vs || (out && (!w.ln_g || !w.ln_b))) return LAMP_E_NULL;
@@ -132,7 +132,9 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
             float* C[1] = {sc.Q};
             LAMP_CK(linear(xq, Mq, d, d, W, 1, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
         }
-        if (need_v && hdk == hdv) {
+        if (kv_ready) {
+            // sc.K / sc.V were projected earlier (on the side stream, see forward_range)
+        } else if (need_v && hdk == hdv) {
             const float* W[2] = {w.w_ks, w.w_vs};
             float* C[2] = {sc.K, sc.V};
             LAMP_CK(linear(xkv, Mk, d, d, W, 2, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
@@ -177,6 +179,23 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
         return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, out, s);
     }
     return launch_layernorm(sc.A, M, d, w.ln_g, w.ln_b, 1e-5f, xq, r_mod, out, s);
+}
+
+// K and V projections of one attention block on their own (same launches mha_core would issue).
+static int project_kv(const float* xkv, int64_t Mk, int d, int dk, int dv, const lamp_mha_weights& w, float* K,
+                      float* V, hipStream_t s) {
+    const int hdk = w.n_head * dk, hdv = w.n_head * dv;
+    if (hdk == hdv) {
+        const float* W[2] = {w.w_ks, w.w_vs};
+        float* C[2] = {K, V};
+        return linear(xkv, Mk, d, d, W, 2, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s);
+    }
+    const float* Wk[1] = {w.w_ks};
+    float* Ck[1] = {K};
+    LAMP_CK(linear(xkv, Mk, d, d, Wk, 1, hdk, d, nullptr, nullptr, 0, 0, Ck, hdk, s));
+    const float* Wv[1] = {w.w_vs};
+    float* Cv[1] = {V};
+    return linear(xkv, Mk, d, d, Wv, 1, hdv, d, nullptr, nullptr, 0, 0, Cv, hdv, s);
 }
 
 // PositionwiseFeedForward.forward (lamp/SubLayers.py:133-142); out may alias x.
@@ -329,6 +348,7 @@ struct FwdPlan {
     size_t per_sample_floats;  // times micro-batch
     int R;                     // rows per sample of the widest activation
     int hdk, hdv;
+    size_t side_kv_floats;     // per sample; only carved in two-stream mode
 };
 
 static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
@@ -349,29 +369,69 @@ static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
     pl->fixed_floats = 64 * 8;
     pl->per_sample_floats = size_t(R) * m->d_inner + size_t(Rq) * pl->hdk + size_t(R) * pl->hdk +
                             size_t(R) * pl->hdv + size_t(Rq) * pl->hdv + size_t(L) * m->d_model;
+    // K/V of decoder layers >= 1, projected ahead on the side stream (lamp_set_forward_streams(2))
+    pl->side_kv_floats = m->n_layers_dec > 1 ? size_t(m->n_layers_dec - 1) * T * (pl->hdk + pl->hdv) : 0;
     return 0;
 }
 
 size_t lamp_forward_workspace_bytes(const lamp_model* m, int32_t micro_batch, int32_t T, int32_t want_attn) {
     FwdPlan pl;
     if (micro_batch <= 0 || make_plan(m, T, want_attn, &pl) != 0) return 0;
-    return (pl.fixed_floats + pl.per_sample_floats * size_t(micro_batch)) * sizeof(float);
+    return (pl.fixed_floats + (pl.per_sample_floats + pl.side_kv_floats) * size_t(micro_batch)) * sizeof(float);
 }
 
-// Samples [b_lo, b_hi) of the batch, in micro-batches that fit `workspace`, all on stream `s`.
+// Side stream for lamp_set_forward_streams(2): one per device, created on first use and kept (an
+// immutable handle, like the kernels' attributes); fork/join with the caller's stream through events.
+namespace {
+constexpr int MAX_SIDE_EVENTS = 16;
+struct SideState {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr;
+    hipEvent_t ready[MAX_SIDE_EVENTS] = {};
+};
+std::mutex g_side_mu;
+SideState g_side[64];
+int g_forward_streams = 1;
+
+int side_state(SideState** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return int(e);
+    if (dev < 0 || dev >= 64) return LAMP_E_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideState& st = g_side[dev];
+    if (!st.stream) {
+        if ((e = hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking)) != hipSuccess) return int(e);
+        if ((e = hipEventCreateWithFlags(&st.fork, hipEventDisableTiming)) != hipSuccess) return int(e);
+        for (int i = 0; i < MAX_SIDE_EVENTS; ++i)
+            if ((e = hipEventCreateWithFlags(&st.ready[i], hipEventDisableTiming)) != hipSuccess) return int(e);
+    }
+    *out = &st;
+    return 0;
+}
+}  // namespace
+
+// The whole batch in micro-batches that fit `workspace`.  `side` (nullable): a second stream on which the
+// K/V projections of decoder layers >= 1 are issued as soon as the encoder output exists; they depend on
+// nothing else, are throughput bound (M = B*T rows), and so fill the CUs that decoder layer 0's small,
+// latency-bound kernels (M = B*L rows) leave idle.  Same kernels on the same data: bit-identical results.
 static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* src_seq, const int64_t* src_pos,
-                         int32_t B, int32_t b_lo, int32_t b_hi, int32_t T, float* logits, float* enc_output,
-                         const lamp_aux* aux, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                         int32_t B, int32_t T, float* logits, float* enc_output, const lamp_aux* aux,
+                         void* workspace, size_t workspace_bytes, hipStream_t s, SideState* side) {
     const bool want_enc_attn = aux && aux->enc_self_attn;
     const int d = m->d_model, dff = m->d_inner, dk = m->d_k, dv = m->d_v, L = m->n_labels;
+    const int n_ahead = side ? m->n_layers_dec - 1 : 0;  // layers whose K/V are projected ahead
+    const size_t per_sample = pl.per_sample_floats + (side ? pl.side_kv_floats : 0);
     const size_t ws_floats = workspace_bytes / sizeof(float);
-    if (ws_floats < pl.fixed_floats + pl.per_sample_floats) return LAMP_E_WORKSPACE;
-    int64_t mb = int64_t((ws_floats - pl.fixed_floats) / pl.per_sample_floats);
-    if (mb > b_hi - b_lo) mb = b_hi - b_lo;
+    if (ws_floats < pl.fixed_floats + per_sample) return LAMP_E_WORKSPACE;
+    int64_t mb = int64_t((ws_floats - pl.fixed_floats) / per_sample);
+    if (mb > B) mb = B;
     if (mb > 65535) mb = 65535;  // grid.z of the attention launch
 
     const int Rq = want_enc_attn ? pl.R : L;
     float *H = nullptr, *Y = nullptr;
+    float* Kahead[MAX_SIDE_EVENTS] = {};
+    float* Vahead[MAX_SIDE_EVENTS] = {};
     MhaScratch sc{};
     for (int attempt = 0; attempt < 2; ++attempt) {
         Carver c(workspace, workspace_bytes);
@@ -381,13 +441,17 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         sc.V = c.take(size_t(mb) * pl.R * pl.hdv);
         sc.A = c.take(size_t(mb) * Rq * pl.hdv);
         Y = c.take(size_t(mb) * L * d);
+        for (int i = 0; i < n_ahead; ++i) {
+            Kahead[i] = c.take(size_t(mb) * T * pl.hdk);
+            Vahead[i] = c.take(size_t(mb) * T * pl.hdv);
+        }
         if (c.ok) break;
         if (attempt == 1 || mb <= 1) return LAMP_E_WORKSPACE;
         --mb;  // rounding slack exhausted: one sample fewer
     }
 
-    for (int64_t b0 = b_lo; b0 < b_hi; b0 += mb) {
-        const int nb = int(b_hi - b0 < mb ? b_hi - b0 : mb);
+    for (int64_t b0 = 0; b0 < B; b0 += mb) {
+        const int nb = int(B - b0 < mb ? B - b0 : mb);
         const int64_t* seq = src_seq + b0 * T;
         const int64_t* pos = src_pos ? src_pos + b0 * T : nullptr;
         float* x = enc_output + b0 * int64_t(T) * d;  // encoder state lives in the output buffer
@@ -408,6 +472,24 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s));  // lamp/Layers.py:18
         }
 
+        // ---- fork: K/V of decoder layers >= 1 on the side stream ----
+        if (n_ahead > 0) {
+            hipError_t e;
+            if ((e = hipEventRecord(side->fork, s)) != hipSuccess) return int(e);
+            if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return int(e);
+            int rc = 0;
+            for (int i = 0; i < n_ahead && rc == 0; ++i) {
+                rc = project_kv(x, Me, d, dk, dv, m->dec_layers[i + 1].enc_attn, Kahead[i], Vahead[i], side->stream);
+                hipError_t e2 = hipEventRecord(side->ready[i], side->stream);
+                if (rc == 0 && e2 != hipSuccess) rc = int(e2);
+            }
+            if (rc) {  // keep the caller's stream ordered after whatever was enqueued, then report
+                (void)hipEventRecord(side->ready[0], side->stream);
+                (void)hipStreamWaitEvent(s, side->ready[0], 0);
+                return rc;
+            }
+        }
+
         // ---- GraphDecoder.forward (lamp/Decoders.py:127-163) ----
         lamp_mask label_mask{m->label_mask ? LAMP_MASK_U8 : LAMP_MASK_NONE, 0, m->label_mask, 0, L};
         const int64_t Md = int64_t(nb) * L;
@@ -418,24 +500,39 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             ++n_int;
             return 0;
         };
-        for (int i = 0; i < m->n_layers_dec; ++i) {
+        int rc = 0;
+        for (int i = 0; i < m->n_layers_dec && rc == 0; ++i) {
             const lamp_dec_layer& l = m->dec_layers[i];
             float* Penc = (aux && aux->dec_enc_attn) ? aux->dec_enc_attn[i] : nullptr;
             float* Pslf = (aux && aux->dec_self_attn) ? aux->dec_self_attn[i] : nullptr;
-            if ((Penc || Pslf) && nb != B) return LAMP_E_UNSUPPORTED;
+            if ((Penc || Pslf) && nb != B) { rc = LAMP_E_UNSUPPORTED; break; }
+            MhaScratch sci = sc;
+            const bool ahead = n_ahead > 0 && i >= 1;
+            if (ahead) {  // join: this layer's K/V come from the side stream
+                hipError_t e = hipStreamWaitEvent(s, side->ready[i - 1], 0);
+                if (e != hipSuccess) { rc = int(e); break; }
+                sci.K = Kahead[i - 1];
+                sci.V = Vahead[i - 1];
+            }
             // input->label messages (lamp/Layers.py:35); layer 0's query is the label table itself
             if (i == 0)
-                LAMP_CK(mha_core(m->tgt_word_emb, true, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sc, s));
+                rc = mha_core(m->tgt_word_emb, true, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s, ahead);
             else
-                LAMP_CK(mha_core(Y, false, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sc, s));
-            LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn1, Y, H, s));  // lamp/Layers.py:36
+                rc = mha_core(Y, false, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s, ahead);
+            if (rc) break;
+            if ((rc = ffn_core(Y, Md, d, dff, l.pos_ffn1, Y, H, s))) break;  // lamp/Layers.py:36
             if (l.slf_attn.present) {
-                LAMP_CK(int_pred());  // dec_output_int, lamp/Decoders.py:149-151
+                if ((rc = int_pred())) break;  // dec_output_int, lamp/Decoders.py:149-151
                 // label->label messages over the label graph (lamp/Layers.py:40)
-                LAMP_CK(mha_core(Y, false, Y, nb, L, L, d, dk, dv, l.slf_attn, &label_mask, Y, Pslf, sc, s));
+                if ((rc = mha_core(Y, false, Y, nb, L, L, d, dk, dv, l.slf_attn, &label_mask, Y, Pslf, sc, s))) break;
             }
-            LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn2, Y, H, s));  // lamp/Layers.py:45
-            if (i + 1 < m->n_layers_dec) LAMP_CK(int_pred());       // all but the last (lamp/Models.py:130)
+            if ((rc = ffn_core(Y, Md, d, dff, l.pos_ffn2, Y, H, s))) break;  // lamp/Layers.py:45
+            if (i + 1 < m->n_layers_dec) rc = int_pred();                   // all but the last (lamp/Models.py:130)
+        }
+        if (rc) {
+            // never leave side-stream work unordered w.r.t. the caller's stream
+            for (int i = 0; i < n_ahead; ++i) (void)hipStreamWaitEvent(s, side->ready[i], 0);
+            return rc;
         }
 
         // ---- read-out (lamp/Models.py:124-126) ----
@@ -443,32 +540,6 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
     }
     return 0;
 }
-
-// Side streams for lamp_set_forward_streams(2): one per device, created on first use and kept (an
-// immutable handle, like the kernels' attributes); fork/join with the caller's stream through events.
-namespace {
-std::mutex g_side_mu;
-hipStream_t g_side_stream[64] = {};
-hipEvent_t g_fork_ev[64] = {}, g_join_ev[64] = {};
-int g_forward_streams = 1;
-
-int side_stream(hipStream_t* st, hipEvent_t* fork, hipEvent_t* join) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return int(e);
-    if (dev < 0 || dev >= 64) return LAMP_E_UNSUPPORTED;
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    if (!g_side_stream[dev]) {
-        if ((e = hipStreamCreateWithFlags(&g_side_stream[dev], hipStreamNonBlocking)) != hipSuccess) return int(e);
-        if ((e = hipEventCreateWithFlags(&g_fork_ev[dev], hipEventDisableTiming)) != hipSuccess) return int(e);
-        if ((e = hipEventCreateWithFlags(&g_join_ev[dev], hipEventDisableTiming)) != hipSuccess) return int(e);
-    }
-    *st = g_side_stream[dev];
-    *fork = g_fork_ev[dev];
-    *join = g_join_ev[dev];
-    return 0;
-}
-}  // namespace
 
 int lamp_set_forward_streams(int32_t n) {
     if (n < 1 || n > 2) return LAMP_E_UNSUPPORTED;
@@ -485,37 +556,17 @@ int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src
     if (!m->src_word_emb || !m->tgt_word_emb || !m->w_out) return LAMP_E_NULL;
     if (m->position_enc && !src_pos) return LAMP_E_NULL;
     if (m->n_layers_dec <= 0) return LAMP_E_DIMS;
-    const bool want_maps = aux && (aux->enc_self_attn || aux->dec_self_attn || aux->dec_enc_attn);
     FwdPlan pl;
     LAMP_CK(make_plan(m, T, aux && aux->enc_self_attn, &pl));
     if ((m->d_model & 3) || (m->d_inner & 3) || (m->d_k & 3) || (m->d_v & 3)) return LAMP_E_UNSUPPORTED;
 
-    // Samples are independent: with two streams the halves of the batch run concurrently, so that one
-    // half's launch gaps, ramp-up and tail hide under the other half's kernels (the batch-32 kernels
-    // are a few tens of microseconds each).  Results are bit-identical to the one-stream order.
-    const size_t half_ws = (workspace_bytes / 2) & ~size_t(255);
-    const size_t need1 = (pl.fixed_floats + pl.per_sample_floats) * sizeof(float);
-    if (g_forward_streams == 2 && B >= 2 && !want_maps && half_ws >= need1) {
-        hipStream_t side;
-        hipEvent_t fork, join;
-        LAMP_CK(side_stream(&side, &fork, &join));
-        const int32_t mid = B / 2;
-        hipError_t e;
-        if ((e = hipEventRecord(fork, s)) != hipSuccess) return int(e);
-        if ((e = hipStreamWaitEvent(side, fork, 0)) != hipSuccess) return int(e);
-        int rc = forward_range(m, pl, src_seq, src_pos, B, mid, B, T, logits, enc_output, aux,
-                               static_cast<char*>(workspace) + half_ws, half_ws, side);
-        // always join, even on error, so the caller's stream stays ordered after the side work
-        hipError_t e1 = hipEventRecord(join, side);
-        int rc0 = forward_range(m, pl, src_seq, src_pos, B, 0, mid, T, logits, enc_output, aux, workspace, half_ws, s);
-        hipError_t e2 = hipStreamWaitEvent(s, join, 0);
-        if (rc) return rc;
-        if (rc0) return rc0;
-        if (e1 != hipSuccess) return int(e1);
-        if (e2 != hipSuccess) return int(e2);
-        return 0;
+    SideState* side = nullptr;
+    if (g_forward_streams == 2 && m->n_layers_dec >= 2 && m->n_layers_dec - 1 <= MAX_SIDE_EVENTS) {
+        // only when the workspace holds at least one sample including the look-ahead K/V buffers
+        const size_t need = (pl.fixed_floats + pl.per_sample_floats + pl.side_kv_floats) * sizeof(float);
+        if (workspace_bytes >= need) LAMP_CK(side_state(&side));
     }
-    return forward_range(m, pl, src_seq, src_pos, B, 0, B, T, logits, enc_output, aux, workspace, workspace_bytes, s);
+    return forward_range(m, pl, src_seq, src_pos, B, T, logits, enc_output, aux, workspace, workspace_bytes, s, side);
 }
 
 // ------------------------------------------------------------------ profiling ABI

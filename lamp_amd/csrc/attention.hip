@@ -113,21 +113,32 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                             : static_cast<const void*>(p.K),
                         p.mask_kind == LAMP_MASK_KEY_TOKENS_I64 ? uint64_t(p.lk) * 8u : 0);
 
-    // S^T tile for this wave's 32 queries vs keys [kt*32, kt*32+32), masked, in the log2 domain.
-    auto scores = [&](int kt, int buf, f32x16& s) {
-        // mask bytes first, so their latency hides under the MFMAs
-        unsigned blocked = 0;  // bit r set = blocked
-        const int kbase = kt * 32 + 4 * hi;
+    // Mask bytes / token-is-PAD flags are fetched ONE TILE AHEAD (next to the K/V prefetch) so that their
+    // wait never lands in front of the MFMAs -- hipcc places the compare right behind the load.
+    unsigned mraw[16], mnext[16];
+    auto load_mask = [&](int kt, unsigned (&dst)[16]) {
+        const int kb = kt * 32 + 4 * hi;
         if (p.mask_kind == LAMP_MASK_U8) {
-            const unsigned mo = unsigned(int64_t(qc) * p.m_sq) + unsigned(kbase);
+            const unsigned mo = unsigned(int64_t(qc) * p.m_sq) + unsigned(kb);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                blocked |= (bload_u8(rsM, mo + (r & 3) + 8 * (r >> 2)) != 0 ? 1u : 0u) << r;
+            for (int r = 0; r < 16; ++r) dst[r] = bload_u8(rsM, mo + (r & 3) + 8 * (r >> 2));
         } else if (p.mask_kind == LAMP_MASK_KEY_TOKENS_I64) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)  // past lk: reads 0 == PAD == blocked (and is forced to -inf below anyway)
-                blocked |= (bload_u64(rsM, unsigned(kbase + (r & 3) + 8 * (r >> 2)) * 8u) == 0 ? 1u : 0u) << r;
+            for (int r = 0; r < 16; ++r)
+                dst[r] = bload_u64(rsM, unsigned(kb + (r & 3) + 8 * (r >> 2)) * 8u) == 0 ? 1u : 0u;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r] = 0u;
         }
+    };
+    auto rotate_mask = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mraw[r] = mnext[r];
+    };
+
+    // S^T tile for this wave's 32 queries vs keys [kt*32, kt*32+32), masked, in the log2 domain.
+    auto scores = [&](int kt, int buf, f32x16& s) {
+        const int kbase = kt * 32 + 4 * hi;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         const float* kp = Ks + buf * 32 * KS + l31 * KS + hi * 4;
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kbase + (r & 3) + 8 * (r >> 2);
-            if (key >= p.lk || ((blocked >> r) & 1u)) s[r] = -INFINITY;
+            if (key >= p.lk || mraw[r] != 0) s[r] = -INFINITY;
         }
     };
 
@@ -169,11 +180,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     if constexpr (WRITE_P) {
         // ---- pass 1: exact row max and row sum (K only) ----
         gload(0, false);
+        load_mask(0, mraw);
         lstore(0, false);
         __syncthreads();
         for (int kt = 0; kt < nt; ++kt) {
             const int buf = kt & 1;
             if (kt + 1 < nt) gload(kt + 1, false);
+            load_mask(kt + 1, mnext);
             if (wave_active) {
                 f32x16 s;
                 scores(kt, buf, s);
@@ -190,6 +203,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                 l_run = l_run * exp2f(m_run - m_use) + psum;
                 m_run = m_new;
             }
+            rotate_mask();
             if (kt + 1 < nt) lstore(buf ^ 1, false);
             __syncthreads();
         }
@@ -199,11 +213,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         float* Prow = p.P + (int64_t(h) * p.B + b) * int64_t(p.lq) * p.lk + int64_t(qc) * p.lk;
         const bool with_v = p.O != nullptr;  // uniform: false = probabilities only
         gload(0, with_v);
+        load_mask(0, mraw);
         lstore(0, with_v);
         __syncthreads();
         for (int kt = 0; kt < nt; ++kt) {
             const int buf = kt & 1;
             if (kt + 1 < nt) gload(kt + 1, with_v);
+            load_mask(kt + 1, mnext);
             if (wave_active) {
                 f32x16 s;
                 scores(kt, buf, s);
@@ -217,6 +233,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                 }
                 if (with_v) pv(buf, s, o);
             }
+            rotate_mask();
             if (kt + 1 < nt) lstore(buf ^ 1, with_v);
             __syncthreads();
         }
@@ -228,13 +245,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                 for (int r = 0; r < 16; ++r) o[cb][r] = __builtin_nanf("");
         }
     } else {
-        // ---- single pass, online softmax ----
+        // ---- single pass, online softmax with the lazy rescale described at attn_reg_kernel ----
+        constexpr float RESCALE_THR = 32.0f;
         gload(0, true);
+        load_mask(0, mraw);
         lstore(0, true);
         __syncthreads();
         for (int kt = 0; kt < nt; ++kt) {
             const int buf = kt & 1;
             if (kt + 1 < nt) gload(kt + 1, true);
+            load_mask(kt + 1, mnext);
             if (wave_active) {
                 f32x16 s;
                 scores(kt, buf, s);
@@ -242,24 +262,28 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
                 tmax = fmaxf(tmax, xor32(tmax));
-                const float m_new = fmaxf(m_run, tmax);
-                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
+                if (__any(tmax > m_run + RESCALE_THR)) {
+                    const float m_new = fmaxf(m_run, tmax);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
+                    l_run *= alpha;
+                    m_run = m_new;
+#pragma unroll
+                    for (int cb = 0; cb < DVB; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+                }
+                const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
                 float psum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    s[r] = exp2f(s[r] - m_use);
+                    s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
                     psum += s[r];
                 }
                 psum += xor32(psum);
-                l_run = l_run * alpha + psum;
-                m_run = m_new;
-#pragma unroll
-                for (int cb = 0; cb < DVB; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+                l_run += psum;
                 pv(buf, s, o);
             }
+            rotate_mask();
             if (kt + 1 < nt) lstore(buf ^ 1, true);
             __syncthreads();
         }
@@ -313,6 +337,7 @@ template <int DP, int KSPLIT, bool WRITE_P>
 __global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
     static_assert(!WRITE_P || KSPLIT == 1, "probability write-out uses unsplit keys");
     constexpr int DKC = DP / 8, DVB = DP / 32, QB = 4 / KSPLIT, QS = DP + 4;
+    constexpr int QG = DKC >= 4 ? 4 : DKC;  // Q fragments read ahead per group
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -362,7 +387,8 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
 
     const int nt = (p.lk + 31) / 32;
     float4 kf[DKC];
-    float vf[DVB][16];
+    float vf[16][DVB];   // V[key_r(hi)][DVB*l31 + e]: block e of O^T holds dv columns {DVB*i + e}
+    unsigned mraw[16];   // raw mask bytes / token-is-PAD flags of the tile, loaded one tile ahead
 
     auto load_k = [&](int kt) {
         const unsigned base = unsigned((kt * 32 + l31) * k_r + hi * 4) * 4u;
@@ -371,58 +397,82 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
             kf[c] = bload4(rsK, (c * 8 + hi * 4 < p.dk) ? base + unsigned(c) * 32u : OOB, 0);
     };
     auto load_v = [&](int kt) {
-        const unsigned base = unsigned((kt * 32 + 4 * hi) * v_r + l31) * 4u;
+        const bool col_ok = DVB * l31 < p.dv;  // dv is a multiple of 4: the DVB-wide vector is all-or-nothing
+        const unsigned base = unsigned((kt * 32 + 4 * hi) * v_r + DVB * l31) * 4u;
 #pragma unroll
-        for (int cb = 0; cb < DVB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                vf[cb][r] = bload1(rsV, (cb * 32 + l31 < p.dv)
-                                            ? base + unsigned(((r & 3) + 8 * (r >> 2)) * v_r + cb * 32) * 4u
-                                            : OOB);
+        for (int r = 0; r < 16; ++r) {
+            const unsigned off = col_ok ? base + unsigned(((r & 3) + 8 * (r >> 2)) * v_r) * 4u : OOB;
+            if constexpr (DVB == 4) {
+                const float4 v = bload4(rsV, off, 0);
+                vf[r][0] = v.x; vf[r][1] = v.y; vf[r][2] = v.z; vf[r][3] = v.w;
+            } else if constexpr (DVB == 2) {
+                const f32x2 v = bload2(rsV, off);
+                vf[r][0] = v.x; vf[r][1] = v.y;
+            } else {
+                vf[r][0] = bload1(rsV, off);
+            }
+        }
     };
-    auto scores = [&](int kt, f32x16& s) {
-        unsigned blocked = 0;
+    auto load_mask = [&](int kt) {
         const int kbase = kt * 32 + 4 * hi;
         if (p.mask_kind == LAMP_MASK_U8) {
             const unsigned mo = unsigned(int64_t(qc) * p.m_sq) + unsigned(kbase);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                blocked |= (bload_u8(rsM, mo + (r & 3) + 8 * (r >> 2)) != 0 ? 1u : 0u) << r;
+            for (int r = 0; r < 16; ++r) mraw[r] = bload_u8(rsM, mo + (r & 3) + 8 * (r >> 2));
         } else if (p.mask_kind == LAMP_MASK_KEY_TOKENS_I64) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                blocked |= (bload_u64(rsM, unsigned(kbase + (r & 3) + 8 * (r >> 2)) * 8u) == 0 ? 1u : 0u) << r;
+            for (int r = 0; r < 16; ++r)  // past lk: reads 0 == PAD == blocked (forced to -inf below anyway)
+                mraw[r] = bload_u64(rsM, unsigned(kbase + (r & 3) + 8 * (r >> 2)) * 8u) == 0 ? 1u : 0u;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mraw[r] = 0u;
         }
+    };
+    // S^T = K Q^T for the tile in kf, Q fragments read QG chunks ahead from LDS; then -inf where blocked.
+    auto scores = [&](int kt, f32x16& s) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         const float* qp = Qs + l31 * QS + hi * 4;
+        float4 qa[QG], qn[QG];
 #pragma unroll
-        for (int c = 0; c < DKC; ++c) {
-            const float4 qf = *reinterpret_cast<const float4*>(qp + c * 8);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].x, qf.x, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].y, qf.y, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].z, qf.z, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].w, qf.w, s, 0, 0, 0);
+        for (int j = 0; j < QG; ++j) qa[j] = *reinterpret_cast<const float4*>(qp + j * 8);
+#pragma unroll
+        for (int g = 0; g < DKC / QG; ++g) {
+            if (g + 1 < DKC / QG) {
+#pragma unroll
+                for (int j = 0; j < QG; ++j) qn[j] = *reinterpret_cast<const float4*>(qp + ((g + 1) * QG + j) * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < QG; ++j) {
+                const float4 kk = kf[g * QG + j];
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qa[j].x, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qa[j].y, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qa[j].z, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qa[j].w, s, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < QG; ++j) qa[j] = qn[j];
         }
+        const int kbase = kt * 32 + 4 * hi;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kbase + (r & 3) + 8 * (r >> 2);
-            if (key >= p.lk || ((blocked >> r) & 1u)) s[r] = -INFINITY;
+            if (key >= p.lk || mraw[r] != 0) s[r] = -INFINITY;
         }
     };
     auto pv = [&](const f32x16& pr, f32x16 (&o)[DVB]) {
 #pragma unroll
-        for (int cb = 0; cb < DVB; ++cb)
+        for (int e = 0; e < DVB; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                o[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cb][r], pr[r], o[cb], 0, 0, 0);
+                o[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r][e], pr[r], o[e], 0, 0, 0);
     };
 
     f32x16 o[DVB];
 #pragma unroll
-    for (int cb = 0; cb < DVB; ++cb)
+    for (int e = 0; e < DVB; ++e)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) o[e][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
     if constexpr (WRITE_P) {
@@ -430,6 +480,7 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
             // pass 1: exact row max / row sum
             for (int kt = 0; kt < nt; ++kt) {
                 load_k(kt);
+                load_mask(kt);
                 f32x16 s;
                 scores(kt, s);
                 float tmax = s[0];
@@ -451,6 +502,7 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
             float* Prow = p.P + (int64_t(h) * p.B + b) * int64_t(p.lq) * p.lk + int64_t(qc) * p.lk;
             for (int kt = 0; kt < nt; ++kt) {
                 load_k(kt);
+                load_mask(kt);
                 if (has_v) load_v(kt);
                 f32x16 s;
                 scores(kt, s);
@@ -465,39 +517,50 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
             }
             if (l_run == 0.f) {
 #pragma unroll
-                for (int cb = 0; cb < DVB; ++cb)
+                for (int e = 0; e < DVB; ++e)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[cb][r] = __builtin_nanf("");
+                    for (int r = 0; r < 16; ++r) o[e][r] = __builtin_nanf("");
             }
         }
     } else {
+        // Online softmax with a LAZY rescale: the running max is only advanced (and O^T, l rescaled) when
+        // some row's tile max exceeds it by more than 2^RESCALE_THR; until then probabilities are taken
+        // relative to the stale max (<= 2^32, harmless in fp32 and exactly cancelled by the final 1/l).
+        // This keeps the 64-register accumulator out of the VALU on almost every tile.  The decision is
+        // wave-uniform and depends only on this (sample, head, query block): batch-invariant.
+        constexpr float RESCALE_THR = 32.0f;
         if (wave_active && ks < nt) {
             load_k(ks);
+            load_mask(ks);
             load_v(ks);
             for (int kt = ks; kt < nt; kt += KSPLIT) {
                 f32x16 s;
                 scores(kt, s);
-                load_k(kt + KSPLIT);  // unconditional (past lk: range-checked zeros); flies under softmax + PV
+                load_k(kt + KSPLIT);     // unconditional prefetch (past lk: range-checked zeros),
+                load_mask(kt + KSPLIT);  // flies under softmax + PV
                 float tmax = s[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
                 tmax = fmaxf(tmax, xor32(tmax));
-                const float m_new = fmaxf(m_run, tmax);
-                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                const float alpha = exp2f(m_run - m_use);
+                if (__any(tmax > m_run + RESCALE_THR)) {
+                    const float m_new = fmaxf(m_run, tmax);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
+                    l_run *= alpha;
+                    m_run = m_new;
+#pragma unroll
+                    for (int e = 0; e < DVB; ++e)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[e][r] *= alpha;
+                }
+                const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
                 float psum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    s[r] = exp2f(s[r] - m_use);
+                    s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
                     psum += s[r];
                 }
                 psum += xor32(psum);
-                l_run = l_run * alpha + psum;
-                m_run = m_new;
-#pragma unroll
-                for (int cb = 0; cb < DVB; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+                l_run += psum;
                 pv(s, o);
                 load_v(kt + KSPLIT);  // flies under the next QK^T
             }
@@ -508,10 +571,10 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
             __syncthreads();                   // every wave is done reading Qs: the region is reused
             float* mine = smem + wave * CW;
 #pragma unroll
-            for (int cb = 0; cb < DVB; ++cb)
+            for (int e = 0; e < DVB; ++e)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    mine[(cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = o[cb][r];
+                    mine[(e * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = o[e][r];
             if (hi == 0) {
                 mine[DP * 32 + l31] = m_run;
                 mine[(DP + 1) * 32 + l31] = l_run;
@@ -525,47 +588,46 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
                 const float w0 = exp2f(m_run - m_use);
                 l_run *= w0;
 #pragma unroll
-                for (int cb = 0; cb < DVB; ++cb)
+                for (int e = 0; e < DVB; ++e)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[cb][r] *= w0;
+                    for (int r = 0; r < 16; ++r) o[e][r] *= w0;
 #pragma unroll
                 for (int s2 = 1; s2 < KSPLIT; ++s2) {
                     const float* other = smem + (wave + s2) * CW;
                     const float ws = exp2f(other[DP * 32 + l31] - m_use);
                     l_run += other[(DP + 1) * 32 + l31] * ws;
 #pragma unroll
-                    for (int cb = 0; cb < DVB; ++cb)
+                    for (int e = 0; e < DVB; ++e)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            o[cb][r] += other[(cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] * ws;
+                            o[e][r] += other[(e * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] * ws;
                 }
             }
         }
         const float inv_l = 1.0f / l_run;
 #pragma unroll
-        for (int cb = 0; cb < DVB; ++cb)
+        for (int e = 0; e < DVB; ++e)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[cb][r] *= inv_l;
+            for (int r = 0; r < 16; ++r) o[e][r] *= inv_l;
     }
 
+    // ---- store: lane (query, hi), register r, block e  <->  O[query][DVB*i(r,hi) + e] ----
     if (wave_active && ks == 0 && qi < p.lq && p.O != nullptr) {
         float* Orow = p.O + int64_t(b) * p.lay.o_b + int64_t(h) * p.lay.o_h + int64_t(qi) * p.lay.o_r;
         const bool vec = ((p.lay.o_b | p.lay.o_h | p.lay.o_r) & 3) == 0 &&
                          (reinterpret_cast<uintptr_t>(p.O) & 15u) == 0;
 #pragma unroll
-        for (int cb = 0; cb < DVB; ++cb)
+        for (int r = 0; r < 16; ++r) {
+            const int col = DVB * ((r & 3) + 8 * (r >> 2) + 4 * hi);
+            if (col >= p.dv) continue;
+            if (DVB == 4 && vec) {
+                *reinterpret_cast<float4*>(Orow + col) = make_float4(o[0][r], o[DVB > 1 ? 1 : 0][r],
+                                                                     o[DVB > 2 ? 2 : 0][r], o[DVB > 3 ? 3 : 0][r]);
+            } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = cb * 32 + g * 8 + hi * 4;
-                if (col >= p.dv) continue;
-                if (vec) {
-                    *reinterpret_cast<float4*>(Orow + col) =
-                        make_float4(o[cb][4 * g], o[cb][4 * g + 1], o[cb][4 * g + 2], o[cb][4 * g + 3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Orow[col + e] = o[cb][4 * g + e];
-                }
+                for (int e = 0; e < DVB; ++e) Orow[col + e] = o[e][r];
             }
+        }
     }
 }
 

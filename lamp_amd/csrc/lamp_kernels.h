@@ -78,6 +78,10 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff
     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     return make_float4(v.x, v.y, v.z, v.w);
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 bload2(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+}
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
 }

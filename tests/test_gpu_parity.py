@@ -293,8 +293,8 @@ def test_samples_are_independent_bitwise(dev):
 
 
 def test_two_stream_forward_is_bit_identical(dev):
-    """lamp_set_forward_streams(2): the halves of the batch run concurrently on two HIP streams; the
-    results must not change by a bit, for odd batches, int_preds and micro-batched runs alike."""
+    """lamp_set_forward_streams(2): the K/V projections of decoder layers >= 1 run ahead on a side
+    stream; the results must not change by a bit, for odd batches, int_preds and micro-batched runs."""
     from lamp_amd import _native as N
     cfg = list(CONFIGS['reuters_ragged'])
     cfg[8] = 7
@@ -314,7 +314,7 @@ def test_two_stream_forward_is_bit_identical(dev):
         m.workspace_limit_bytes = 64 << 20
         split, _, _ = m(src, None, None, None)
         assert torch.equal(split, one)
-        # maps: falls back to one stream; the map-writing kernels use an exact two-pass softmax, so
+        # the map-writing kernels use an exact two-pass softmax, so
         # these logits agree with the default path to rounding, not bitwise
         lg, _, _, _ = m(src, None, None, None, return_attns=True)
         assert max_abs_diff(lg, one) < 1e-5
