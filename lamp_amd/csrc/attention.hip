@@ -1,21 +1,34 @@
 // Fused masked attention  O = softmax_k(mask(Q K^T * inv_temperature)) V  in exact fp32 on the
 // CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).  Scores never leave the CU.
 //
-// Work decomposition: grid = (ceil(lq/128), H, B); a 256-thread workgroup owns 128 query rows of
-// one (sample, head); each of its four 64-lane waves owns 32 of them.  Keys/values stream through
-// LDS in tiles of 32 keys, register-staged and double buffered (the next tile's global loads are
-// in flight under the current tile's MFMAs; one barrier per tile).
+// Work decomposition: a 64-lane wave owns 32 query rows of one (sample, head) and streams 32-key tiles;
+// the four waves of a 256-thread workgroup cover QB = 4/KSPLIT query blocks, the KSPLIT waves of one
+// block taking interleaved key tiles (flash-decoding style, merged at the end) -- KSPLIT = 2 when there
+// are at most 128 queries (reuters' 90 labels would otherwise leave most of the chip idle), else 1.
 //
 // Both products are computed TRANSPOSED so that the query index lands on the lane (MFMA C/D
 // column = lane & 31) in both accumulators:
-//     S^T[key][query] = K . Q^T      A = K rows (from LDS), B = Q rows (registers, pre-scaled)
-//     O^T[dv ][query] = V^T . P^T    A = V columns (from LDS), B = P (the S^T accumulator itself)
+//     S^T[key][query] = K . Q^T      A = K rows,    B = Q rows (pre-scaled, from LDS)
+//     O^T[dv ][query] = V^T . P^T    A = V columns, B = P (the S^T accumulator itself)
 // Lane (q = l&31, hi = l>>5) then holds, for ITS query, the 16 keys {(r&3)+8(r>>2)+4hi} of the
 // tile.  Row max / row sum are 15 in-lane ops plus ONE exchange with lane l^32; the online-softmax
 // rescale of O^T is a plain per-lane multiply; and -- because an MFMA may take its k index in any
 // order as long as A and B agree -- accumulator register r of S^T is DIRECTLY the B operand of PV
 // step r (key (r&3)+8(r>>2)+4hi for both operands).  P never moves: no LDS round trip, no
 // permutes, no bf16 repack, exact fp32 throughout.
+//
+// There is NO shared K/V tile and NO barrier in the main loop: every wave pulls its own MFMA
+// fragments straight from global/L2 into registers through range-checked buffer descriptors --
+//   K : lane (key = l&31, hi) reads 16 B at K[key][8c + 4hi], c = 0..DP/8-1
+//   V : lane (i = l&31, hi) reads 16 B at V[key_r(hi)][4i .. 4i+3]: block e of O^T then holds the dv
+//       columns {4i + e}, which turns the epilogue into 16-byte stores as well
+// -- and software-prefetches the next tile's K and mask bytes right after the QK^T MFMAs and the next
+// V right after the PV MFMAs, so the loads fly under ~4096 cycles of matrix work each (fp32 MFMA is
+// slow enough, 64 cycles per 32x32x2, that the L2 traffic of unsynchronised waves is a non-issue; an
+// LDS-tiled variant with a shared K/V tile measured equal or slower on every shape and was removed,
+// profiles/r01_attn_variants.txt).  An earlier version lost half its time because hipcc put the wait
+// for the mask bytes -- and with it for the whole V prefetch -- in front of the QK^T MFMAs; hence the
+// one-tile-ahead mask registers.
 //
 // Masking follows the reference: blocked scores become -inf BEFORE the softmax; a fully blocked
 // row therefore has zero row-sum and comes out NaN (0 * inf), exactly like torch's
@@ -26,315 +39,8 @@ namespace lamp {
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
-template <int DP, bool WRITE_P>
-__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
-    constexpr int DKC = DP / 8;   // 8-wide k-dim chunks of Q.K
-    constexpr int DVB = DP / 32;  // 32-wide column blocks of O
-    constexpr int KS = DP + 4;    // K tile row stride: padded -> conflict-free ds_read_b128
-    constexpr int VS = DP;        // V tile row stride (b32 reads of 32 consecutive columns)
-    constexpr int LD = DP / 32;   // float4 loads per thread per 32xDP tile (256 threads)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                // [2][32][KS]
-    float* Vs = smem + 2 * 32 * KS;  // [2][32][VS]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    const int qi = q0 + l31;
-    const bool wave_active = q0 < p.lq;  // wave-uniform
-    const int qc = qi < p.lq ? qi : p.lq - 1;  // clamped row for mask reads
-
-    // Per-(sample, head) buffer descriptors: keys past lk read as 0 through the hardware range check.
-    const int k_r = int(p.lay.k_r), v_r = int(p.lay.v_r);
-    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K + int64_t(b) * p.lay.k_b + int64_t(h) * p.lay.k_h,
-                                                 (uint64_t(p.lk - 1) * k_r + p.dk) * 4u);
-    const bool has_v = p.V != nullptr;
-    const __amdgpu_buffer_rsrc_t rsV =
-        make_rsrc(has_v ? p.V + int64_t(b) * p.lay.v_b + int64_t(h) * p.lay.v_h : p.K,
-                  has_v ? (uint64_t(p.lk - 1) * v_r + p.dv) * 4u : 0);
-
-    // ---- Q fragments: lane holds Q[qi][8c + 4hi .. +3], pre-multiplied by scale*log2(e) ----
-    float4 qf[DKC];
-    {
-        const int q_r = int(p.lay.q_r);
-        const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q + int64_t(b) * p.lay.q_b + int64_t(h) * p.lay.q_h,
-                                                     (uint64_t(p.lq - 1) * q_r + p.dk) * 4u);
-#pragma unroll
-        for (int c = 0; c < DKC; ++c) {
-            const int kd = c * 8 + hi * 4;
-            const float4 v = bload4(rsQ, (qi < p.lq && kd < p.dk) ? unsigned(qi * q_r + kd) * 4u : OOB, 0);
-            qf[c] = make_float4(v.x * p.scale_log2e, v.y * p.scale_log2e, v.z * p.scale_log2e,
-                                v.w * p.scale_log2e);
-        }
-    }
-
-    const int nt = (p.lk + 31) / 32;
-    float4 rk[LD], rv[LD];
-    constexpr int C4 = DP / 4;
-
-    // This thread's float4s of a 32 x DP tile: row = key within the tile, c = first column.
-    unsigned vok[LD], vov[LD];
-#pragma unroll
-    for (int i = 0; i < LD; ++i) {
-        const int idx = tid + i * 256;
-        const int row = idx / C4, c = (idx - row * C4) * 4;
-        vok[i] = c < p.dk ? unsigned(row * k_r + c) * 4u : OOB;  // padding columns read as 0
-        vov[i] = c < p.dv ? unsigned(row * v_r + c) * 4u : OOB;
-    }
-    auto gload = [&](int kt, bool with_v) {
-        // tile base: key = kt*32 -> byte offset kt*32*stride*4, added on the VGPR side so that keys
-        // past lk fail the range check and come back as 0
-        const unsigned kb = unsigned(kt * 32 * k_r) * 4u, vb = unsigned(kt * 32 * v_r) * 4u;
-#pragma unroll
-        for (int i = 0; i < LD; ++i) {
-            rk[i] = bload4(rsK, vok[i] == OOB ? OOB : vok[i] + kb, 0);
-            if (with_v) rv[i] = bload4(rsV, vov[i] == OOB ? OOB : vov[i] + vb, 0);
-        }
-    };
-    auto lstore = [&](int buf, bool with_v) {
-#pragma unroll
-        for (int i = 0; i < LD; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / C4, c4 = idx - row * C4;
-            *reinterpret_cast<float4*>(Ks + buf * 32 * KS + row * KS + c4 * 4) = rk[i];
-            if (with_v) *reinterpret_cast<float4*>(Vs + buf * 32 * VS + row * VS + c4 * 4) = rv[i];
-        }
-    };
-
-    // Mask descriptor: uint8 rows [qc*m_sq + key] of sample b, or the sample's int64 token row.
-    const __amdgpu_buffer_rsrc_t rsM =
-        p.mask_kind == LAMP_MASK_U8
-            ? make_rsrc(static_cast<const unsigned char*>(p.mask) + int64_t(b) * p.m_sb,
-                        uint64_t(p.lq - 1) * uint64_t(p.m_sq) + p.lk)
-            : make_rsrc(p.mask_kind == LAMP_MASK_KEY_TOKENS_I64
-                            ? static_cast<const void*>(static_cast<const long long*>(p.mask) + int64_t(b) * p.m_sb)
-                            : static_cast<const void*>(p.K),
-                        p.mask_kind == LAMP_MASK_KEY_TOKENS_I64 ? uint64_t(p.lk) * 8u : 0);
-
-    // Mask bytes / token-is-PAD flags are fetched ONE TILE AHEAD (next to the K/V prefetch) so that their
-    // wait never lands in front of the MFMAs -- hipcc places the compare right behind the load.
-    unsigned mraw[16], mnext[16];
-    auto load_mask = [&](int kt, unsigned (&dst)[16]) {
-        const int kb = kt * 32 + 4 * hi;
-        if (p.mask_kind == LAMP_MASK_U8) {
-            const unsigned mo = unsigned(int64_t(qc) * p.m_sq) + unsigned(kb);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dst[r] = bload_u8(rsM, mo + (r & 3) + 8 * (r >> 2));
-        } else if (p.mask_kind == LAMP_MASK_KEY_TOKENS_I64) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dst[r] = bload_u64(rsM, unsigned(kb + (r & 3) + 8 * (r >> 2)) * 8u) == 0 ? 1u : 0u;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dst[r] = 0u;
-        }
-    };
-    auto rotate_mask = [&]() {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mraw[r] = mnext[r];
-    };
-
-    // S^T tile for this wave's 32 queries vs keys [kt*32, kt*32+32), masked, in the log2 domain.
-    auto scores = [&](int kt, int buf, f32x16& s) {
-        const int kbase = kt * 32 + 4 * hi;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        const float* kp = Ks + buf * 32 * KS + l31 * KS + hi * 4;
-#pragma unroll
-        for (int c = 0; c < DKC; ++c) {
-            const float4 kf = *reinterpret_cast<const float4*>(kp + c * 8);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[c].x, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[c].y, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[c].z, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[c].w, s, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kbase + (r & 3) + 8 * (r >> 2);
-            if (key >= p.lk || mraw[r] != 0) s[r] = -INFINITY;
-        }
-    };
-
-    auto pv = [&](int buf, const f32x16& pr, f32x16 (&o)[DVB]) {
-        const float* vp = Vs + buf * 32 * VS + (4 * hi) * VS + l31;
-#pragma unroll
-        for (int cb = 0; cb < DVB; ++cb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float vf = vp[((r & 3) + 8 * (r >> 2)) * VS + cb * 32];
-                o[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, pr[r], o[cb], 0, 0, 0);
-            }
-        }
-    };
-
-    f32x16 o[DVB];
-#pragma unroll
-    for (int cb = 0; cb < DVB; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
-
-    float m_run = -INFINITY, l_run = 0.f;
-
-    if constexpr (WRITE_P) {
-        // ---- pass 1: exact row max and row sum (K only) ----
-        gload(0, false);
-        load_mask(0, mraw);
-        lstore(0, false);
-        __syncthreads();
-        for (int kt = 0; kt < nt; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nt) gload(kt + 1, false);
-            load_mask(kt + 1, mnext);
-            if (wave_active) {
-                f32x16 s;
-                scores(kt, buf, s);
-                float tmax = s[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-                tmax = fmaxf(tmax, xor32(tmax));
-                const float m_new = fmaxf(m_run, tmax);
-                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                float psum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) psum += exp2f(s[r] - m_use);
-                psum += xor32(psum);
-                l_run = l_run * exp2f(m_run - m_use) + psum;
-                m_run = m_new;
-            }
-            rotate_mask();
-            if (kt + 1 < nt) lstore(buf ^ 1, false);
-            __syncthreads();
-        }
-        // ---- pass 2: normalised probabilities out, and O = P V ----
-        const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
-        const float inv_l = 1.0f / l_run;  // l == 0 (fully blocked row) -> inf -> P, O = NaN
-        float* Prow = p.P + (int64_t(h) * p.B + b) * int64_t(p.lq) * p.lk + int64_t(qc) * p.lk;
-        const bool with_v = p.O != nullptr;  // uniform: false = probabilities only
-        gload(0, with_v);
-        load_mask(0, mraw);
-        lstore(0, with_v);
-        __syncthreads();
-        for (int kt = 0; kt < nt; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nt) gload(kt + 1, with_v);
-            load_mask(kt + 1, mnext);
-            if (wave_active) {
-                f32x16 s;
-                scores(kt, buf, s);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[r] = exp2f(s[r] - m_use) * inv_l;
-                    const int key = kt * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
-                    if (qi < p.lq && key < p.lk) Prow[key] = s[r];
-                    // keys beyond lk hold exp2(-inf) * inv_l: 0, or NaN for a dead row -- their V rows are 0
-                    if (key >= p.lk) s[r] = 0.f;
-                }
-                if (with_v) pv(buf, s, o);
-            }
-            rotate_mask();
-            if (kt + 1 < nt) lstore(buf ^ 1, with_v);
-            __syncthreads();
-        }
-        if (l_run == 0.f) {
-            // fully blocked row: the reference gets NaN from softmax; 0-padded keys must not hide it
-#pragma unroll
-            for (int cb = 0; cb < DVB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[cb][r] = __builtin_nanf("");
-        }
-    } else {
-        // ---- single pass, online softmax with the lazy rescale described at attn_reg_kernel ----
-        constexpr float RESCALE_THR = 32.0f;
-        gload(0, true);
-        load_mask(0, mraw);
-        lstore(0, true);
-        __syncthreads();
-        for (int kt = 0; kt < nt; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nt) gload(kt + 1, true);
-            load_mask(kt + 1, mnext);
-            if (wave_active) {
-                f32x16 s;
-                scores(kt, buf, s);
-                float tmax = s[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-                tmax = fmaxf(tmax, xor32(tmax));
-                if (__any(tmax > m_run + RESCALE_THR)) {
-                    const float m_new = fmaxf(m_run, tmax);
-                    const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
-                    l_run *= alpha;
-                    m_run = m_new;
-#pragma unroll
-                    for (int cb = 0; cb < DVB; ++cb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
-                }
-                const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
-                float psum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
-                    psum += s[r];
-                }
-                psum += xor32(psum);
-                l_run += psum;
-                pv(buf, s, o);
-            }
-            rotate_mask();
-            if (kt + 1 < nt) lstore(buf ^ 1, true);
-            __syncthreads();
-        }
-        const float inv_l = 1.0f / l_run;  // 0 -> inf; O is 0 there -> NaN, as the reference
-#pragma unroll
-        for (int cb = 0; cb < DVB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[cb][r] *= inv_l;
-    }
-
-    // ---- store O[b, qi, h, :]: lane owns columns 32cb + 8g + 4hi + {0..3} = registers 4g..4g+3 ----
-    if (wave_active && qi < p.lq && p.O != nullptr) {
-        float* Orow = p.O + int64_t(b) * p.lay.o_b + int64_t(h) * p.lay.o_h + int64_t(qi) * p.lay.o_r;
-        const bool vec = ((p.lay.o_b | p.lay.o_h | p.lay.o_r) & 3) == 0 &&
-                         (reinterpret_cast<uintptr_t>(p.O) & 15u) == 0;
-#pragma unroll
-        for (int cb = 0; cb < DVB; ++cb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = cb * 32 + g * 8 + hi * 4;
-                if (col >= p.dv) continue;  // dv is a multiple of 4
-                if (vec) {
-                    *reinterpret_cast<float4*>(Orow + col) =
-                        make_float4(o[cb][4 * g], o[cb][4 * g + 1], o[cb][4 * g + 2], o[cb][4 * g + 3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Orow[col + e] = o[cb][4 * g + e];
-                }
-            }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Register-streaming variant with key splitting, for problems too small to fill the chip with one
-// workgroup per 128 queries (reuters: 90 labels x 128 (sample, head) pairs).
-//
-// The four waves of a workgroup cover QB = 4/KSPLIT query blocks of 32; the KSPLIT waves of one block
-// take interleaved 32-key tiles (flash-decoding style) and are merged at the end.  There is NO shared
-// K/V tile and NO barrier in the main loop: every wave pulls its own MFMA fragments straight from
-// global/L2 into registers --
-//   K (A operand of S^T = K Q^T): lane (key = l&31, hi) reads 16 B at K[key][8c + 4hi], c = 0..DP/8-1
-//   V (A operand of O^T = V^T P^T): lane (col = l&31, hi) reads V[key_r(hi)][32cb + col]: two fully
-//     coalesced 128-byte rows per instruction
-// -- and software-prefetches the next tile's K right after the QK^T MFMAs and the next V right after
-// the PV MFMAs, so the loads fly under 4096 cycles of matrix work each.  (fp32 MFMA is slow enough,
-// 64 cycles per 32x32x2, that the L2 traffic of four unsynchronised waves is a non-issue.)
-// Q is staged once in LDS, pre-scaled.  The merge is lane-local: all partial (m, l, O^T) of a query
-// sit at the same lane position in every wave.
 template <int DP, int KSPLIT, bool WRITE_P>
-__global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
+__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     static_assert(!WRITE_P || KSPLIT == 1, "probability write-out uses unsplit keys");
     constexpr int DKC = DP / 8, DVB = DP / 32, QB = 4 / KSPLIT, QS = DP + 4;
     constexpr int QG = DKC >= 4 ? 4 : DKC;  // Q fragments read ahead per group
@@ -632,12 +338,12 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(AttnParams p) {
 }
 
 template <int DP, int KSPLIT, bool WRITE_P>
-static int launch_attn_reg(const AttnParams& p, hipStream_t s) {
+static int launch_attn_ks(const AttnParams& p, hipStream_t s) {
     constexpr int QB = 4 / KSPLIT;
     constexpr size_t lds_q = size_t(QB) * 32 * (DP + 4) * sizeof(float);
     constexpr size_t lds_c = KSPLIT > 1 ? size_t(4) * (DP + 2) * 32 * sizeof(float) : 0;
     constexpr size_t lds = lds_q > lds_c ? lds_q : lds_c;
-    auto kern = attn_reg_kernel<DP, KSPLIT, WRITE_P>;
+    auto kern = attn_kernel<DP, KSPLIT, WRITE_P>;
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -653,35 +359,16 @@ static int launch_attn_reg(const AttnParams& p, hipStream_t s) {
 }
 
 template <int DP>
-static int launch_attn_reg_dp(const AttnParams& p, int ksplit, hipStream_t s) {
-    if (p.P) return launch_attn_reg<DP, 1, true>(p, s);
-    if (ksplit >= 4) return launch_attn_reg<DP, 4, false>(p, s);
-    if (ksplit == 2) return launch_attn_reg<DP, 2, false>(p, s);
-    return launch_attn_reg<DP, 1, false>(p, s);
+static int launch_attn_dp(const AttnParams& p, int ksplit, hipStream_t s) {
+    if (p.P) return launch_attn_ks<DP, 1, true>(p, s);
+    if (ksplit >= 4) return launch_attn_ks<DP, 4, false>(p, s);
+    if (ksplit == 2) return launch_attn_ks<DP, 2, false>(p, s);
+    return launch_attn_ks<DP, 1, false>(p, s);
 }
 
-// Debug/tuning hook (not part of the ABI header): 0 = heuristic, 1 = LDS-tiled kernel,
-// 2/3/4 = register-streaming kernel with KSPLIT 1/2/4.
+// Debug/tuning hook (not part of the ABI header): 0 = heuristic, 1/2/4 = force that key split.
 static int g_force_attn = 0;
 extern "C" void lamp_debug_force_attn(int v) { g_force_attn = v; }
-
-template <int DP, bool WRITE_P>
-static int launch_attn_cfg(const AttnParams& p, hipStream_t s) {
-    constexpr size_t lds = size_t(2) * 32 * ((DP + 4) + DP) * sizeof(float);
-    auto kern = attn_kernel<DP, WRITE_P>;
-    static bool attr_done[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (lds > 65536 && dev >= 0 && dev < 64 && !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (e != hipSuccess) return int(e);
-        attr_done[dev] = true;
-    }
-    dim3 grid((p.lq + 127) / 128, p.H, p.B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
-    return int(hipGetLastError());
-}
 
 int launch_attn(const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.H <= 0 || p.lq <= 0 || p.lk <= 0 || p.dk <= 0 || p.dv <= 0) return LAMP_E_DIMS;
@@ -700,32 +387,19 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
                          (p.P ? 4.0 * p.B * p.H * double(p.lq) * p.lk : 0.0);
     ProfScope prof(LAMP_K_ATTN, flops, bytes, s);
     const int dmax = p.dk > p.dv ? p.dk : p.dv;
-    const bool wp = p.P != nullptr;
     if (int64_t(p.lq) * L.q_r * 4 >= 0x7fffffffLL || int64_t(p.lk) * L.k_r * 4 >= 0x7fffffffLL ||
         int64_t(p.lk) * L.v_r * 4 >= 0x7fffffffLL || int64_t(p.lq) * p.m_sq + p.lk >= 0x7fffffffLL)
         return LAMP_E_UNSUPPORTED;  // 32-bit offsets inside one (sample, head) slice
-    // Small grids: split the keys over the four waves of a workgroup until there are ~2 workgroups per CU.
+    // Key split: must NOT depend on the batch size (a split sums in a different order than the
+    // sequential online softmax, and samples must come out bit-identical for every batch / shard), so it
+    // is chosen from the per-sample shape only.  At most 128 queries and >= 4 key tiles -> 2-way split
+    // (36-40 us vs 56-61 us unsplit at reuters batch 32); otherwise none.
     const int nt = (p.lk + 31) / 32;
-    int mode = g_force_attn;
-    if (mode == 0) {
-        // The variant must NOT depend on the batch size (a 2-way key split sums in a different order than
-        // the sequential online softmax, and samples must come out bit-identical for every batch / shard):
-        // choose by the per-sample shape only.  Few queries (<= 128: at most one workgroup per (sample,
-        // head) in the LDS-tiled kernel, e.g. reuters' 90 labels) and >= 4 key tiles -> 2-way key split in
-        // the register-streaming kernel (41-45 us vs 55-67 us at batch 32, profiles/r01_attn_variants.txt);
-        // otherwise the LDS-tiled kernel.
-        mode = (p.lq <= 128 && nt >= 4) ? 3 : 1;
-    }
-    if (mode == 1 && p.O == nullptr) mode = 2;
-    if (mode >= 2) {
-        const int ksplit = wp ? 1 : (mode == 2 ? 1 : mode == 3 ? 2 : 4);
-        if (dmax <= 32) return launch_attn_reg_dp<32>(p, ksplit, s);
-        if (dmax <= 64) return launch_attn_reg_dp<64>(p, ksplit, s);
-        return launch_attn_reg_dp<128>(p, ksplit, s);
-    }
-    if (dmax <= 32) return wp ? launch_attn_cfg<32, true>(p, s) : launch_attn_cfg<32, false>(p, s);
-    if (dmax <= 64) return wp ? launch_attn_cfg<64, true>(p, s) : launch_attn_cfg<64, false>(p, s);
-    return wp ? launch_attn_cfg<128, true>(p, s) : launch_attn_cfg<128, false>(p, s);
+    int ksplit = g_force_attn;
+    if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = (p.lq <= 128 && nt >= 4) ? 2 : 1;
+    if (dmax <= 32) return launch_attn_dp<32>(p, ksplit, s);
+    if (dmax <= 64) return launch_attn_dp<64>(p, ksplit, s);
+    return launch_attn_dp<128>(p, ksplit, s);
 }
 
 }  // namespace lamp

@@ -102,7 +102,7 @@ def attn():
                            lq * H * dk, dk, H * dk)
         force = N.lib().lamp_debug_force_attn
         force.argtypes = [ctypes.c_int]
-        for mode in (0, 1, 2, 3, 4):
+        for mode in (0, 1, 2, 4):  # 0 = heuristic, else forced key split
           for mname, ms in (('none', None), ('shared-u8', N.Mask(N.LAMP_MASK_U8, 0, mask.data_ptr(), 0, lk))):
             force(mode)
 
