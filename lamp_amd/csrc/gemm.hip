@@ -100,7 +100,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
 #pragma unroll
             for (int r = 0; r < NACC; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[T::A_LD], rb[T::B_LD];
+    // Two register sets: tiles kt+1 and kt+2 are in flight while tile kt is multiplied (prefetch distance
+    // of two K steps -- with a single workgroup on a CU, as on the M = B*L decoder shapes, one step of MFMAs
+    // does not cover an L2/MALL round trip).
+    float4 ra0[T::A_LD], rb0[T::B_LD], ra1[T::A_LD], rb1[T::B_LD];
     unsigned voa[T::A_LD], vob[T::B_LD];  // byte offsets of this thread's float4s inside the tile
 #pragma unroll
     for (int i = 0; i < T::A_LD; ++i) {
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         vob[i] = unsigned(row * ldw + c4 * 4) * 4u;
     }
 
-    auto gload = [&](int k0) {
+    auto gload = [&](int k0, float4 (&ra)[T::A_LD], float4 (&rb)[T::B_LD]) {
         if constexpr (KTAIL) {
             // K is not a multiple of BK: columns past K must read as 0 (the row range check cannot see them)
 #pragma unroll
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
             for (int i = 0; i < T::B_LD; ++i) rb[i] = bload4(rsW, vob[i], so);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const float4 (&ra)[T::A_LD], const float4 (&rb)[T::B_LD]) {
         float* a = As + buf * BM * S;
         float* b = Bs + buf * BN * S;
 #pragma unroll
@@ -152,15 +155,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
             *reinterpret_cast<float4*>(b + row * S + c4 * 4) = rb[i];
         }
     };
-
-    const int nk = (p.K + BK - 1) / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+    auto compute = [&](int buf) {
         const float* a = As + buf * BM * S + (wm * T::WTM + l31) * S + hi * 4;
         const float* b = Bs + buf * BN * S + (wn * T::WTN + l31) * S + hi * 4;
 #pragma unroll
@@ -187,7 +182,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
                     }
                 }
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0, ra0, rb0);
+    lstore(0, ra0, rb0);
+    if (nk > 1) gload(BK, ra0, rb0);      // tile 1 -> set 0
+    if (nk > 2) gload(2 * BK, ra1, rb1);  // tile 2 -> set 1
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even step: tile kt in LDS[0]; tile kt+1 in set 0, tile kt+2 in set 1
+        compute(0);
+        if (kt + 1 < nk) lstore(1, ra0, rb0);
+        if (kt + 3 < nk) gload((kt + 3) * BK, ra0, rb0);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd step: tile kt+1 in LDS[1]; tile kt+2 in set 1, tile kt+3 in set 0
+        compute(1);
+        if (kt + 2 < nk) lstore(0, ra1, rb1);
+        if (kt + 4 < nk) gload((kt + 4) * BK, ra1, rb1);
         __syncthreads();
     }
 

@@ -236,6 +236,8 @@ CONFIGS = {
     'bibtex': (1840, 159, 100, 512, 1024, 4, 'prior', False, 4, 0.05, None),
     'delicious': (504, 983, 40, 1024, 2048, 8, 'none', False, 2, 0.0, [40, 17]),
     'inveye_8h': (300, 70, 50, 256, 512, 8, 'inveye', True, 3, 0.0, [50, 1, 23]),
+    # 4096 labels (configs[4]'s label graph: 128 key tiles per label row, sparse prior mask), narrow model
+    'labels4096': (500, 4096, 64, 256, 512, 2, 'prior', True, 2, 0.05, [64, 30]),
 }
 
 
