@@ -117,14 +117,22 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no HIP device is visible (there is no CPU path)')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # > 1 rank per GPU only happens in the 1-GPU smoke test
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     dist = None
+    # "nccl" is RCCL on ROCm.  LAMP_BENCH_BACKEND=gloo lets two ranks share one GPU to smoke-test this path.
+    backend = os.environ.get('LAMP_BENCH_BACKEND', 'nccl')
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world if world > 1 else 1
+    if world > 1 and args.gpus != world and rank == 0:
+        print('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
 
     from lamp_amd import _native as N
     N.lib()
@@ -164,13 +172,32 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
     # sanity: the timed work produced finite logits
     logits = out[0]
     assert torch.isfinite(logits).all(), 'non-finite logits'
+
+    # ---- throughput mode (reported beside `value`, never as `value`): successive batches issued round-robin
+    # on two HIP streams, so that one forward's launch gaps / ramp / tail are filled by the other's kernels ----
+    pipelined = None
+    if not args.graph:
+        streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+        for st in streams:
+            with torch.cuda.stream(st):
+                step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            with torch.cuda.stream(streams[i & 1]):
+                step()
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t1
+        pipelined = {'streams': 2, 'value': args.batch * args.steps / e2, 'unit': 'samples/s per GPU',
+                     'ms_per_step_amortised': e2 / args.steps * 1e3,
+                     'note': 'two independent batches in flight; latency per batch is NOT halved'}
 
     # ---- instrumented replay: per-kernel HIP-event durations on the launch stream ----
     prof_steps = min(args.steps, 20)
@@ -230,6 +257,7 @@ def main():
             'kernel_time_us_per_step': sum(k['us_per_step'] for k in kernels.values()),
         },
         'kernels': kernels,
+        'pipelined_two_batches_in_flight': pipelined,
     }
     if n_gpus == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(w, sd, blocked, seq, pos, args.cpu_budget)

@@ -195,6 +195,14 @@ int lamp_embed_fwd(const int64_t* src_seq, const int64_t* src_pos, int64_t n_tok
 int lamp_diag_logits_fwd(const float* y, const float* w_out, int32_t B, int32_t L, int32_t d_model,
                          float* logits, lamp_stream_t stream);
 
+/* Post-processing of the evaluation loop (test.py:49-51), the step right after the hot path:
+ *   probs[b,i]  = sigmoid(logits[b,i])                                   (probs nullable)
+ *   row_loss[b] = sum_i  max(x,0) - x*z + log1p(exp(-|x|)),  x = logits[b,i], z = targets[b,i]
+ * i.e. F.binary_cross_entropy_with_logits summed per row (row_loss and targets nullable together);
+ * the 'mean' reduction is sum(row_loss) / (n_rows * L). */
+int lamp_sigmoid_bce_fwd(const float* logits, const float* targets, int64_t n_rows, int32_t L,
+                         float* probs, float* row_loss, lamp_stream_t stream);
+
 /* ---- the whole hot path ------------------------------------------------------------------- */
 
 /* Bytes of workspace lamp_forward needs to process `micro_batch` samples of padded length T at a

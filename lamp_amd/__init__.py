@@ -5,6 +5,7 @@ Mirrors the reference package layout (``lamp.Models``, ``lamp.Layers``, ``lamp.S
 """
 from . import Constants, utils, SubLayers, Attention, Layers, Encoders, Decoders, Models, Translator, Beam  # noqa: F401,E501
 from .Models import LAMP  # noqa: F401
+from . import data, evaluate, sharding  # noqa: F401,E402
 
 __all__ = ['Constants', 'utils', 'SubLayers', 'Attention', 'Layers', 'Encoders', 'Decoders', 'Models',
            'Translator', 'Beam', 'LAMP']

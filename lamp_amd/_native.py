@@ -87,6 +87,7 @@ PROTOTYPES = {
     'lamp_ffn_fwd': (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(FfnWeights), _vp, _vp, _sz, _vp]),
     'lamp_embed_fwd': (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     'lamp_diag_logits_fwd': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'lamp_sigmoid_bce_fwd': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     'lamp_forward_workspace_bytes': (_sz, [C.POINTER(Model), _i32, _i32, _i32]),
     'lamp_forward': (C.c_int, [C.POINTER(Model), _vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(Aux), _vp, _sz, _vp]),
     'lamp_set_forward_streams': (C.c_int, [_i32]),
@@ -153,8 +154,9 @@ _ws = {}
 
 
 def workspace(nbytes, device):
-    """Grow-only per-device scratch buffer (the library itself never allocates)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only scratch buffer per (device, HIP stream): forwards issued on different streams may be in
+    flight at the same time and must not share scratch (the library itself never allocates)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), stream())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
@@ -296,6 +298,19 @@ def diag_logits(y, w_out):
     check(lib().lamp_diag_logits_fwd(ptr(y), ptr(f32c(w_out)), B, L, d, ptr(out), stream()),
           'lamp_diag_logits_fwd')
     return out
+
+
+def sigmoid_bce(logits, targets=None):
+    """-> (sigmoid(logits), per-row summed BCE-with-logits or None)   (test.py:49-51)."""
+    require_device(logits, targets)
+    x = f32c(logits)
+    B, L = x.shape
+    probs = torch.empty_like(x)
+    z = f32c(targets) if targets is not None else None
+    row_loss = torch.empty((B,), dtype=torch.float32, device=x.device) if z is not None else None
+    check(lib().lamp_sigmoid_bce_fwd(ptr(x), ptr(z), B, L, ptr(probs), ptr(row_loss), stream()),
+          'lamp_sigmoid_bce_fwd')
+    return probs, row_loss
 
 
 def set_forward_streams(n):

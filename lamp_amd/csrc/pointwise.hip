@@ -106,6 +106,29 @@ __global__ __launch_bounds__(256) void diag_kernel(const float* __restrict__ y, 
     if (lane == 0) logits[row] = s;
 }
 
+// test_epoch post-processing (test.py:49-51): probs = sigmoid(logits) and, per row, the summed
+// binary-cross-entropy-with-logits  max(x,0) - x*z + log1p(exp(-|x|))  against the gold 0/1 targets.
+__global__ __launch_bounds__(256) void sigmoid_bce_kernel(const float* __restrict__ logits,
+                                                          const float* __restrict__ targets, int64_t n_rows, int L,
+                                                          float* __restrict__ probs, float* __restrict__ row_loss) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    float loss = 0.f;
+    for (int i = lane; i < L; i += 64) {
+        const float x = logits[row * L + i];
+        if (probs) probs[row * L + i] = 1.0f / (1.0f + expf(-x));
+        if (targets) {
+            const float z = targets[row * L + i];
+            loss += fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+        }
+    }
+    if (row_loss) {
+        loss = wave_sum(loss);
+        if (lane == 0) row_loss[row] = loss;
+    }
+}
+
 static inline int grid4(int64_t rows, unsigned* g) {
     const int64_t n = (rows + 3) / 4;
     if (n > 0x7fffffffLL) return LAMP_E_DIMS;
@@ -148,6 +171,16 @@ int launch_layernorm(const float* x, int64_t M, int d, const float* g, const flo
         hipLaunchKernelGGL(layernorm_kernel<8>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y);
     else
         hipLaunchKernelGGL(layernorm_kernel<16>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y);
+    return int(hipGetLastError());
+}
+
+int launch_sigmoid_bce(const float* logits, const float* targets, int64_t n_rows, int L, float* probs,
+                       float* row_loss, hipStream_t s) {
+    if (n_rows <= 0 || L <= 0) return LAMP_E_DIMS;
+    if (!logits || (!probs && !row_loss) || (row_loss && !targets)) return LAMP_E_NULL;
+    unsigned g;
+    if (int e = grid4(n_rows, &g)) return e;
+    hipLaunchKernelGGL(sigmoid_bce_kernel, dim3(g), dim3(256), 0, s, logits, targets, n_rows, L, probs, row_loss);
     return int(hipGetLastError());
 }
 

@@ -1,0 +1,96 @@
+"""Data side of the evaluation harness: what reaches the hot path and in which shape
+(reference: utils/data_loader.py; on-disk format: utils/preprocess.py:218-232).
+
+Host-side Python on purpose: this is index bookkeeping done once per dataset / per batch on the CPU in
+the reference too.  The tensors it emits are exactly the ones ``LAMP.forward`` receives.
+"""
+import numpy as np
+import torch
+
+from . import Constants
+
+
+def load_dataset(path):
+    """The ``train_valid_test.pt`` dict: settings / dict{src,tgt} / train,valid,test{src,tgt} (main.py:23).
+    It pickles an argparse.Namespace, hence weights_only=False."""
+    return torch.load(path, weights_only=False)
+
+
+def vocabulary_sizes(data, binary_relevance=True):
+    """(src_vocab_size, tgt_vocab_size) as process_data derives them: the label count excludes the four
+    special tokens for the graph decoder (utils/data_loader.py:119-124)."""
+    n_src = len(data['dict']['src'])
+    n_tgt = len(data['dict']['tgt'])
+    return n_src, (n_tgt - 4 if binary_relevance else n_tgt)
+
+
+def prior_adjacency(train_tgt, n_tgt_dict):
+    """Label co-occurrence graph of the train split (utils/data_loader.py:37-44): identity, plus an edge
+    between every two distinct labels that share a sample.  Targets are [BOS, label ids..., EOS] with ids
+    offset by the four special tokens."""
+    L = n_tgt_dict - 4
+    adj = torch.eye(L)
+    for sample in train_tgt:
+        labels = [int(v) - 4 for v in sample[1:-1]]
+        for i, a in enumerate(labels):
+            for b in labels[i + 1:]:
+                if a != b:
+                    adj[a, b] = 1
+                    adj[b, a] = 1
+    return adj
+
+
+def pad_to_longest(insts):
+    """-> (ids int64 (B, T), positions int64 (B, T)); T = longest instance of the batch, PAD = 0, position
+    = 1-based index on non-PAD tokens and 0 on PAD (utils/data_loader.py:261-279)."""
+    T = max(len(x) for x in insts)
+    ids = np.full((len(insts), T), Constants.PAD, dtype=np.int64)
+    for i, x in enumerate(insts):
+        ids[i, :len(x)] = x
+    pos = np.where(ids != Constants.PAD, np.arange(1, T + 1, dtype=np.int64)[None, :], 0)
+    return torch.from_numpy(ids), torch.from_numpy(pos)
+
+
+class EvalBatcher(object):
+    """Sequential (unshuffled) batches in the reference DataLoader's format
+    ``((src_seq, src_pos), None, tgt)`` -- utils/data_loader.py:129-312 with shuffle=False, drop_last=False,
+    as process_data builds the valid/test loaders.  Tensors are moved to `device` if given."""
+
+    def __init__(self, src_insts, tgt_insts, batch_size, device=None):
+        if not src_insts or len(src_insts) < batch_size:
+            raise ValueError('need at least batch_size instances (reference: data_loader.py:139)')
+        if tgt_insts is not None and len(tgt_insts) != len(src_insts):
+            raise ValueError('src / tgt instance counts differ')
+        self._src_insts, self._tgt_insts = src_insts, tgt_insts
+        self._batch_size = batch_size
+        self._n_batch = (len(src_insts) + batch_size - 1) // batch_size
+        self.device = device
+
+    def __len__(self):
+        return self._n_batch
+
+    @property
+    def n_insts(self):
+        return len(self._src_insts)
+
+    def __iter__(self):
+        for b in range(self._n_batch):
+            lo, hi = b * self._batch_size, (b + 1) * self._batch_size
+            src_seq, src_pos = pad_to_longest(self._src_insts[lo:hi])
+            tgt = None
+            if self._tgt_insts is not None:
+                tgt, _ = pad_to_longest(self._tgt_insts[lo:hi])
+            if self.device is not None:
+                src_seq, src_pos = src_seq.to(self.device), src_pos.to(self.device)
+            yield (src_seq, src_pos), None, tgt
+
+
+def get_gold_binary(gold, n_labels):
+    """(B, n_labels) float 0/1 matrix from padded target rows WITHOUT their leading BOS: drop PADs, drop the
+    trailing EOS, shift ids by the four specials (utils/utils.py:205-216)."""
+    out = torch.zeros((gold.size(0), n_labels + 4))
+    for i in range(gold.size(0)):
+        ids = gold[i][gold[i] > 0][:-1]
+        if len(ids) > 0:
+            out[i].index_fill_(0, ids, 1)
+    return out[:, 4:]

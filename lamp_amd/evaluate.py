@@ -1,0 +1,37 @@
+"""The evaluation epoch around the hot path (reference: test.py:16-58, binary-relevance branch).
+
+Per batch: zero-pad the last batch up to `batch_size` (the reference does so because it forces
+multi_gpu, test.py:35-39; the all-PAD rows come out NaN and are sliced off again),
+run ``model(src, adj, None, None)`` on the MI355X, sigmoid + BCE-with-logits on the device
+(lamp_sigmoid_bce_fwd), gold-binary targets on the host.
+"""
+import torch
+
+from . import _native as N
+from .data import get_gold_binary
+
+
+def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True, int_preds=False):
+    """-> (all_predictions (n, L) cpu, all_targets (n, L) cpu, bce_total float), as test.py:16-78 returns
+    them.  `batches` yields ((src_seq, src_pos), adj, tgt) like lamp_amd.data.EvalBatcher."""
+    model.eval()
+    n = batches.n_insts
+    all_predictions = torch.zeros(n, n_labels)
+    all_targets = torch.zeros(n, n_labels)
+    bce_total = 0.0
+    for bi, ((src_seq, src_pos), adj, tgt) in enumerate(batches):
+        real = src_seq.size(0)
+        src_seq, src_pos = src_seq.to(device), src_pos.to(device)
+        if pad_last_batch and real < batch_size:
+            pad = torch.zeros((batch_size - real, src_seq.size(1)), dtype=src_seq.dtype, device=device)
+            src_seq = torch.cat((src_seq, pad), 0)
+            src_pos = torch.cat((src_pos, pad), 0)
+        pred = model((src_seq, src_pos), adj, None, None, int_preds=int_preds)[0]
+        pred = pred[:real]
+        gold_binary = get_gold_binary(tgt[:, 1:], n_labels)
+        probs, row_loss = N.sigmoid_bce(pred, gold_binary.to(device))
+        bce_total += float(row_loss.cpu().double().sum()) / (real * n_labels)  # reduction='mean'
+        lo = bi * batch_size
+        all_predictions[lo:lo + real] = probs.cpu()
+        all_targets[lo:lo + real] = gold_binary
+    return all_predictions, all_targets, bce_total

@@ -1,0 +1,97 @@
+"""Eval harness either side of the hot path against golden/harness.npz, which holds what
+the reference's process_data / DataLoader / test_epoch produced on a synthetic dataset."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, max_abs_diff
+from lamp_amd import data as D
+
+
+def unflatten(flat, off):
+    return [flat[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+
+
+@pytest.fixture(scope='module')
+def fx():
+    d, sd = load_golden('harness')
+    splits = {}
+    for name in ('train', 'valid', 'test'):
+        splits[name] = {part: unflatten(d['%s_%s_flat' % (name, part)], d['%s_%s_off' % (name, part)])
+                        for part in ('src', 'tgt')}
+    return d, sd, splits
+
+
+def test_prior_adjacency_and_vocab_sizes(fx):
+    d, sd, splits = fx
+    adj = D.prior_adjacency(splits['train']['tgt'], d['n_tgt_dict'])
+    assert torch.equal(adj, d['label_adj_matrix'])
+    data = {'dict': {'src': range(d['n_src_dict']), 'tgt': range(d['n_tgt_dict'])}}
+    assert D.vocabulary_sizes(data) == (d['src_vocab_size'], d['tgt_vocab_size'])
+
+
+def test_batcher_emits_the_reference_batches_bitwise(fx):
+    d, sd, splits = fx
+    b = D.EvalBatcher(splits['test']['src'], splits['test']['tgt'], d['batch_size'])
+    assert len(b) == d['n_batches'] and b.n_insts == len(splits['test']['src'])
+    for i, ((src_seq, src_pos), adj, tgt) in enumerate(b):
+        assert adj is None
+        for got, key in ((src_seq, 'src_seq'), (src_pos, 'src_pos'), (tgt, 'tgt')):
+            ref = d['batch%d_%s' % (i, key)]
+            assert got.dtype == torch.int64 and torch.equal(got, ref), (i, key)
+    with pytest.raises(ValueError):
+        D.EvalBatcher(splits['test']['src'][:3], None, 8)
+
+
+def test_gold_binary_matches_reference_targets(fx):
+    d, sd, splits = fx
+    L = d['tgt_vocab_size']
+    rows = []
+    for (_, _, tgt) in D.EvalBatcher(splits['test']['src'], splits['test']['tgt'], d['batch_size']):
+        rows.append(D.get_gold_binary(tgt[:, 1:], L))
+    assert torch.equal(torch.cat(rows), d['targets'])
+
+
+def test_pad_to_longest_edge_cases():
+    ids, pos = D.pad_to_longest([[2, 7, 3], [2, 3], [2, 9, 9, 9, 3]])
+    assert ids.tolist() == [[2, 7, 3, 0, 0], [2, 3, 0, 0, 0], [2, 9, 9, 9, 3]]
+    assert pos.tolist() == [[1, 2, 3, 0, 0], [1, 2, 0, 0, 0], [1, 2, 3, 4, 5]]
+
+
+@pytest.mark.gpu
+def test_test_epoch_matches_reference(fx):
+    d, sd, splits = fx
+    from lamp_amd.Models import LAMP
+    from lamp_amd.evaluate import test_epoch
+    dev = torch.device('cuda:0')
+    L, dm = sd['decoder.tgt_word_emb.weight'].shape
+    h = d['n_head']
+    m = LAMP(d['src_vocab_size'], L, d['max_token_seq_len_e'], L, n_layers_enc=2, n_layers_dec=2, n_head=h,
+             n_head2=h, d_word_vec=dm, d_model=dm, d_inner_hid=2 * dm, d_k=dm // h, d_v=dm // h, encoder='graph',
+             decoder='graph', label_adj_matrix=d['label_adj_matrix'].clone(), label_mask='prior',
+             dec_dropout2=False)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    batches = D.EvalBatcher(splits['test']['src'], splits['test']['tgt'], d['batch_size'])
+    preds, targets, bce = test_epoch(m, batches, L, d['batch_size'], dev)
+    assert torch.equal(targets, d['targets'])
+    assert not torch.isnan(preds).any()          # the zero-padded rows of the last batch were sliced off
+    assert max_abs_diff(preds, d['predictions']) < 2e-5
+    assert abs(bce - d['bce_total']) < 2e-5 * d['n_batches']
+    # without the reference's last-batch padding the kept rows are bit-identical (samples are independent)
+    preds2, _, bce2 = test_epoch(m, batches, L, d['batch_size'], dev, pad_last_batch=False)
+    assert torch.equal(preds2, preds) and abs(bce2 - bce) < 1e-7
+
+
+@pytest.mark.gpu
+def test_sigmoid_bce_kernel_vs_torch():
+    from lamp_amd import _native as N
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(37, 90, generator=g) * 6
+    x[0, 0], x[0, 1] = 80.0, -80.0
+    z = (torch.rand(37, 90, generator=g) < 0.2).float()
+    probs, row_loss = N.sigmoid_bce(x.to(dev), z.to(dev))
+    ref_loss = torch.nn.functional.binary_cross_entropy_with_logits(x.double(), z.double(), reduction='none').sum(1)
+    assert max_abs_diff(probs, torch.sigmoid(x.double())) < 1e-6
+    assert max_abs_diff(row_loss, ref_loss) < 1e-3 * 1e-1
