@@ -50,7 +50,7 @@ def f_live(w, n_enc=2, n_dec=2):
 
 
 def build(w, batch, device, seed=0):
-    from oracle import lamp_ref as R  # synthetic weights / inputs only (shared with the tests)
+    from lamp_amd import synthetic as R
     from lamp_amd.Models import LAMP
     sd = R.make_state_dict(w['V'], w['L'], w['T'], w['d'], w['dff'], w['h'], 2, 2, pos_emb=w['pos'], seed=seed)
     adj = R.make_adjacency(w['L'], w['p'], seed) if w['mask'] == 'prior' else None
@@ -63,14 +63,15 @@ def build(w, batch, device, seed=0):
                  dec_dropout2=False)
     model.load_state_dict(sd)
     model = model.to(device).eval()
-    blocked = R.label_block_mask(adj, w['mask'], w['L'])
-    return model, sd, blocked, seq, pos
+    return model, sd, adj, seq, pos
 
 
-def cpu_baseline(w, sd, blocked, seq, pos, budget_s=20.0):
-    """Reference-as-written op sequence on the host CPU (oracle port), bounded sample."""
+def cpu_baseline(w, sd, adj, seq, pos, budget_s=20.0):
+    """Reference-as-written op sequence on the host CPU (oracle port), bounded sample.  The ONLY place
+    bench.py touches oracle/."""
     from oracle import lamp_ref as R
     h = w['h']
+    blocked = R.label_block_mask(adj, w['mask'], w['L'])
     sd_g = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
 
     def timed(fn, max_iters, budget):
@@ -138,7 +139,7 @@ def main():
     N.lib()
     N.set_forward_streams(args.streams)
     w = WORKLOADS[args.workload]
-    model, sd, blocked, seq, pos = build(w, args.batch, device, seed=rank)
+    model, sd, adj, seq, pos = build(w, args.batch, device, seed=rank)
     src = (seq.to(device), pos.to(device))
 
     def step():
@@ -260,7 +261,7 @@ def main():
         'pipelined_two_batches_in_flight': pipelined,
     }
     if n_gpus == 1 and not args.no_cpu_baseline:
-        cb = cpu_baseline(w, sd, blocked, seq, pos, args.cpu_budget)
+        cb = cpu_baseline(w, sd, adj, seq, pos, args.cpu_budget)
         result['cpu_baseline'] = cb
         result['speedup_vs_cpu_as_written'] = value / cb['value']
     print(json.dumps(result))
