@@ -123,6 +123,11 @@ typedef struct lamp_model {
     const uint8_t* label_mask;  /* [n_labels, n_labels] nonzero = blocked, or NULL ('none') */
     const lamp_enc_layer* enc_layers;
     const lamp_dec_layer* dec_layers;
+    /* Optional: decoder layer 0's enc-attention query, tgt_word_emb . w_qs^T  [n_labels, n_head*d_k].  It
+     * depends on weights only (the decoder input is the label table for every sample, lamp/Decoders.py:
+     * 132-134), so a caller may compute it once per weight version (lamp_linear_fwd) and
+     * pass it here; NULL = lamp_forward projects it on every call. */
+    const float* dec0_query;
 } lamp_model;
 
 /* Optional extra outputs of lamp_forward (return_attns / int_preds, lamp/Models.py:127-135).

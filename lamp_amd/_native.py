@@ -62,7 +62,8 @@ class Model(C.Structure):
                 ('d_model', C.c_int32), ('d_inner', C.c_int32), ('d_k', C.c_int32), ('d_v', C.c_int32),
                 ('n_layers_enc', C.c_int32), ('n_layers_dec', C.c_int32), ('reserved', C.c_int32),
                 ('src_word_emb', _vp), ('position_enc', _vp), ('tgt_word_emb', _vp), ('w_out', _vp),
-                ('label_mask', _vp), ('enc_layers', C.POINTER(EncLayer)), ('dec_layers', C.POINTER(DecLayer))]
+                ('label_mask', _vp), ('enc_layers', C.POINTER(EncLayer)), ('dec_layers', C.POINTER(DecLayer)),
+                ('dec0_query', _vp)]
 
 
 class Aux(C.Structure):

@@ -110,7 +110,8 @@ struct MhaScratch {
 // `out == nullptr` computes the attention map only (the reference's dead encoder self-attention).
 static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, int lq, int lk, int d, int dk,
                     int dv, const lamp_mha_weights& w, const lamp_mask* mask, float* out, float* attn,
-                    const MhaScratch& sc, hipStream_t s, bool kv_ready = false) {
+                    const MhaScratch& sc, hipStream_t s, bool kv_ready = false,
+                    const float* q_ready = nullptr) {
     const int h = w.n_head;
     if (h < 1 || dk < 1 || dv < 1) return LAMP_E_DIMS;
     if (!w.w_qs || !w.w_ks || !w.w_vs || (out && (!w.ln_g || !w.ln_b))) return LAMP_E_NULL;
@@ -127,7 +128,7 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
         float* C[3] = {sc.Q, sc.K, sc.V};
         LAMP_CK(linear(xq, Mq, d, d, W, 3, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
     } else {
-        {
+        if (!q_ready) {
             const float* W[1] = {w.w_qs};
             float* C[1] = {sc.Q};
             LAMP_CK(linear(xq, Mq, d, d, W, 1, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
@@ -151,7 +152,7 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     }
 
     AttnParams a{};
-    a.Q = sc.Q; a.K = sc.K; a.V = need_v ? sc.V : nullptr; a.O = need_v ? sc.A : nullptr; a.P = attn;
+    a.Q = q_ready ? q_ready : sc.Q; a.K = sc.K; a.V = need_v ? sc.V : nullptr; a.O = need_v ? sc.A : nullptr; a.P = attn;
     a.B = B; a.H = h; a.lq = lq; a.lk = lk; a.dk = dk; a.dv = dv;
     a.lay.q_b = xq_shared ? 0 : int64_t(lq) * hdk; a.lay.q_h = dk; a.lay.q_r = hdk;
     a.lay.k_b = int64_t(lk) * hdk; a.lay.k_h = dk; a.lay.k_r = hdk;
@@ -477,8 +478,11 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s));  // lamp/Layers.py:18
         }
 
-        // ---- fork: K/V of decoder layers >= 1 on the side stream ----
+        // ---- two-stream mode: layer 0's K/V on the caller's stream, THEN fork the K/V of layers >= 1 onto the
+        // side stream, so that they run underneath layer 0's small (M = B*L rows) kernels rather than next to
+        // its own full-chip K/V projection ----
         if (n_ahead > 0) {
+            LAMP_CK(project_kv(x, Me, d, dk, dv, m->dec_layers[0].enc_attn, sc.K, sc.V, s));
             hipError_t e;
             if ((e = hipEventRecord(side->fork, s)) != hipSuccess) return int(e);
             if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return int(e);
@@ -512,8 +516,8 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             float* Pslf = (aux && aux->dec_self_attn) ? aux->dec_self_attn[i] : nullptr;
             if ((Penc || Pslf) && nb != B) { rc = LAMP_E_UNSUPPORTED; break; }
             MhaScratch sci = sc;
-            const bool ahead = n_ahead > 0 && i >= 1;
-            if (ahead) {  // join: this layer's K/V come from the side stream
+            const bool ahead = n_ahead > 0;  // K/V already projected (layer 0: above; others: side stream)
+            if (ahead && i >= 1) {  // join: this layer's K/V come from the side stream
                 hipError_t e = hipStreamWaitEvent(s, side->ready[i - 1], 0);
                 if (e != hipSuccess) { rc = int(e); break; }
                 sci.K = Kahead[i - 1];
@@ -521,7 +525,8 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             }
             // input->label messages (lamp/Layers.py:35); layer 0's query is the label table itself
             if (i == 0)
-                rc = mha_core(m->tgt_word_emb, true, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s, ahead);
+                rc = mha_core(m->tgt_word_emb, true, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s, ahead,
+                              m->dec0_query);
             else
                 rc = mha_core(Y, false, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s, ahead);
             if (rc) break;

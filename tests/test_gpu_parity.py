@@ -324,6 +324,28 @@ def test_two_stream_forward_is_bit_identical(dev):
         N.set_forward_streams(1)
 
 
+def test_layer0_query_cache_tracks_weight_updates(dev):
+    """The hoisted label-table x W_q projection is bit-identical to projecting per call, and is refreshed
+    when either operand is modified in place (load_state_dict / optimiser step keep data_ptr)."""
+    m, sd, blocked, seq, spos, h = make_case(CONFIGS['bibtex'], dev)
+    src = (seq.to(dev), spos.to(dev))
+    cached, _, _ = m(src, None, None, None)
+    m.cache_layer0_query = False
+    m._native_cache = None
+    plain, _, _ = m(src, None, None, None)
+    assert torch.equal(cached, plain)
+    m.cache_layer0_query = True
+    m._native_cache = None
+    m(src, None, None, None)
+    with torch.no_grad():
+        m.decoder.layer_stack[0].enc_attn.w_qs.weight.mul_(1.5)   # in place: same data_ptr, new _version
+    after, _, _ = m(src, None, None, None)
+    m.cache_layer0_query = False
+    m._native_cache = None
+    ref, _, _ = m(src, None, None, None)
+    assert torch.equal(after, ref) and not torch.equal(after, cached)
+
+
 def test_trailing_padding_does_not_change_results(dev):
     """Extra PAD columns are blocked keys and PAD rows of the encoder: logits must not move beyond
     rounding noise (tile boundaries shift, so not bitwise)."""

@@ -41,7 +41,7 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(N.FfnWeights) == 48
     assert ctypes.sizeof(N.EncLayer) == 104
     assert ctypes.sizeof(N.DecLayer) == 208
-    assert ctypes.sizeof(N.Model) == 96
+    assert ctypes.sizeof(N.Model) == 104
     assert ctypes.sizeof(N.Aux) == 40
 
 
