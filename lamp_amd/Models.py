@@ -119,6 +119,9 @@ class LAMP(nn.Module):
             # weight version (lamp_linear_fwd) instead of on every forward
             q0 = N.linear(dec.tgt_word_emb.weight.detach(), dec.layer_stack[0].enc_attn.w_qs.weight.detach())
             m.dec0_query = q0.data_ptr()
+            # forwards may be issued from several streams (evaluate.test_epoch(streams=2)); the cached
+            # projection must be complete before any of them reads it -- a one-off sync per weight version
+            torch.cuda.current_stream().synchronize()
         self._native_cache = (key, (m, enc_arr, dec_arr, q0))
         return self._native_cache[1]
 

@@ -81,6 +81,9 @@ def test_test_epoch_matches_reference(fx):
     # without the reference's last-batch padding the kept rows are bit-identical (samples are independent)
     preds2, _, bce2 = test_epoch(m, batches, L, d['batch_size'], dev, pad_last_batch=False)
     assert torch.equal(preds2, preds) and abs(bce2 - bce) < 1e-7
+    # two batches in flight on two HIP streams: same numbers
+    preds3, targets3, bce3 = test_epoch(m, batches, L, d['batch_size'], dev, streams=2)
+    assert torch.equal(preds3, preds) and torch.equal(targets3, targets) and abs(bce3 - bce) < 1e-7
 
 
 @pytest.mark.gpu
