@@ -432,7 +432,6 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
     if (ws_floats < pl.fixed_floats + per_sample) return LAMP_E_WORKSPACE;
     int64_t mb = int64_t((ws_floats - pl.fixed_floats) / per_sample);
     if (mb > B) mb = B;
-    if (mb > 65535) mb = 65535;  // grid.z of the attention launch
 
     const int Rq = want_enc_attn ? pl.R : L;
     float *H = nullptr, *Y = nullptr;

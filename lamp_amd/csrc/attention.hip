@@ -50,8 +50,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int qb = wave / KSPLIT, ks = wave % KSPLIT;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = (blockIdx.x * QB + qb) * 32;
+    // 1-D grid, XCD-aware: consecutive work items = the query blocks of one (sample, head), kept on one XCD
+    const int nqb = (p.lq + 32 * QB - 1) / (32 * QB);
+    const int item = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = item % nqb;
+    const int bh = item / nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    const int q0 = (qblk * QB + qb) * 32;
     const int qi = q0 + l31;
     const bool wave_active = q0 < p.lq;
     const int qc = qi < p.lq ? qi : p.lq - 1;
@@ -353,8 +358,9 @@ static int launch_attn_ks(const AttnParams& p, hipStream_t s) {
         if (e != hipSuccess) return int(e);
         attr_done[dev] = true;
     }
-    dim3 grid((p.lq + 32 * QB - 1) / (32 * QB), p.H, p.B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    const int64_t nwg = int64_t((p.lq + 32 * QB - 1) / (32 * QB)) * p.H * p.B;
+    if (nwg > 0x7fffffffLL) return LAMP_E_DIMS;
+    hipLaunchKernelGGL(kern, dim3(unsigned(nwg)), dim3(256), lds, s, p);
     return int(hipGetLastError());
 }
 
@@ -372,7 +378,6 @@ extern "C" void lamp_debug_force_attn(int v) { g_force_attn = v; }
 
 int launch_attn(const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.H <= 0 || p.lq <= 0 || p.lk <= 0 || p.dk <= 0 || p.dv <= 0) return LAMP_E_DIMS;
-    if (p.B > 65535 || p.H > 65535) return LAMP_E_UNSUPPORTED;
     if (p.dk > 128 || p.dv > 128) return LAMP_E_UNSUPPORTED;
     if ((p.dk & 3) || (p.dv & 3)) return LAMP_E_UNSUPPORTED;
     if (!p.Q || !p.K) return LAMP_E_NULL;

@@ -47,14 +47,6 @@ struct GemmTile {
     static_assert(BK % 8 == 0, "BK must be a multiple of 8");
 };
 
-// Workgroup id -> tile id such that each XCD (block b runs on XCD b % 8) works on a contiguous
-// range of tiles: tiles that share an A row-panel hit the same 4 MiB L2.  Bijective for any count.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
                                                                           int tiles_n) {

@@ -98,6 +98,15 @@ __device__ __forceinline__ unsigned long long bload_u64(__amdgpu_buffer_rsrc_t r
     return __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
 }
 
+// Workgroup id -> work-item id such that each XCD (workgroup b runs on XCD b % 8) gets a CONTIGUOUS range
+// of work items: GEMM tiles sharing an A row-panel, or attention query blocks sharing one (sample, head)'s
+// K/V, then hit the same 4 MiB L2.  Bijective for any count; placement affects speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace lamp
