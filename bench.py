@@ -124,6 +124,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     ap.add_argument('--graph', action='store_true', help='replay the step from a captured HIP graph')
+    ap.add_argument('--no-pipelined', action='store_true',
+                    help='skip the extra two-batches-in-flight measurement (use under rocprofv3: overlapping '
+                         'kernels inflate per-kernel durations)')
     ap.add_argument('--streams', type=int, default=1, choices=[1, 2],
                     help='HIP streams one forward spreads its batch over (lamp_set_forward_streams)')
     args = ap.parse_args()
@@ -199,7 +202,7 @@ def main():
     # ---- throughput mode (reported beside `value`, never as `value`): successive batches issued round-robin
     # on two HIP streams, so that one forward's launch gaps / ramp / tail are filled by the other's kernels ----
     pipelined = None
-    if not args.graph:
+    if not args.graph and not args.no_pipelined:
         streams = [torch.cuda.Stream(device=device) for _ in range(2)]
         for st in streams:
             with torch.cuda.stream(st):
