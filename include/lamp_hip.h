@@ -223,10 +223,10 @@ int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src
                  int32_t B, int32_t T, float* logits, float* enc_output, const lamp_aux* aux,
                  void* workspace, size_t workspace_bytes, lamp_stream_t stream);
 
-/* Number of HIP streams one lamp_forward call uses: 1 (default) or 2.  With 2, the K/V projections of
- * decoder layers >= 1 (they depend only on the encoder output) are issued on a library-owned side stream,
- * forked from and joined to `stream` with events, and run underneath decoder layer 0.  Same kernels on
- * the same data: results are bit-identical either way.  Process-wide setting. */
+/* Number of HIP streams one lamp_forward call uses: 1 (default) or 2.  With 2, the encoder and the K/V
+ * projections of every decoder layer run on `stream`; then the two halves of the batch go through the decoder
+ * stack concurrently, one on `stream`, one on a library-owned side stream (forked from and joined to `stream`
+ * with events).  Samples are independent: results are bit-identical either way.  Process-wide setting. */
 int lamp_set_forward_streams(int32_t n);
 
 /* ---- per-kernel timing (HIP events on the launch stream; used by bench.py's roofline) ------ */

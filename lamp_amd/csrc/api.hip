@@ -376,7 +376,7 @@ static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
     pl->per_sample_floats = size_t(R) * m->d_inner + size_t(Rq) * pl->hdk + size_t(R) * pl->hdk +
                             size_t(R) * pl->hdv + size_t(Rq) * pl->hdv + size_t(L) * m->d_model;
     // K/V of decoder layers >= 1, projected ahead on the side stream (lamp_set_forward_streams(2))
-    pl->side_kv_floats = m->n_layers_dec > 1 ? size_t(m->n_layers_dec - 1) * T * (pl->hdk + pl->hdv) : 0;
+    pl->side_kv_floats = size_t(m->n_layers_dec) * T * (pl->hdk + pl->hdv);
     return 0;
 }
 
@@ -417,16 +417,19 @@ int side_state(SideState** out) {
 }
 }  // namespace
 
-// The whole batch in micro-batches that fit `workspace`.  `side` (nullable): a second stream on which the
-// K/V projections of decoder layers >= 1 are issued as soon as the encoder output exists; they depend on
-// nothing else, are throughput bound (M = B*T rows), and so fill the CUs that decoder layer 0's small,
-// latency-bound kernels (M = B*L rows) leave idle.  Same kernels on the same data: bit-identical results.
+// The whole batch in micro-batches that fit `workspace`.  `side` (nullable) enables the two-stream mode:
+// encoder and the K/V projections of EVERY decoder layer (they depend only on the encoder output and are
+// throughput bound, M = B*T rows) run full-size on the caller's stream; then the two halves of the micro-batch
+// go through the decoder stack concurrently, one on the caller's stream and one on the side stream -- the
+// decoder's kernels work on only B*L rows and are latency bound, so two of them in flight fill each other's
+// launch gaps and tails.  Samples are independent and the kernels/variants do not depend on the batch size, so
+// results are bit-identical to the one-stream order.
 static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* src_seq, const int64_t* src_pos,
                          int32_t B, int32_t T, float* logits, float* enc_output, const lamp_aux* aux,
                          void* workspace, size_t workspace_bytes, hipStream_t s, SideState* side) {
     const bool want_enc_attn = aux && aux->enc_self_attn;
     const int d = m->d_model, dff = m->d_inner, dk = m->d_k, dv = m->d_v, L = m->n_labels;
-    const int n_ahead = side ? m->n_layers_dec - 1 : 0;  // layers whose K/V are projected ahead
+    const int n_ahead = side ? m->n_layers_dec : 0;  // layers whose enc K/V are projected before the decoder starts
     const size_t per_sample = pl.per_sample_floats + (side ? pl.side_kv_floats : 0);
     const size_t ws_floats = workspace_bytes / sizeof(float);
     if (ws_floats < pl.fixed_floats + per_sample) return LAMP_E_WORKSPACE;
@@ -464,88 +467,96 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
 
         // ---- GraphEncoder.forward (lamp/Encoders.py:64-110) ----
         LAMP_CK(launch_embed(seq, pos, Me, m->src_word_emb, m->n_src_vocab, m->position_enc, m->n_position, d, x, s));
-        lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq, T, 0};
-        for (int i = 0; i < m->n_layers_enc; ++i) {
-            const lamp_enc_layer& l = m->enc_layers[i];
-            if (want_enc_attn && aux->enc_self_attn[i]) {
-                // lamp/Layers.py:16 -- only the attention map of this block is ever observable.  Maps are
-                // (h*B, T, T) over the WHOLE batch, so they need the batch in one micro-batch.
-                if (nb != B) return LAMP_E_UNSUPPORTED;
-                LAMP_CK(mha_core(x, false, x, nb, T, T, d, dk, dv, l.slf_attn, &pad_mask, nullptr,
-                                 aux->enc_self_attn[i], sc, s));
+        {
+            lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq, T, 0};
+            for (int i = 0; i < m->n_layers_enc; ++i) {
+                const lamp_enc_layer& l = m->enc_layers[i];
+                if (want_enc_attn && aux->enc_self_attn[i]) {
+                    // lamp/Layers.py:16 -- only the attention map of this block is ever observable.  Maps are
+                    // (h*B, T, T) over the WHOLE batch, so they need the batch in one micro-batch.
+                    if (nb != B) return LAMP_E_UNSUPPORTED;
+                    LAMP_CK(mha_core(x, false, x, nb, T, T, d, dk, dv, l.slf_attn, &pad_mask, nullptr,
+                                     aux->enc_self_attn[i], sc, s));
+                }
+                LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s));  // lamp/Layers.py:18
             }
-            LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s));  // lamp/Layers.py:18
         }
 
-        // ---- two-stream mode: layer 0's K/V on the caller's stream, THEN fork the K/V of layers >= 1 onto the
-        // side stream, so that they run underneath layer 0's small (M = B*L rows) kernels rather than next to
-        // its own full-chip K/V projection ----
-        if (n_ahead > 0) {
-            LAMP_CK(project_kv(x, Me, d, dk, dv, m->dec_layers[0].enc_attn, sc.K, sc.V, s));
+        // ---- GraphDecoder.forward (lamp/Decoders.py:127-163) for samples [r_lo, r_hi) of the micro-batch ----
+        auto decoder_range = [&](int r_lo, int r_hi, hipStream_t st) -> int {
+            const int nr = r_hi - r_lo;
+            if (nr <= 0) return 0;
+            const float* xr = x + int64_t(r_lo) * T * d;
+            float* Yr = Y + int64_t(r_lo) * L * d;
+            float* Hr = H + int64_t(r_lo) * pl.R * dff;
+            MhaScratch scr;
+            scr.Q = sc.Q + int64_t(r_lo) * Rq * pl.hdk;
+            scr.K = sc.K + int64_t(r_lo) * pl.R * pl.hdk;
+            scr.V = sc.V + int64_t(r_lo) * pl.R * pl.hdv;
+            scr.A = sc.A + int64_t(r_lo) * Rq * pl.hdv;
+            lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq + int64_t(r_lo) * T, T, 0};
+            lamp_mask label_mask{m->label_mask ? LAMP_MASK_U8 : LAMP_MASK_NONE, 0, m->label_mask, 0, L};
+            const int64_t Md = int64_t(nr) * L;
+            int n_int = 0;
+            auto int_pred = [&](void) -> int {
+                if (aux && aux->int_preds && n_int < aux->n_int_preds && aux->int_preds[n_int])
+                    LAMP_CK(launch_diag(Yr, m->w_out, nr, L, d, aux->int_preds[n_int] + (b0 + r_lo) * L, st));
+                ++n_int;
+                return 0;
+            };
+            for (int i = 0; i < m->n_layers_dec; ++i) {
+                const lamp_dec_layer& l = m->dec_layers[i];
+                float* Penc = (aux && aux->dec_enc_attn) ? aux->dec_enc_attn[i] : nullptr;
+                float* Pslf = (aux && aux->dec_self_attn) ? aux->dec_self_attn[i] : nullptr;
+                if ((Penc || Pslf) && nr != B) return LAMP_E_UNSUPPORTED;
+                MhaScratch sci = scr;
+                const bool ahead = n_ahead > 0;
+                if (ahead) {
+                    sci.K = Kahead[i] + int64_t(r_lo) * T * pl.hdk;
+                    sci.V = Vahead[i] + int64_t(r_lo) * T * pl.hdv;
+                }
+                // input->label messages (lamp/Layers.py:35); layer 0's query is the label table itself
+                if (i == 0)
+                    LAMP_CK(mha_core(m->tgt_word_emb, true, xr, nr, L, T, d, dk, dv, l.enc_attn, &pad_mask, Yr, Penc,
+                                     sci, st, ahead, m->dec0_query));
+                else
+                    LAMP_CK(mha_core(Yr, false, xr, nr, L, T, d, dk, dv, l.enc_attn, &pad_mask, Yr, Penc, sci, st, ahead));
+                LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn1, Yr, Hr, st));  // lamp/Layers.py:36
+                if (l.slf_attn.present) {
+                    LAMP_CK(int_pred());  // dec_output_int, lamp/Decoders.py:149-151
+                    // label->label messages over the label graph (lamp/Layers.py:40)
+                    LAMP_CK(mha_core(Yr, false, Yr, nr, L, L, d, dk, dv, l.slf_attn, &label_mask, Yr, Pslf, scr, st));
+                }
+                LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn2, Yr, Hr, st));  // lamp/Layers.py:45
+                if (i + 1 < m->n_layers_dec) LAMP_CK(int_pred());        // all but the last (lamp/Models.py:130)
+            }
+            // read-out (lamp/Models.py:124-126)
+            return launch_diag(Yr, m->w_out, nr, L, d, logits + (b0 + r_lo) * L, st);
+        };
+
+        const bool maps = aux && (aux->dec_enc_attn || aux->dec_self_attn);
+        if (n_ahead > 0 && nb >= 2 && !maps) {
+            for (int i = 0; i < n_ahead; ++i)
+                LAMP_CK(project_kv(x, Me, d, dk, dv, m->dec_layers[i].enc_attn, Kahead[i], Vahead[i], s));
             hipError_t e;
             if ((e = hipEventRecord(side->fork, s)) != hipSuccess) return int(e);
             if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return int(e);
-            int rc = 0;
-            for (int i = 0; i < n_ahead && rc == 0; ++i) {
-                rc = project_kv(x, Me, d, dk, dv, m->dec_layers[i + 1].enc_attn, Kahead[i], Vahead[i], side->stream);
-                hipError_t e2 = hipEventRecord(side->ready[i], side->stream);
-                if (rc == 0 && e2 != hipSuccess) rc = int(e2);
-            }
-            if (rc) {  // keep the caller's stream ordered after whatever was enqueued, then report
-                (void)hipEventRecord(side->ready[0], side->stream);
-                (void)hipStreamWaitEvent(s, side->ready[0], 0);
-                return rc;
-            }
+            const int mid = nb / 2;
+            const int rc_side = decoder_range(mid, nb, side->stream);
+            const hipError_t e1 = hipEventRecord(side->ready[0], side->stream);
+            const int rc_main = decoder_range(0, mid, s);
+            const hipError_t e2 = hipStreamWaitEvent(s, side->ready[0], 0);  // join, also on error
+            if (rc_side) return rc_side;
+            if (rc_main) return rc_main;
+            if (e1 != hipSuccess) return int(e1);
+            if (e2 != hipSuccess) return int(e2);
+        } else if (n_ahead > 0) {
+            for (int i = 0; i < n_ahead; ++i)
+                LAMP_CK(project_kv(x, Me, d, dk, dv, m->dec_layers[i].enc_attn, Kahead[i], Vahead[i], s));
+            LAMP_CK(decoder_range(0, nb, s));
+        } else {
+            LAMP_CK(decoder_range(0, nb, s));
         }
-
-        // ---- GraphDecoder.forward (lamp/Decoders.py:127-163) ----
-        lamp_mask label_mask{m->label_mask ? LAMP_MASK_U8 : LAMP_MASK_NONE, 0, m->label_mask, 0, L};
-        const int64_t Md = int64_t(nb) * L;
-        int n_int = 0;
-        auto int_pred = [&](void) -> int {
-            if (aux && aux->int_preds && n_int < aux->n_int_preds && aux->int_preds[n_int])
-                LAMP_CK(launch_diag(Y, m->w_out, nb, L, d, aux->int_preds[n_int] + b0 * L, s));
-            ++n_int;
-            return 0;
-        };
-        int rc = 0;
-        for (int i = 0; i < m->n_layers_dec && rc == 0; ++i) {
-            const lamp_dec_layer& l = m->dec_layers[i];
-            float* Penc = (aux && aux->dec_enc_attn) ? aux->dec_enc_attn[i] : nullptr;
-            float* Pslf = (aux && aux->dec_self_attn) ? aux->dec_self_attn[i] : nullptr;
-            if ((Penc || Pslf) && nb != B) { rc = LAMP_E_UNSUPPORTED; break; }
-            MhaScratch sci = sc;
-            const bool ahead = n_ahead > 0;  // K/V already projected (layer 0: above; others: side stream)
-            if (ahead && i >= 1) {  // join: this layer's K/V come from the side stream
-                hipError_t e = hipStreamWaitEvent(s, side->ready[i - 1], 0);
-                if (e != hipSuccess) { rc = int(e); break; }
-                sci.K = Kahead[i - 1];
-                sci.V = Vahead[i - 1];
-            }
-            // input->label messages (lamp/Layers.py:35); layer 0's query is the label table itself
-            if (i == 0)
-                rc = mha_core(m->tgt_word_emb, true, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s, ahead,
-                              m->dec0_query);
-            else
-                rc = mha_core(Y, false, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s, ahead);
-            if (rc) break;
-            if ((rc = ffn_core(Y, Md, d, dff, l.pos_ffn1, Y, H, s))) break;  // lamp/Layers.py:36
-            if (l.slf_attn.present) {
-                if ((rc = int_pred())) break;  // dec_output_int, lamp/Decoders.py:149-151
-                // label->label messages over the label graph (lamp/Layers.py:40)
-                if ((rc = mha_core(Y, false, Y, nb, L, L, d, dk, dv, l.slf_attn, &label_mask, Y, Pslf, sc, s))) break;
-            }
-            if ((rc = ffn_core(Y, Md, d, dff, l.pos_ffn2, Y, H, s))) break;  // lamp/Layers.py:45
-            if (i + 1 < m->n_layers_dec) rc = int_pred();                   // all but the last (lamp/Models.py:130)
-        }
-        if (rc) {
-            // never leave side-stream work unordered w.r.t. the caller's stream
-            for (int i = 0; i < n_ahead; ++i) (void)hipStreamWaitEvent(s, side->ready[i], 0);
-            return rc;
-        }
-
-        // ---- read-out (lamp/Models.py:124-126) ----
-        LAMP_CK(launch_diag(Y, m->w_out, nb, L, d, logits + b0 * L, s));
     }
     return 0;
 }
@@ -570,7 +581,7 @@ int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src
     if ((m->d_model & 3) || (m->d_inner & 3) || (m->d_k & 3) || (m->d_v & 3)) return LAMP_E_UNSUPPORTED;
 
     SideState* side = nullptr;
-    if (g_forward_streams == 2 && m->n_layers_dec >= 2 && m->n_layers_dec - 1 <= MAX_SIDE_EVENTS) {
+    if (g_forward_streams == 2 && B >= 2 && m->n_layers_dec <= MAX_SIDE_EVENTS) {
         // only when the workspace holds at least one sample including the look-ahead K/V buffers
         const size_t need = (pl.fixed_floats + pl.per_sample_floats + pl.side_kv_floats) * sizeof(float);
         if (workspace_bytes >= need) LAMP_CK(side_state(&side));
