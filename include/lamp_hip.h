@@ -62,6 +62,13 @@ typedef struct lamp_mask {
     const void* ptr;
     int64_t stride_b;
     int64_t stride_q;
+    /* Optional sparsity hint for a SHARED mask (stride_b == 0): for every block of 32 query rows, the list of
+     * 32-key tiles that contain at least one unblocked entry -- int32 rows of length tile_list_stride:
+     * [count, tile_0, tile_1, ...] in ascending order.  Tiles not listed are skipped entirely (exact: their
+     * probabilities are 0).  NULL = visit every tile.  Ignored when attention maps are written.  This is the
+     * label graph's block structure (lamp/Decoders.py:109-113) handed to the kernel once per model. */
+    const int32_t* tile_list;
+    int64_t tile_list_stride;
 } lamp_mask;
 
 /* Element strides of the four attention operands, so that one kernel serves both the
@@ -121,6 +128,8 @@ typedef struct lamp_model {
     const float* tgt_word_emb;  /* [n_labels, d_model]     decoder.tgt_word_emb.weight */
     const float* w_out;         /* [n_labels, d_model]     tgt_word_proj.linear.weight */
     const uint8_t* label_mask;  /* [n_labels, n_labels] nonzero = blocked, or NULL ('none') */
+    const int32_t* label_tiles; /* optional active-tile list of label_mask (see lamp_mask.tile_list), row stride
+                                   ceil(n_labels/32) + 1; NULL = dense */
     const lamp_enc_layer* enc_layers;
     const lamp_dec_layer* dec_layers;
     /* Optional: decoder layer 0's enc-attention query, tgt_word_emb . w_qs^T  [n_labels, n_head*d_k].  It

@@ -50,6 +50,10 @@ class GraphDecoder(nn.Module):
         if self.label_mask is not None:
             blocked = (self.label_mask.reshape(n_tgt_vocab, n_tgt_vocab) != 0).to(torch.uint8)
         self.register_buffer('label_mask_u8', blocked, persistent=False)
+        # block structure of the label graph: per 32-label query block, the 32-label key tiles with at least
+        # one edge -- lets the attention kernel skip fully blocked tiles (large sparse / clustered graphs)
+        self.register_buffer('label_tiles', N.active_tile_list(blocked) if blocked is not None else None,
+                             persistent=False)
         self.layer_stack = nn.ModuleList(
             DecoderLayer(d_model, d_inner_hid, n_head, n_head2, d_k, d_v, dropout=dropout, dropout2=dropout2,
                          no_dec_self_att=no_dec_self_att, attn_type=attn_type) for _ in range(n_layers))
@@ -60,7 +64,9 @@ class GraphDecoder(nn.Module):
             return None
         N.require_device(m)
         L = m.size(0)
-        return N.Mask(N.LAMP_MASK_U8, 0, m.data_ptr(), 0, L)
+        t = self.label_tiles
+        return N.Mask(N.LAMP_MASK_U8, 0, m.data_ptr(), 0, L, t.data_ptr() if t is not None else None,
+                      t.size(1) if t is not None else 0)
 
     def forward(self, tgt, src_seq, enc_output, return_attns=False, int_preds=False):
         _eval_only(self)

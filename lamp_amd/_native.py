@@ -31,7 +31,8 @@ _vp = C.c_void_p
 
 class Mask(C.Structure):
     _fields_ = [('kind', C.c_int32), ('reserved', C.c_int32), ('ptr', _vp),
-                ('stride_b', C.c_int64), ('stride_q', C.c_int64)]
+                ('stride_b', C.c_int64), ('stride_q', C.c_int64),
+                ('tile_list', _vp), ('tile_list_stride', C.c_int64)]
 
 
 class AttnLayout(C.Structure):
@@ -62,7 +63,7 @@ class Model(C.Structure):
                 ('d_model', C.c_int32), ('d_inner', C.c_int32), ('d_k', C.c_int32), ('d_v', C.c_int32),
                 ('n_layers_enc', C.c_int32), ('n_layers_dec', C.c_int32), ('reserved', C.c_int32),
                 ('src_word_emb', _vp), ('position_enc', _vp), ('tgt_word_emb', _vp), ('w_out', _vp),
-                ('label_mask', _vp), ('enc_layers', C.POINTER(EncLayer)), ('dec_layers', C.POINTER(DecLayer)),
+                ('label_mask', _vp), ('label_tiles', _vp), ('enc_layers', C.POINTER(EncLayer)), ('dec_layers', C.POINTER(DecLayer)),
                 ('dec0_query', _vp)]
 
 
@@ -184,7 +185,25 @@ def make_mask(mask, B, lq, lk):
         m = m.contiguous()
     sb = 0 if m.size(0) == 1 else m.stride(0)
     sq = 0 if m.size(1) == 1 else m.stride(1)
-    return Mask(LAMP_MASK_U8, 0, m.data_ptr(), sb, sq), m
+    return Mask(LAMP_MASK_U8, 0, m.data_ptr(), sb, sq, None, 0), m
+
+
+def active_tile_list(blocked_u8):
+    """Sparsity hint for a shared (lq, lk) uint8 mask: int32 [ceil(lq/32), ceil(lk/32) + 1] rows
+    [count, tile_0, tile_1, ...] of the 32-key tiles holding at least one unblocked entry (host-side, built
+    once per mask)."""
+    m = (blocked_u8.cpu() == 0)
+    lq, lk = m.shape
+    nq, nk = (lq + 31) // 32, (lk + 31) // 32
+    pad = torch.zeros((nq * 32, nk * 32), dtype=torch.bool)
+    pad[:lq, :lk] = m
+    act = pad.view(nq, 32, nk, 32).any(dim=3).any(dim=1)        # (nq, nk)
+    out = torch.zeros((nq, nk + 1), dtype=torch.int32)
+    for i in range(nq):
+        idx = act[i].nonzero().flatten().to(torch.int32)
+        out[i, 0] = idx.numel()
+        out[i, 1:1 + idx.numel()] = idx
+    return out
 
 
 def key_token_mask(src_seq, T):
@@ -193,7 +212,7 @@ def key_token_mask(src_seq, T):
     s = src_seq if src_seq.dtype == torch.int64 else src_seq.long()
     if s.stride(-1) != 1:
         s = s.contiguous()
-    return Mask(LAMP_MASK_KEY_TOKENS_I64, 0, s.data_ptr(), s.stride(0), 0), s
+    return Mask(LAMP_MASK_KEY_TOKENS_I64, 0, s.data_ptr(), s.stride(0), 0, None, 0), s
 
 
 # ------------------------------------------------------------------ thin wrappers

@@ -163,6 +163,8 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     a.mask = mask ? mask->ptr : nullptr;
     a.m_sb = mask ? mask->stride_b : 0;
     a.m_sq = mask ? mask->stride_q : 0;
+    a.tiles = (mask && !attn) ? mask->tile_list : nullptr;
+    a.tiles_stride = mask ? mask->tile_list_stride : 0;
     LAMP_CK(launch_attn(a, s));
     if (!out) return 0;
 
@@ -276,6 +278,8 @@ int lamp_sdpa_fwd(const float* q, const float* k, const float* v, float* out, fl
     a.mask = mask ? mask->ptr : nullptr;
     a.m_sb = mask ? mask->stride_b : 0;
     a.m_sq = mask ? mask->stride_q : 0;
+    a.tiles = (mask && !attn) ? mask->tile_list : nullptr;
+    a.tiles_stride = mask ? mask->tile_list_stride : 0;
     return launch_attn(a, hipStream_t(stream));
 }
 
@@ -468,7 +472,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         // ---- GraphEncoder.forward (lamp/Encoders.py:64-110) ----
         LAMP_CK(launch_embed(seq, pos, Me, m->src_word_emb, m->n_src_vocab, m->position_enc, m->n_position, d, x, s));
         {
-            lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq, T, 0};
+            lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq, T, 0, nullptr, 0};
             for (int i = 0; i < m->n_layers_enc; ++i) {
                 const lamp_enc_layer& l = m->enc_layers[i];
                 if (want_enc_attn && aux->enc_self_attn[i]) {
@@ -494,8 +498,9 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             scr.K = sc.K + int64_t(r_lo) * pl.R * pl.hdk;
             scr.V = sc.V + int64_t(r_lo) * pl.R * pl.hdv;
             scr.A = sc.A + int64_t(r_lo) * Rq * pl.hdv;
-            lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq + int64_t(r_lo) * T, T, 0};
-            lamp_mask label_mask{m->label_mask ? LAMP_MASK_U8 : LAMP_MASK_NONE, 0, m->label_mask, 0, L};
+            lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq + int64_t(r_lo) * T, T, 0, nullptr, 0};
+            lamp_mask label_mask{m->label_mask ? LAMP_MASK_U8 : LAMP_MASK_NONE, 0, m->label_mask, 0, L,
+                                 m->label_mask ? m->label_tiles : nullptr, (L + 31) / 32 + 1};
             const int64_t Md = int64_t(nr) * L;
             int n_int = 0;
             auto int_pred = [&](void) -> int {

@@ -240,15 +240,22 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         // This keeps the 64-register accumulator out of the VALU on almost every tile.  The decision is
         // wave-uniform and depends only on this (sample, head, query block): batch-invariant.
         constexpr float RESCALE_THR = 32.0f;
-        if (wave_active && ks < nt) {
-            load_k(ks);
-            load_mask(ks);
-            load_v(ks);
-            for (int kt = ks; kt < nt; kt += KSPLIT) {
+        // Key tiles to visit: all of them, or -- for a shared mask with a sparsity hint -- only the tiles of this
+        // 32-query block that hold at least one unblocked entry (skipped tiles would contribute exp2(-inf) = 0).
+        const int* tl = p.tiles ? p.tiles + int64_t(q0 >> 5) * p.tiles_stride : nullptr;  // wave-uniform
+        const int n_act = tl ? tl[0] : nt;
+        auto tile_at = [&](int idx) { return idx < n_act ? (tl ? tl[1 + idx] : idx) : nt; };  // nt = past the end
+        if (wave_active && ks < n_act) {
+            int kt = tile_at(ks);
+            load_k(kt);
+            load_mask(kt);
+            load_v(kt);
+            for (int idx = ks; idx < n_act; idx += KSPLIT) {
+                const int kn = tile_at(idx + KSPLIT);  // next tile of this wave (past-the-end: range-checked zeros)
                 f32x16 s;
                 scores(kt, s);
-                load_k(kt + KSPLIT);     // unconditional prefetch (past lk: range-checked zeros),
-                load_mask(kt + KSPLIT);  // flies under softmax + PV
+                load_k(kn);     // unconditional prefetch, flies under softmax + PV
+                load_mask(kn);
                 float tmax = s[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
@@ -273,7 +280,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                 psum += xor32(psum);
                 l_run += psum;
                 pv(s, o);
-                load_v(kt + KSPLIT);  // flies under the next QK^T
+                load_v(kn);  // flies under the next QK^T
+                kt = kn;
             }
         }
         if constexpr (KSPLIT > 1) {
@@ -400,6 +408,7 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     // is chosen from the per-sample shape only.  At most 128 queries and >= 4 key tiles -> 2-way split
     // (36-40 us vs 56-61 us unsplit at reuters batch 32); otherwise none.
     const int nt = (p.lk + 31) / 32;
+    if (p.tiles && (p.m_sb != 0 || p.mask_kind != LAMP_MASK_U8)) return LAMP_E_UNSUPPORTED;  // hint = shared masks
     int ksplit = g_force_attn;
     if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = (p.lq <= 128 && nt >= 4) ? 2 : 1;
     if (dmax <= 32) return launch_attn_dp<32>(p, ksplit, s);

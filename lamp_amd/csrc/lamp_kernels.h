@@ -44,6 +44,8 @@ struct AttnParams {
     int mask_kind;
     const void* mask;
     int64_t m_sb, m_sq;
+    const int* tiles;      // optional per-32-query-block active key-tile lists (shared masks), or nullptr
+    int64_t tiles_stride;
 };
 
 int launch_gemm(const GemmParams& p, hipStream_t s);

@@ -346,6 +346,71 @@ def test_layer0_query_cache_tracks_weight_updates(dev):
     assert torch.equal(after, ref) and not torch.equal(after, cached)
 
 
+def clustered_adjacency(L, n_clusters, seed=0, extra=0.0):
+    """Block-diagonal label graph (labels only co-occur inside their cluster) plus optional random edges."""
+    adj = torch.zeros(L, L)
+    edges = torch.linspace(0, L, n_clusters + 1).long().tolist()
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        adj[lo:hi, lo:hi] = 1
+    if extra > 0:
+        g = torch.Generator().manual_seed(seed)
+        r = (torch.rand(L, L, generator=g) < extra).float()
+        adj = ((adj + r + r.t()) > 0).float()
+    return adj
+
+
+@pytest.mark.parametrize('lq,extra', [(500, 0.0), (500, 0.00005), (100, 0.0)])
+def test_sdpa_tile_skipping_is_exact(dev, lq, extra):
+    """Sparse-aware attention: with the active-tile list of a clustered label mask the kernel
+    visits only tiles holding an edge; the result must equal the dense visit (bitwise when keys are not split
+    across waves) and the oracle."""
+    import ctypes
+    from lamp_amd import _native as N
+    g = torch.Generator().manual_seed(lq)
+    dk, n = 64, 3
+    q, k, v = (torch.randn(n, lq, dk, generator=g) for _ in range(3))
+    blocked = (clustered_adjacency(lq, 5, extra=extra) == 0)
+    ref_o, _ = R.sdpa(q.double(), k.double(), v.double(), blocked.unsqueeze(0).expand(n, lq, lq))
+    mu8 = blocked.to(torch.uint8).to(dev)
+    tiles = N.active_tile_list(mu8).to(dev)
+    assert tiles[:, 0].float().mean().item() < 0.75 * (tiles.size(1) - 1)  # the hint really removes tiles
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    out = {}
+    for name, tl in (('dense', None), ('sparse', tiles)):
+        o = torch.empty_like(qd)
+        ms = N.Mask(N.LAMP_MASK_U8, 0, mu8.data_ptr(), 0, lq, tl.data_ptr() if tl is not None else None,
+                    tl.size(1) if tl is not None else 0)
+        lay = N.AttnLayout(lq * dk, 0, dk, lq * dk, 0, dk, lq * dk, 0, dk, lq * dk, 0, dk)
+        N.check(N.lib().lamp_sdpa_fwd(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), None, n, 1, lq, lq,
+                                      dk, dk, dk ** -0.5, ctypes.byref(ms), ctypes.byref(lay), N.stream()), 'sdpa')
+        out[name] = o
+    assert max_abs_diff(out['sparse'], ref_o) < 2e-5 and max_abs_diff(out['dense'], ref_o) < 2e-5
+    if lq > 128:  # no key split -> same tiles in the same order minus exact zeros
+        assert torch.equal(out['sparse'], out['dense'])
+
+
+def test_model_with_clustered_label_graph_uses_tile_lists(dev):
+    from lamp_amd.Models import LAMP
+    V, L, T, d, dff, h, B = 300, 512, 40, 128, 256, 4, 3
+    sd = R.make_state_dict(V, L, T, d, dff, h, 1, 2, pos_emb=True, seed=4)
+    adj = clustered_adjacency(L, 8)
+    seq, spos = R.make_batch(B, V, T, lengths=[40, 11, 25], seed=4)
+    m = LAMP(V, L, T, L, n_layers_enc=1, n_layers_dec=2, n_head=h, n_head2=h, d_word_vec=d, d_model=d,
+             d_inner_hid=dff, d_k=d // h, d_v=d // h, encoder='graph', decoder='graph',
+             label_adj_matrix=adj.clone(), label_mask='prior', dec_dropout2=False)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    assert m.decoder.label_tiles[:, 0].max().item() <= 3          # 8 clusters of 64 labels: <= 3 tiles per row block
+    src = (seq.to(dev), spos.to(dev))
+    sparse, _, _ = m(src, None, None, None)
+    m.use_label_tiles = False
+    dense, _, _ = m(src, None, None, None)
+    with torch.no_grad():
+        ref, _, _ = R.forward(sd, seq, spos, h, R.label_block_mask(adj, 'prior', L))
+    assert torch.equal(sparse, dense)
+    assert max_abs_diff(sparse, ref) < TOL_LOGIT
+
+
 def test_trailing_padding_does_not_change_results(dev):
     """Extra PAD columns are blocked keys and PAD rows of the encoder: logits must not move beyond
     rounding noise (tile boundaries shift, so not bitwise)."""

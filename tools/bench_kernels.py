@@ -86,6 +86,36 @@ def steady():
         print(row)
 
 
+def sparse():
+    """Label self-attention at L = 4096 with a clustered (block-diagonal) label graph: dense tile visit vs the
+    active-tile list."""
+    dev = torch.device('cuda:0')
+    B, H, L, dk = 4, 8, 4096, 128
+    q = torch.randn(B, L, H * dk, device=dev)
+    k = torch.randn(B, L, H * dk, device=dev)
+    v = torch.randn(B, L, H * dk, device=dev)
+    o = torch.empty_like(q)
+    lay = N.AttnLayout(L * H * dk, dk, H * dk, L * H * dk, dk, H * dk, L * H * dk, dk, H * dk, L * H * dk, dk, H * dk)
+    for n_clusters in (1, 4, 16, 64):
+        blocked = torch.ones(L, L, dtype=torch.uint8)
+        edges = torch.linspace(0, L, n_clusters + 1).long().tolist()
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            blocked[lo:hi, lo:hi] = 0
+        mu8 = blocked.to(dev)
+        tiles = N.active_tile_list(mu8).to(dev)
+        for name, tl in (('dense', None), ('tile-list', tiles)):
+            ms = N.Mask(N.LAMP_MASK_U8, 0, mu8.data_ptr(), 0, L, tl.data_ptr() if tl is not None else None,
+                        tl.size(1) if tl is not None else 0)
+
+            def fn():
+                N.check(N.lib().lamp_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), None, B, H, L, L,
+                                              dk, dk, dk ** -0.5, ctypes.byref(ms), ctypes.byref(lay), N.stream()),
+                        'sdpa')
+            us = time_fn(fn, iters=5, warm=2)
+            print('L=4096, %2d clusters (%5.1f%% of tiles active)  %-9s %9.1f us' %
+                  (n_clusters, 100.0 * tiles[:, 0].float().mean().item() / (tiles.size(1) - 1), name, us))
+
+
 def attn():
     dev = torch.device('cuda:0')
     cases = [('reuters enc-attn', 32, 4, 90, 302, 128), ('reuters self', 32, 4, 90, 90, 128),
@@ -119,4 +149,4 @@ def attn():
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
-    {'gemm': gemm, 'attn': attn, 'steady': steady}[which]()
+    {'gemm': gemm, 'attn': attn, 'steady': steady, 'sparse': sparse}[which]()
