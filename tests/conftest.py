@@ -17,6 +17,14 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_sessionstart(session):
+    """liblamp_hip.so is a build artefact (git-ignored): compile it for gfx950 if this checkout has none, or if
+    a source is newer.  hipcc cross-compiles without a GPU, so this also works in the CPU-only container."""
+    from lamp_amd import build as _build
+    if _build.needs_build():
+        _build.build()
+
+
 def load_golden(name):
     """Load one committed fixture -> (dict of torch tensors / python scalars, state_dict)."""
     z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)

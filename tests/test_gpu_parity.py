@@ -451,3 +451,55 @@ def test_label_permutation_equivariance(dev):
     m2 = m2.to(dev).eval()
     out, _, _ = m2((seq.to(dev), spos.to(dev)), None, None, None)
     assert max_abs_diff(out, base[:, perm.to(dev)]) < 2e-5
+
+
+# ------------------------------------------------------------------ randomized shape sweep
+def _random_case(i):
+    import random
+    rng = random.Random(1000 + i)
+    h = rng.choice([1, 2, 3, 4, 8])
+    dk = rng.choice([4, 8, 12, 16, 20, 32, 36, 64])
+    d = h * dk
+    if h == 1:
+        d = rng.choice([4, 8, 20, 64, 128])  # no fc: d_v must equal d_model
+    dff = rng.choice([4, 12, 64, 100, 200, 516])
+    L = rng.choice([1, 2, 17, 31, 32, 33, 64, 95, 129, 300])
+    T = rng.choice([1, 2, 5, 31, 32, 33, 97, 150])
+    B = rng.randint(1, 6)
+    mask = rng.choice(['prior', 'none', 'inveye'])
+    pos = rng.random() < 0.5
+    n_enc, n_dec = rng.randint(1, 3), rng.randint(1, 3)
+    no_slf = rng.random() < 0.2
+    lengths = [rng.randint(1, T) for _ in range(B)]
+    lengths[rng.randrange(B)] = T
+    return dict(h=h, d=d, dff=dff, L=L, T=T, B=B, mask=mask, pos=pos, n_enc=n_enc, n_dec=n_dec, no_slf=no_slf,
+                lengths=lengths, V=rng.choice([5, 40, 1000]))
+
+
+@pytest.mark.parametrize('i', list(range(24)))
+def test_random_model_shapes_vs_oracle(dev, i):
+    """Seeded sweep over awkward shapes (tiny / non-power-of-two widths, L or T of 1, ragged lengths, 1-3
+    layers, every mask kind, with and without decoder self-attention): whole-model logits vs the oracle."""
+    from lamp_amd.Models import LAMP
+    c = _random_case(i)
+    h, d = c['h'], c['d']
+    sd = R.make_state_dict(c['V'], c['L'], c['T'], d, c['dff'], h, c['n_enc'], c['n_dec'], pos_emb=c['pos'],
+                           seed=i, no_dec_self_att=c['no_slf'])
+    adj = R.make_adjacency(c['L'], 0.2, i) if c['mask'] == 'prior' else None
+    seq, spos = R.make_batch(c['B'], c['V'], c['T'], lengths=c['lengths'], seed=i)
+    m = LAMP(c['V'], c['L'], c['T'], c['L'], n_layers_enc=c['n_enc'], n_layers_dec=c['n_dec'], n_head=h, n_head2=h,
+             d_word_vec=d, d_model=d, d_inner_hid=c['dff'], d_k=d // h, d_v=d // h, encoder='graph', decoder='graph',
+             no_enc_pos_embedding=not c['pos'], no_dec_self_att=c['no_slf'],
+             label_adj_matrix=adj.clone() if adj is not None else None, label_mask=c['mask'], dec_dropout2=False)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        ref_logits, ref_enc, _ = R.forward(sd, seq, spos, h, R.label_block_mask(adj, c['mask'], c['L']))
+        ref64, _, _ = R.forward(R.to_dtype(sd, torch.float64), seq, spos, h,
+                                R.label_block_mask(adj, c['mask'], c['L']))
+    logits, enc, _ = m((seq.to(dev), spos.to(dev)), None, None, None)
+    assert logits.shape == ref_logits.shape, c
+    assert max_abs_diff(enc, ref_enc) < TOL_ACT, c
+    # tiny widths make LayerNorm ill-conditioned: scale the bar by the oracle's own fp32-vs-fp64 gap (SURVEY G13)
+    gap = max_abs_diff(ref_logits, ref64)
+    assert max_abs_diff(logits, ref64) < max(TOL_LOGIT, 4 * gap), (c, gap)
