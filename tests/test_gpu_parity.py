@@ -503,3 +503,41 @@ def test_random_model_shapes_vs_oracle(dev, i):
     # tiny widths make LayerNorm ill-conditioned: scale the bar by the oracle's own fp32-vs-fp64 gap
     gap = max_abs_diff(ref_logits, ref64)
     assert max_abs_diff(logits, ref64) < max(TOL_LOGIT, 4 * gap), (c, gap)
+
+
+# ------------------------------------------------------------------ error behaviour at the boundary
+def test_errors_surface_as_status_codes_not_crashes(dev):
+    """SURVEY.md 8b "Errors": unsupported configurations, undersized workspaces and misaligned pointers come back
+    as negative lamp_status codes (-> LampError in Python); the device stays usable afterwards."""
+    import ctypes
+    from lamp_amd import _native as N
+    lib = N.lib()
+    x = torch.randn(8, 64, device=dev)
+    w = torch.randn(32, 64, device=dev)
+    out = torch.empty(8, 32, device=dev)
+    # misaligned A (offset by one float): LAMP_E_ALIGN
+    buf = torch.randn(8 * 64 + 4, device=dev)
+    assert lib.lamp_linear_fwd(buf.data_ptr() + 4, 8, 64, 64, w.data_ptr(), 32, 64, None, None, 0, 0,
+                               out.data_ptr(), 32, N.stream()) == -2
+    # d_k = 132 > 128: LAMP_E_UNSUPPORTED, raised as LampError by the wrapper
+    q = torch.randn(2, 5, 132, device=dev)
+    with pytest.raises(N.LampError) as ei:
+        N.sdpa(q, q, q, None, 1.0)
+    assert ei.value.status == -4 and 'not supported' in str(ei.value)
+    # workspace one byte short of a single sample: LAMP_E_WORKSPACE
+    m, sd, blocked, seq, spos, h = make_case(CONFIGS['inveye_8h'], dev)
+    model, enc_arr, dec_arr, _q0 = m._native_model()
+    B, T = seq.shape
+    need = lib.lamp_forward_workspace_bytes(ctypes.byref(model), 1, T, 0)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    logits = torch.empty(B, m.n_labels, device=dev)
+    enc = torch.empty(B, T, m.d_model, device=dev)
+    s_, p_ = seq.to(dev), spos.to(dev)
+    args = (ctypes.byref(model), s_.data_ptr(), p_.data_ptr(), B, T, logits.data_ptr(), enc.data_ptr(), None)
+    assert lib.lamp_forward(*args, ws.data_ptr(), need // 2, N.stream()) == -3
+    # ... and with exactly one sample's worth it succeeds by micro-batching sample by sample
+    assert lib.lamp_forward(*args, ws.data_ptr(), need, N.stream()) == 0
+    ref, _, _ = m((s_, p_), None, None, None)
+    assert torch.equal(logits, ref)
+    # the earlier failures left no sticky error behind
+    assert max_abs_diff(N.linear(x, w), x.double() @ w.double().t()) < 1e-4
