@@ -53,7 +53,10 @@ enum lamp_status {
 enum lamp_mask_kind {
     LAMP_MASK_NONE = 0,
     LAMP_MASK_U8 = 1,            /* uint8, nonzero = blocked; element (b,q,k) at ptr[b*stride_b + q*stride_q + k] */
-    LAMP_MASK_KEY_TOKENS_I64 = 2 /* int64 token ids [B, stride_b]; key k of sample b is blocked iff token == 0 (PAD) */
+    LAMP_MASK_KEY_TOKENS_I64 = 2, /* int64 token ids [B, stride_b]; key k of sample b is blocked iff token == 0 (PAD) */
+    LAMP_MASK_BITS_U32 = 3        /* bit-packed rows: uint32 words, element (b,q,k) = bit (k & 31) of word
+                                     ptr[b*stride_b + q*stride_q + (k >> 5)] (strides in words), 1 = blocked; bits
+                                     past lk are ignored.  One 4-byte load covers a whole 32-key tile of a row. */
 };
 
 typedef struct lamp_mask {
@@ -128,6 +131,8 @@ typedef struct lamp_model {
     const float* tgt_word_emb;  /* [n_labels, d_model]     decoder.tgt_word_emb.weight */
     const float* w_out;         /* [n_labels, d_model]     tgt_word_proj.linear.weight */
     const uint8_t* label_mask;  /* [n_labels, n_labels] nonzero = blocked, or NULL ('none') */
+    const uint32_t* label_mask_bits; /* optional bit-packed copy of label_mask (LAMP_MASK_BITS_U32 rows of
+                                        ceil(n_labels/32) words); used instead of the byte mask when given */
     const int32_t* label_tiles; /* optional active-tile list of label_mask (see lamp_mask.tile_list), row stride
                                    ceil(n_labels/32) + 1; NULL = dense */
     const lamp_enc_layer* enc_layers;

@@ -50,6 +50,9 @@ class GraphDecoder(nn.Module):
         if self.label_mask is not None:
             blocked = (self.label_mask.reshape(n_tgt_vocab, n_tgt_vocab) != 0).to(torch.uint8)
         self.register_buffer('label_mask_u8', blocked, persistent=False)
+        # the same mask bit-packed per row: the attention kernel then fetches one 32-bit word per 32-key tile
+        self.register_buffer('label_mask_bits', N.pack_mask_bits(blocked) if blocked is not None else None,
+                             persistent=False)
         # block structure of the label graph: per 32-label query block, the 32-label key tiles with at least
         # one edge -- lets the attention kernel skip fully blocked tiles (large sparse / clustered graphs)
         self.register_buffer('label_tiles', N.active_tile_list(blocked) if blocked is not None else None,
@@ -64,9 +67,11 @@ class GraphDecoder(nn.Module):
             return None
         N.require_device(m)
         L = m.size(0)
-        t = self.label_tiles
-        return N.Mask(N.LAMP_MASK_U8, 0, m.data_ptr(), 0, L, t.data_ptr() if t is not None else None,
-                      t.size(1) if t is not None else 0)
+        t, bits = self.label_tiles, self.label_mask_bits
+        tl = (t.data_ptr() if t is not None else None, t.size(1) if t is not None else 0)
+        if bits is not None:
+            return N.Mask(N.LAMP_MASK_BITS_U32, 0, bits.data_ptr(), 0, bits.size(1), *tl)
+        return N.Mask(N.LAMP_MASK_U8, 0, m.data_ptr(), 0, L, *tl)
 
     def forward(self, tgt, src_seq, enc_output, return_attns=False, int_preds=False):
         _eval_only(self)

@@ -87,8 +87,9 @@ class LAMP(nn.Module):
         params = [p for p in self.parameters()]
         mask = self.decoder.label_mask_u8
         tiles = self.decoder.label_tiles
-        key = tuple(p.data_ptr() for p in params) + (N.ptr(mask), N.ptr(tiles), self.use_label_tiles,
-                                                      self.cache_layer0_query)
+        bits = self.decoder.label_mask_bits
+        key = tuple(p.data_ptr() for p in params) + (N.ptr(mask), N.ptr(bits), N.ptr(tiles), self.use_label_tiles,
+                                                      self.cache_layer0_query, self.use_mask_bits)
         if self.cache_layer0_query:  # the hoisted projection below is stale once either operand changes
             l0 = self.decoder.layer_stack[0].enc_attn
             key += (self.decoder.tgt_word_emb.weight._version, l0.w_qs.weight._version)
@@ -114,7 +115,8 @@ class LAMP(nn.Module):
         m = N.Model(enc.src_word_emb.weight.size(0), pos.size(0) if pos is not None else 0, self.n_labels,
                     self.d_model, self.d_inner, self.d_k, self.d_v, len(enc.layer_stack), len(dec.layer_stack),
                     0, N.ptr(enc.src_word_emb.weight), N.ptr(pos), N.ptr(dec.tgt_word_emb.weight),
-                    N.ptr(w_out), N.ptr(mask), N.ptr(tiles) if self.use_label_tiles else 0, enc_arr, dec_arr, 0)
+                    N.ptr(w_out), N.ptr(mask), N.ptr(bits) if self.use_mask_bits else 0,
+                    N.ptr(tiles) if self.use_label_tiles else 0, enc_arr, dec_arr, 0)
         q0 = None
         if self.cache_layer0_query and len(dec.layer_stack) > 0:
             # decoder layer 0's query = label table x W_q: weights only, so it is projected here once per
@@ -194,3 +196,5 @@ class LAMP(nn.Module):
     cache_layer0_query = True
     # Skip fully blocked 32x32 tiles of the label graph in the label->label attention.
     use_label_tiles = True
+    # Read the label mask bit-packed (one 32-bit word per 32-key tile and row) instead of as bytes.
+    use_mask_bits = True

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblamp_hip.so')
 
-LAMP_MASK_NONE, LAMP_MASK_U8, LAMP_MASK_KEY_TOKENS_I64 = 0, 1, 2
+LAMP_MASK_NONE, LAMP_MASK_U8, LAMP_MASK_KEY_TOKENS_I64, LAMP_MASK_BITS_U32 = 0, 1, 2, 3
 K_EMBED, K_GEMM, K_ATTN, K_LAYERNORM, K_DIAG, K_COUNT = 0, 1, 2, 3, 4, 5
 KERNEL_CLASS_NAMES = ('embed', 'gemm', 'attention', 'layernorm', 'diag_readout')
 
@@ -63,7 +63,7 @@ class Model(C.Structure):
                 ('d_model', C.c_int32), ('d_inner', C.c_int32), ('d_k', C.c_int32), ('d_v', C.c_int32),
                 ('n_layers_enc', C.c_int32), ('n_layers_dec', C.c_int32), ('reserved', C.c_int32),
                 ('src_word_emb', _vp), ('position_enc', _vp), ('tgt_word_emb', _vp), ('w_out', _vp),
-                ('label_mask', _vp), ('label_tiles', _vp), ('enc_layers', C.POINTER(EncLayer)), ('dec_layers', C.POINTER(DecLayer)),
+                ('label_mask', _vp), ('label_mask_bits', _vp), ('label_tiles', _vp), ('enc_layers', C.POINTER(EncLayer)), ('dec_layers', C.POINTER(DecLayer)),
                 ('dec0_query', _vp)]
 
 
@@ -186,6 +186,20 @@ def make_mask(mask, B, lq, lk):
     sb = 0 if m.size(0) == 1 else m.stride(0)
     sq = 0 if m.size(1) == 1 else m.stride(1)
     return Mask(LAMP_MASK_U8, 0, m.data_ptr(), sb, sq, None, 0), m
+
+
+def pack_mask_bits(blocked_u8):
+    """(lq, lk) uint8 mask -> int32 [lq, ceil(lk/32)] rows, bit (k & 31) of word (k >> 5) = blocked
+    (LAMP_MASK_BITS_U32).  Host-side, once per mask."""
+    m = (blocked_u8.cpu() != 0)
+    lq, lk = m.shape
+    nw = (lk + 31) // 32
+    pad = torch.zeros((lq, nw * 32), dtype=torch.int64)
+    pad[:, :lk] = m.to(torch.int64)
+    weights = (torch.ones(32, dtype=torch.int64) << torch.arange(32, dtype=torch.int64))
+    words = (pad.view(lq, nw, 32) * weights).sum(dim=2)             # 0 .. 2^32 - 1
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words)    # reinterpret as int32
+    return words.to(torch.int32).contiguous()
 
 
 def active_tile_list(blocked_u8):

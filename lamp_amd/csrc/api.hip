@@ -93,7 +93,8 @@ static int linear(const float* A, int64_t M, int K, int64_t lda, const float* co
 
 static int check_mask(const lamp_mask* m) {
     if (!m) return 0;
-    if (m->kind != LAMP_MASK_NONE && m->kind != LAMP_MASK_U8 && m->kind != LAMP_MASK_KEY_TOKENS_I64)
+    if (m->kind != LAMP_MASK_NONE && m->kind != LAMP_MASK_U8 && m->kind != LAMP_MASK_KEY_TOKENS_I64 &&
+        m->kind != LAMP_MASK_BITS_U32)
         return LAMP_E_UNSUPPORTED;
     if (m->kind != LAMP_MASK_NONE && !m->ptr) return LAMP_E_NULL;
     return 0;
@@ -499,8 +500,13 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             scr.V = sc.V + int64_t(r_lo) * pl.R * pl.hdv;
             scr.A = sc.A + int64_t(r_lo) * Rq * pl.hdv;
             lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq + int64_t(r_lo) * T, T, 0, nullptr, 0};
-            lamp_mask label_mask{m->label_mask ? LAMP_MASK_U8 : LAMP_MASK_NONE, 0, m->label_mask, 0, L,
-                                 m->label_mask ? m->label_tiles : nullptr, (L + 31) / 32 + 1};
+            // the label graph: bit-packed rows when the caller provides them (one dword per 32-key tile), else bytes
+            lamp_mask label_mask{LAMP_MASK_NONE, 0, nullptr, 0, 0, nullptr, 0};
+            if (m->label_mask_bits)
+                label_mask = lamp_mask{LAMP_MASK_BITS_U32, 0, m->label_mask_bits, 0, (L + 31) / 32, m->label_tiles,
+                                       (L + 31) / 32 + 1};
+            else if (m->label_mask)
+                label_mask = lamp_mask{LAMP_MASK_U8, 0, m->label_mask, 0, L, m->label_tiles, (L + 31) / 32 + 1};
             const int64_t Md = int64_t(nr) * L;
             int n_int = 0;
             auto int_pred = [&](void) -> int {

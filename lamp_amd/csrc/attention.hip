@@ -39,7 +39,8 @@ namespace lamp {
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
-template <int DP, int KSPLIT, bool WRITE_P>
+// MK = mask kind (LAMP_MASK_*), a compile-time parameter so that each variant carries only its own mask code.
+template <int DP, int KSPLIT, bool WRITE_P, int MK>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     static_assert(!WRITE_P || KSPLIT == 1, "probability write-out uses unsplit keys");
     constexpr int DKC = DP / 8, DVB = DP / 32, QB = 4 / KSPLIT, QS = DP + 4;
@@ -71,13 +72,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         make_rsrc(has_v ? p.V + int64_t(b) * p.lay.v_b + int64_t(h) * p.lay.v_h : p.K,
                   has_v ? (uint64_t(p.lk - 1) * v_r + p.dv) * 4u : 0);
     const __amdgpu_buffer_rsrc_t rsM =
-        p.mask_kind == LAMP_MASK_U8
+        MK == LAMP_MASK_BITS_U32
+            ? make_rsrc(static_cast<const unsigned*>(p.mask) + int64_t(b) * p.m_sb,
+                        (uint64_t(p.lq - 1) * uint64_t(p.m_sq) + (p.lk + 31) / 32) * 4u)
+        : MK == LAMP_MASK_U8
             ? make_rsrc(static_cast<const unsigned char*>(p.mask) + int64_t(b) * p.m_sb,
                         uint64_t(p.lq - 1) * uint64_t(p.m_sq) + p.lk)
-            : make_rsrc(p.mask_kind == LAMP_MASK_KEY_TOKENS_I64
-                            ? static_cast<const void*>(static_cast<const long long*>(p.mask) + int64_t(b) * p.m_sb)
-                            : static_cast<const void*>(p.K),
-                        p.mask_kind == LAMP_MASK_KEY_TOKENS_I64 ? uint64_t(p.lk) * 8u : 0);
+        : MK == LAMP_MASK_KEY_TOKENS_I64
+            ? make_rsrc(static_cast<const long long*>(p.mask) + int64_t(b) * p.m_sb, uint64_t(p.lk) * 8u)
+            : make_rsrc(p.K, 0);
 
     // ---- Q block -> LDS (pre-scaled); the KSPLIT waves of a block share the copy work ----
     float* Qs = smem + qb * 32 * QS;
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     float4 kf[DKC];
     float vf[16][DVB];   // V[key_r(hi)][DVB*l31 + e]: block e of O^T holds dv columns {DVB*i + e}
     unsigned mraw[16];   // raw mask bytes / token-is-PAD flags of the tile, loaded one tile ahead
+    unsigned mword = 0;  // LAMP_MASK_BITS_U32: this row's 32 mask bits of the tile (one load instead of sixteen)
 
     auto load_k = [&](int kt) {
         const unsigned base = unsigned((kt * 32 + l31) * k_r + hi * 4) * 4u;
@@ -126,17 +130,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     };
     auto load_mask = [&](int kt) {
         const int kbase = kt * 32 + 4 * hi;
-        if (p.mask_kind == LAMP_MASK_U8) {
+        if constexpr (MK == LAMP_MASK_BITS_U32) {
+            // this row's 32 mask bits of the tile, pre-shifted so that bit (r&3)+8(r>>2) belongs to register r
+            mword = __builtin_amdgcn_raw_buffer_load_b32(rsM, unsigned(int64_t(qc) * p.m_sq + kt) * 4u, 0, 0);
+        } else if constexpr (MK == LAMP_MASK_U8) {
             const unsigned mo = unsigned(int64_t(qc) * p.m_sq) + unsigned(kbase);
 #pragma unroll
             for (int r = 0; r < 16; ++r) mraw[r] = bload_u8(rsM, mo + (r & 3) + 8 * (r >> 2));
-        } else if (p.mask_kind == LAMP_MASK_KEY_TOKENS_I64) {
+        } else if constexpr (MK == LAMP_MASK_KEY_TOKENS_I64) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)  // past lk: reads 0 == PAD == blocked (forced to -inf below anyway)
                 mraw[r] = bload_u64(rsM, unsigned(kbase + (r & 3) + 8 * (r >> 2)) * 8u) == 0 ? 1u : 0u;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mraw[r] = 0u;
         }
     };
     // S^T = K Q^T for the tile in kf, Q fragments read QG chunks ahead from LDS; then -inf where blocked.
@@ -165,10 +169,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             for (int j = 0; j < QG; ++j) qa[j] = qn[j];
         }
         const int kbase = kt * 32 + 4 * hi;
+        const unsigned mw = MK == LAMP_MASK_BITS_U32 ? mword >> (4 * hi) : 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kbase + (r & 3) + 8 * (r >> 2);
-            if (key >= p.lk || mraw[r] != 0) s[r] = -INFINITY;
+            bool blk = false;
+            if constexpr (MK == LAMP_MASK_BITS_U32) blk = (mw & (1u << ((r & 3) + 8 * (r >> 2)))) != 0;
+            if constexpr (MK == LAMP_MASK_U8 || MK == LAMP_MASK_KEY_TOKENS_I64) blk = mraw[r] != 0;
+            if (key >= p.lk || blk) s[r] = -INFINITY;
         }
     };
     auto pv = [&](const f32x16& pr, f32x16 (&o)[DVB]) {
@@ -350,13 +358,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     }
 }
 
-template <int DP, int KSPLIT, bool WRITE_P>
-static int launch_attn_ks(const AttnParams& p, hipStream_t s) {
+template <int DP, int KSPLIT, bool WRITE_P, int MK>
+static int launch_attn_mk(const AttnParams& p, hipStream_t s) {
     constexpr int QB = 4 / KSPLIT;
     constexpr size_t lds_q = size_t(QB) * 32 * (DP + 4) * sizeof(float);
     constexpr size_t lds_c = KSPLIT > 1 ? size_t(4) * (DP + 2) * 32 * sizeof(float) : 0;
     constexpr size_t lds = lds_q > lds_c ? lds_q : lds_c;
-    auto kern = attn_kernel<DP, KSPLIT, WRITE_P>;
+    auto kern = attn_kernel<DP, KSPLIT, WRITE_P, MK>;
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -370,6 +378,16 @@ static int launch_attn_ks(const AttnParams& p, hipStream_t s) {
     if (nwg > 0x7fffffffLL) return LAMP_E_DIMS;
     hipLaunchKernelGGL(kern, dim3(unsigned(nwg)), dim3(256), lds, s, p);
     return int(hipGetLastError());
+}
+
+template <int DP, int KSPLIT, bool WRITE_P>
+static int launch_attn_ks(const AttnParams& p, hipStream_t s) {
+    switch (p.mask_kind) {
+        case LAMP_MASK_U8: return launch_attn_mk<DP, KSPLIT, WRITE_P, LAMP_MASK_U8>(p, s);
+        case LAMP_MASK_KEY_TOKENS_I64: return launch_attn_mk<DP, KSPLIT, WRITE_P, LAMP_MASK_KEY_TOKENS_I64>(p, s);
+        case LAMP_MASK_BITS_U32: return launch_attn_mk<DP, KSPLIT, WRITE_P, LAMP_MASK_BITS_U32>(p, s);
+        default: return launch_attn_mk<DP, KSPLIT, WRITE_P, LAMP_MASK_NONE>(p, s);
+    }
 }
 
 template <int DP>
@@ -401,14 +419,15 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     ProfScope prof(LAMP_K_ATTN, flops, bytes, s);
     const int dmax = p.dk > p.dv ? p.dk : p.dv;
     if (int64_t(p.lq) * L.q_r * 4 >= 0x7fffffffLL || int64_t(p.lk) * L.k_r * 4 >= 0x7fffffffLL ||
-        int64_t(p.lk) * L.v_r * 4 >= 0x7fffffffLL || int64_t(p.lq) * p.m_sq + p.lk >= 0x7fffffffLL)
+        int64_t(p.lk) * L.v_r * 4 >= 0x7fffffffLL || (int64_t(p.lq) * p.m_sq + p.lk) * (p.mask_kind == LAMP_MASK_BITS_U32 ? 4 : 1) >= 0x7fffffffLL)
         return LAMP_E_UNSUPPORTED;  // 32-bit offsets inside one (sample, head) slice
     // Key split: must NOT depend on the batch size (a split sums in a different order than the
     // sequential online softmax, and samples must come out bit-identical for every batch / shard), so it
     // is chosen from the per-sample shape only.  At most 128 queries and >= 4 key tiles -> 2-way split
     // (36-40 us vs 56-61 us unsplit at reuters batch 32); otherwise none.
     const int nt = (p.lk + 31) / 32;
-    if (p.tiles && (p.m_sb != 0 || p.mask_kind != LAMP_MASK_U8)) return LAMP_E_UNSUPPORTED;  // hint = shared masks
+    if (p.tiles && (p.m_sb != 0 || (p.mask_kind != LAMP_MASK_U8 && p.mask_kind != LAMP_MASK_BITS_U32)))
+        return LAMP_E_UNSUPPORTED;  // the sparsity hint belongs to shared masks
     int ksplit = g_force_attn;
     if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = (p.lq <= 128 && nt >= 4) ? 2 : 1;
     if (dmax <= 32) return launch_attn_dp<32>(p, ksplit, s);

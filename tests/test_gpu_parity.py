@@ -389,6 +389,41 @@ def test_sdpa_tile_skipping_is_exact(dev, lq, extra):
         assert torch.equal(out['sparse'], out['dense'])
 
 
+@pytest.mark.parametrize('lq,lk', [(90, 90), (159, 159), (70, 130), (33, 31)])
+def test_bit_packed_mask_equals_byte_mask(dev, lq, lk):
+    """LAMP_MASK_BITS_U32 (one dword per row and 32-key tile) must give exactly the bits of the uint8 mask,
+    dead rows and ragged last words included, with and without attention maps."""
+    import ctypes
+    from lamp_amd import _native as N
+    g = torch.Generator().manual_seed(lq * lk)
+    dk, n = 32, 4
+    q = torch.randn(n, lq, dk, generator=g).to(dev)
+    k = torch.randn(n, lk, dk, generator=g).to(dev)
+    v = torch.randn(n, lk, dk, generator=g).to(dev)
+    blocked = (torch.rand(lq, lk, generator=g) < 0.6).to(torch.uint8)
+    blocked[:, 0] = 0
+    blocked[lq // 2, :] = 1                       # a dead row
+    mu8 = blocked.to(dev)
+    bits = N.pack_mask_bits(blocked).to(dev)
+    lay = N.AttnLayout(lq * dk, 0, dk, lk * dk, 0, dk, lk * dk, 0, dk, lq * dk, 0, dk)
+    res = {}
+    for name, ms in (('u8', N.Mask(N.LAMP_MASK_U8, 0, mu8.data_ptr(), 0, lk, None, 0)),
+                     ('bits', N.Mask(N.LAMP_MASK_BITS_U32, 0, bits.data_ptr(), 0, bits.size(1), None, 0))):
+        for want_p in (False, True):
+            o = torch.empty_like(q)
+            pm = torch.empty(n, lq, lk, device=dev) if want_p else None
+            N.check(N.lib().lamp_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), N.ptr(pm), n, 1, lq,
+                                          lk, dk, dk, dk ** -0.5, ctypes.byref(ms), ctypes.byref(lay), N.stream()),
+                    'sdpa')
+            res[(name, want_p)] = (o, pm)
+    for want_p in (False, True):
+        a, b = res[('u8', want_p)], res[('bits', want_p)]
+        assert max_abs_diff(a[0], b[0]) == 0.0
+        if want_p:
+            assert max_abs_diff(a[1], b[1]) == 0.0
+    assert torch.isnan(res[('bits', False)][0][:, lq // 2]).all()
+
+
 def test_model_with_clustered_label_graph_uses_tile_lists(dev):
     from lamp_amd.Models import LAMP
     V, L, T, d, dff, h, B = 300, 512, 40, 128, 256, 4, 3
@@ -405,6 +440,9 @@ def test_model_with_clustered_label_graph_uses_tile_lists(dev):
     sparse, _, _ = m(src, None, None, None)
     m.use_label_tiles = False
     dense, _, _ = m(src, None, None, None)
+    m.use_mask_bits = False
+    bytes_, _, _ = m(src, None, None, None)
+    assert torch.equal(bytes_, dense)
     with torch.no_grad():
         ref, _, _ = R.forward(sd, seq, spos, h, R.label_block_mask(adj, 'prior', L))
     assert torch.equal(sparse, dense)

@@ -41,7 +41,7 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(N.FfnWeights) == 48
     assert ctypes.sizeof(N.EncLayer) == 104
     assert ctypes.sizeof(N.DecLayer) == 208
-    assert ctypes.sizeof(N.Model) == 112
+    assert ctypes.sizeof(N.Model) == 120
     assert ctypes.sizeof(N.Aux) == 40
 
 
@@ -84,7 +84,7 @@ def test_state_dict_layout_equals_reference(name):
         assert torch.equal(m.decoder.label_mask_u8, (d['ref_label_mask'].view(L, L) != 0).to(torch.uint8))
     elif d['label_mask'] == 'none':
         assert m.decoder.label_mask is None and m.decoder.label_mask_u8 is None
-    assert 'decoder.label_mask_u8' not in own and 'decoder.label_tiles' not in own
+    assert not any(k.startswith('decoder.label_') for k in own)
     # the sinusoid table is frozen out of the optimiser's parameter list only
     n_train = sum(1 for _ in m.get_trainable_parameters())
     assert n_train == len(list(m.parameters())) - (1 if 'encoder.position_enc.weight' in sd else 0)
@@ -116,6 +116,19 @@ def test_active_tile_list_of_a_clustered_label_graph():
     assert tl[1].tolist() == [4, 0, 1, 2, 3]
     assert tl[2].tolist() == [3, 1, 2, 3, 0]
     assert tl[3].tolist() == [3, 1, 2, 3, 0]
+
+
+def test_pack_mask_bits_layout():
+    g = torch.Generator().manual_seed(0)
+    blocked = (torch.rand(70, 100, generator=g) < 0.5).to(torch.uint8)
+    blocked[3, 31] = 1
+    blocked[3, 63] = 1
+    bits = N.pack_mask_bits(blocked)
+    assert bits.shape == (70, 4) and bits.dtype == torch.int32
+    w = bits.to(torch.int64) & 0xFFFFFFFF
+    for q, k in ((0, 0), (3, 31), (3, 63), (69, 99), (10, 64), (5, 33)):
+        assert ((w[q, k >> 5] >> (k & 31)) & 1).item() == blocked[q, k].item()
+    assert (w[:, 3] >> 4).max().item() == 0        # bits past lk = 100 (word 3 holds keys 96..99) are zero
 
 
 def test_product_has_no_cpu_path():
