@@ -1,0 +1,26 @@
+#!/bin/bash
+# Regenerates the evidence under profiles/ on a GPU box (run from the repo root through gpurun):
+#     gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
+# Writes into gpurun_out/<tag>/ ; copy what should be judged into profiles/ afterwards.
+set -u
+TAG=${1:-rXX}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+for wl in bibtex delicious; do
+  python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/bench_$wl.json" 2>/dev/null
+done
+python bench.py --workload synthetic4096 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_synthetic4096.json" 2>/dev/null
+python tools/bench_kernels.py gemm 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles.txt"
+python tools/bench_kernels.py attn 2>&1 | grep -v amdgpu.ids > "$OUT/attn_variants.txt"
+python tools/bench_kernels.py sparse 2>&1 | grep -v amdgpu.ids > "$OUT/sparse_label_attention.txt"
+BENCH="python $PWD/bench.py --no-cpu-baseline --no-pipelined"
+( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o p -f csv -- $BENCH --steps 100 --warmup 10 > "$OUT/bench_under_rocprof.json" 2>/dev/null )
+# PMC passes are separate runs, each with --kernel-trace only (never combined with other trace domains)
+( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
+      -d "$OUT/pmc_sq" -o p -f csv -- $BENCH --steps 5 --warmup 3 > /dev/null 2>&1 )
+for c in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o p -f csv -- $BENCH --steps 5 --warmup 3 > /dev/null 2>&1 )
+done
+ls -R "$OUT" | head -40

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 output of tools/collect_profiles.sh into the small text tables kept under profiles/.
+
+    python tools/summarize_profiles.py gpurun_out/<tag> profiles r01
+"""
+import collections
+import csv
+import os
+import shutil
+import sys
+
+
+def last_forward(rows_by_dispatch):
+    ids = list(rows_by_dispatch)
+    diag = [i for i, k in enumerate(ids) if 'diag_kernel' in rows_by_dispatch[k]['name']]
+    return ids[diag[-2] + 1:diag[-1] + 1]
+
+
+def load_pmc(d):
+    disp = collections.OrderedDict()
+    for r in csv.DictReader(open(os.path.join(d, 'p_counter_collection.csv'))):
+        e = disp.setdefault(r['Dispatch_Id'], {'name': r['Kernel_Name'], 'grid': int(r['Grid_Size']),
+                                               'wg': int(r['Workgroup_Size'])})
+        e[r['Counter_Name']] = float(r['Counter_Value'])
+    dur = {r['Dispatch_Id']: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1000.0
+           for r in csv.DictReader(open(os.path.join(d, 'p_kernel_trace.csv')))}
+    return disp, dur
+
+
+def short(name):
+    return name.split('(')[0].replace('void lamp::', '').replace('lamp::', '')[:46]
+
+
+def main():
+    src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    cp = lambda a, b: shutil.copy(os.path.join(src, a), os.path.join(dst, '%s_%s' % (tag, b)))
+    cp('bench.json', 'bench.json')
+    cp('bench_under_rocprof.json', 'bench_under_rocprof.json')
+    for wl in ('bibtex', 'delicious', 'synthetic4096'):
+        cp('bench_%s.json' % wl, 'bench_%s.json' % wl)
+    cp('gemm_tiles.txt', 'gemm_tiles.txt')
+    cp('attn_variants.txt', 'attn_variants.txt')
+    cp('sparse_label_attention.txt', 'sparse_label_attention.txt')
+    cp('stats/p_kernel_stats.csv', 'bench_kernel_stats.csv')
+
+    disp, dur = load_pmc(os.path.join(src, 'pmc_sq'))
+    L = ['# One forward (reuters, batch 32) under rocprofv3 --pmc (SQ counters; kernels run serialized and ~4 % slower under the profiler).',
+         '# clock_GHz  = SQ_BUSY_CYCLES / 32 shader engines / duration   (the sustained clock under this load, not the 2.4 GHz spec)',
+         '# mfma_busy  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock)  -- fraction of the matrix pipes\' cycles spent in MFMAs',
+         '#              (the busy-cycle count equals 64 cycles x the algorithmic number of 32x32x2 MFMAs exactly: no wasted matrix work)',
+         '# wait_any   = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves parked on s_waitcnt / barriers);  wait_mfma = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (issue stalls, mostly the busy matrix pipe)',
+         '%-46s %8s %8s %9s %9s %9s %9s' % ('kernel', 'WGs', 'us', 'clock_GHz', 'mfma_busy', 'wait_any', 'wait_mfma')]
+    for k in last_forward(disp):
+        d, us = disp[k], dur[k]
+        clk = d['SQ_BUSY_CYCLES'] / 32 / us / 1000
+        mf = d['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * us * 1000 * clk) if clk > 0 else 0
+        wc = d['SQ_WAVE_CYCLES'] or 1
+        L.append('%-46s %8d %8.1f %9.2f %9.2f %9.2f %9.2f' % (short(d['name']), d['grid'] // d['wg'], us, clk, mf,
+                                                             d['SQ_WAIT_ANY'] / wc, d['SQ_WAIT_INST_ANY'] / wc))
+    open(os.path.join(dst, '%s_mfma_busy.txt' % tag), 'w').write('\n'.join(L) + '\n')
+
+    res = {}
+    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+        disp, _ = load_pmc(os.path.join(src, 'pmc_' + c))
+        res[c] = [(disp[k]['name'], disp[k]['grid'], disp[k].get(c, 0.0)) for k in last_forward(disp)]
+    L = ['# HBM-side traffic of ONE forward (reuters, batch 32), rocprofv3 PMC, separate passes for FETCH_SIZE and WRITE_SIZE.',
+         '# The counters are in KiB; per the MI355X guide FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950,',
+         '# so "fetch MB(x2)" doubles it.',
+         '%-46s %10s %12s %12s' % ('kernel', 'grid', 'fetch MB(x2)', 'write MB')]
+    tf = tw = 0.0
+    for (n, g, f), (_, _, w) in zip(res['FETCH_SIZE'], res['WRITE_SIZE']):
+        fm, wm = f * 1024 * 2 / 1e6, w * 1024 / 1e6
+        tf, tw = tf + fm, tw + wm
+        L.append('%-46s %10d %12.2f %12.2f' % (short(n), g, fm, wm))
+    L.append('%-46s %10s %12.2f %12.2f' % ('TOTAL per forward', '', tf, tw))
+    open(os.path.join(dst, '%s_hbm_traffic.txt' % tag), 'w').write('\n'.join(L) + '\n')
+    print('wrote', sorted(f for f in os.listdir(dst) if f.startswith(tag)))
+
+
+if __name__ == '__main__':
+    main()
