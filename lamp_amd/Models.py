@@ -176,8 +176,6 @@ class LAMP(nn.Module):
         # enough for the whole batch in one pass unless that exceeds the cap (then it micro-batches)
         whole = fixed + (per_sample - fixed) * B + 4096
         budget = max(per_sample + 4096, min(whole, self.workspace_limit_bytes))
-        if want_attn:  # attention maps need the whole batch in one micro-batch
-            budget = whole
         ws = N.workspace(budget, dev)
         N.check(lib.lamp_forward(C.byref(model), seq.data_ptr(), pos.data_ptr(), B, T, logits.data_ptr(),
                                  enc_output.data_ptr(), C.byref(aux) if aux is not None else None,

@@ -112,7 +112,7 @@ struct MhaScratch {
 static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, int lq, int lk, int d, int dk,
                     int dv, const lamp_mha_weights& w, const lamp_mask* mask, float* out, float* attn,
                     const MhaScratch& sc, hipStream_t s, bool kv_ready = false,
-                    const float* q_ready = nullptr) {
+                    const float* q_ready = nullptr, int P_batch = 0, int P_b0 = 0) {
     const int h = w.n_head;
     if (h < 1 || dk < 1 || dv < 1) return LAMP_E_DIMS;
     if (!w.w_qs || !w.w_ks || !w.w_vs || (out && (!w.ln_g || !w.ln_b))) return LAMP_E_NULL;
@@ -155,6 +155,7 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     AttnParams a{};
     a.Q = q_ready ? q_ready : sc.Q; a.K = sc.K; a.V = need_v ? sc.V : nullptr; a.O = need_v ? sc.A : nullptr; a.P = attn;
     a.B = B; a.H = h; a.lq = lq; a.lk = lk; a.dk = dk; a.dv = dv;
+    a.P_batch = P_batch > 0 ? P_batch : B; a.P_b0 = P_b0;
     a.lay.q_b = xq_shared ? 0 : int64_t(lq) * hdk; a.lay.q_h = dk; a.lay.q_r = hdk;
     a.lay.k_b = int64_t(lk) * hdk; a.lay.k_h = dk; a.lay.k_r = hdk;
     a.lay.v_b = int64_t(lk) * hdv; a.lay.v_h = dv; a.lay.v_r = hdv;
@@ -273,6 +274,7 @@ int lamp_sdpa_fwd(const float* q, const float* k, const float* v, float* out, fl
     AttnParams a{};
     a.Q = q; a.K = k; a.V = v; a.O = out; a.P = attn;
     a.B = B; a.H = H; a.lq = lq; a.lk = lk; a.dk = d_k; a.dv = d_v;
+    a.P_batch = B; a.P_b0 = 0;
     a.lay = *layout;
     a.scale_log2e = float(double(inv_temperature) * 1.4426950408889634);
     a.mask_kind = mask ? mask->kind : LAMP_MASK_NONE;
@@ -478,10 +480,9 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
                 const lamp_enc_layer& l = m->enc_layers[i];
                 if (want_enc_attn && aux->enc_self_attn[i]) {
                     // lamp/Layers.py:16 -- only the attention map of this block is ever observable.  Maps are
-                    // (h*B, T, T) over the WHOLE batch, so they need the batch in one micro-batch.
-                    if (nb != B) return LAMP_E_UNSUPPORTED;
+                    // (h*B, T, T) over the WHOLE batch: this micro-batch fills rows h*B + b0 + b.
                     LAMP_CK(mha_core(x, false, x, nb, T, T, d, dk, dv, l.slf_attn, &pad_mask, nullptr,
-                                     aux->enc_self_attn[i], sc, s));
+                                     aux->enc_self_attn[i], sc, s, false, nullptr, B, int(b0)));
                 }
                 LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s));  // lamp/Layers.py:18
             }
@@ -519,7 +520,6 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
                 const lamp_dec_layer& l = m->dec_layers[i];
                 float* Penc = (aux && aux->dec_enc_attn) ? aux->dec_enc_attn[i] : nullptr;
                 float* Pslf = (aux && aux->dec_self_attn) ? aux->dec_self_attn[i] : nullptr;
-                if ((Penc || Pslf) && nr != B) return LAMP_E_UNSUPPORTED;
                 MhaScratch sci = scr;
                 const bool ahead = n_ahead > 0;
                 if (ahead) {
@@ -529,14 +529,16 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
                 // input->label messages (lamp/Layers.py:35); layer 0's query is the label table itself
                 if (i == 0)
                     LAMP_CK(mha_core(m->tgt_word_emb, true, xr, nr, L, T, d, dk, dv, l.enc_attn, &pad_mask, Yr, Penc,
-                                     sci, st, ahead, m->dec0_query));
+                                     sci, st, ahead, m->dec0_query, B, int(b0) + r_lo));
                 else
-                    LAMP_CK(mha_core(Yr, false, xr, nr, L, T, d, dk, dv, l.enc_attn, &pad_mask, Yr, Penc, sci, st, ahead));
+                    LAMP_CK(mha_core(Yr, false, xr, nr, L, T, d, dk, dv, l.enc_attn, &pad_mask, Yr, Penc, sci, st, ahead, nullptr, B,
+                                     int(b0) + r_lo));
                 LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn1, Yr, Hr, st));  // lamp/Layers.py:36
                 if (l.slf_attn.present) {
                     LAMP_CK(int_pred());  // dec_output_int, lamp/Decoders.py:149-151
                     // label->label messages over the label graph (lamp/Layers.py:40)
-                    LAMP_CK(mha_core(Yr, false, Yr, nr, L, L, d, dk, dv, l.slf_attn, &label_mask, Yr, Pslf, scr, st));
+                    LAMP_CK(mha_core(Yr, false, Yr, nr, L, L, d, dk, dv, l.slf_attn, &label_mask, Yr, Pslf, scr, st, false, nullptr,
+                                     B, int(b0) + r_lo));
                 }
                 LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn2, Yr, Hr, st));  // lamp/Layers.py:45
                 if (i + 1 < m->n_layers_dec) LAMP_CK(int_pred());        // all but the last (lamp/Models.py:130)
@@ -545,8 +547,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             return launch_diag(Yr, m->w_out, nr, L, d, logits + (b0 + r_lo) * L, st);
         };
 
-        const bool maps = aux && (aux->dec_enc_attn || aux->dec_self_attn);
-        if (n_ahead > 0 && nb >= 2 && !maps) {
+        if (n_ahead > 0 && nb >= 2) {
             for (int i = 0; i < n_ahead; ++i)
                 LAMP_CK(project_kv(x, Me, d, dk, dv, m->dec_layers[i].enc_attn, Kahead[i], Vahead[i], s));
             hipError_t e;

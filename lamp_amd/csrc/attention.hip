@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             // pass 2: normalised probabilities out, O = P V
             const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
             const float inv_l = 1.0f / l_run;
-            float* Prow = p.P + (int64_t(h) * p.B + b) * int64_t(p.lq) * p.lk + int64_t(qc) * p.lk;
+            float* Prow = p.P + (int64_t(h) * p.P_batch + p.P_b0 + b) * int64_t(p.lq) * p.lk + int64_t(qc) * p.lk;
             for (int kt = 0; kt < nt; ++kt) {
                 load_k(kt);
                 load_mask(kt);

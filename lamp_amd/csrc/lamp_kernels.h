@@ -39,6 +39,7 @@ struct AttnParams {
     float* P;  // nullable: (H*B, lq, lk) probabilities, index h*B + b.  With P given, V and O may
                // both be NULL: probabilities only (the reference's dead encoder self-attention).
     int B, H, lq, lk, dk, dv;
+    int P_batch, P_b0;  // P is indexed (h * P_batch + P_b0 + b): the maps of a micro-batch inside a larger batch
     lamp_attn_layout lay;
     float scale_log2e;  // inv_temperature * log2(e)
     int mask_kind;

@@ -324,6 +324,27 @@ def test_two_stream_forward_is_bit_identical(dev):
         N.set_forward_streams(1)
 
 
+def test_attention_maps_survive_micro_batching_and_two_streams(dev):
+    """return_attns=True with the batch split into micro-batches (tiny workspace) and with the two-stream
+    decoder: every (h*B, lq, lk) map must equal the single-pass one."""
+    from lamp_amd import _native as N
+    m, sd, blocked, seq, spos, h = make_case(CONFIGS['inveye_8h'], dev)
+    src = (seq.to(dev), spos.to(dev))
+    lg, enc, enc_attns, dec2 = m(src, None, None, None, return_attns=True)
+    flat = [a for a in enc_attns[0]] + [a for a in dec2[0]] + [a for a in dec2[1]]
+    try:
+        for streams, limit in ((1, 3 << 20), (2, 8 << 30), (2, 6 << 20)):
+            N.set_forward_streams(streams)
+            m.workspace_limit_bytes = limit
+            lg2, enc2, ea2, d2 = m(src, None, None, None, return_attns=True)
+            flat2 = [a for a in ea2[0]] + [a for a in d2[0]] + [a for a in d2[1]]
+            assert torch.equal(lg2, lg) and torch.equal(enc2, enc)
+            for a, b in zip(flat, flat2):
+                assert max_abs_diff(a, b) == 0.0
+    finally:
+        N.set_forward_streams(1)
+
+
 def test_layer0_query_cache_tracks_weight_updates(dev):
     """The hoisted label-table x W_q projection is bit-identical to projecting per call, and is refreshed
     when either operand is modified in place (load_state_dict / optimiser step keep data_ptr)."""
