@@ -205,7 +205,8 @@ static int project_kv(const float* xkv, int64_t Mk, int d, int dk, int dv, const
 
 // PositionwiseFeedForward.forward (lamp/SubLayers.py:133-142); out may alias x.
 static int ffn_core(const float* x, int64_t M, int d, int dff, const lamp_ffn_weights& w, float* out,
-                    float* hidden, hipStream_t s) {
+                    float* hidden, hipStream_t s, const float* w_out = nullptr, int n_labels = 0,
+                    float* logits = nullptr) {
     if (!w.w1 || !w.b1 || !w.w2 || !w.b2 || !w.ln_g || !w.ln_b) return LAMP_E_NULL;
     {
         const float* W[1] = {w.w1};
@@ -219,7 +220,9 @@ static int ffn_core(const float* x, int64_t M, int d, int dff, const lamp_ffn_we
         float* C[1] = {out};
         LAMP_CK(linear(hidden, M, dff, dff, W, 1, d, dff, b, x, d, 0, C, d, s));
     }
-    return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, out, s);
+    // with w_out: the final decoder LayerNorm also produces the logits and its output row is not stored
+    return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, w_out ? nullptr : out, s, w_out, n_labels,
+                            logits);
 }
 
 static size_t mha_ws_floats(int64_t B, int64_t lq, int64_t lk, int hdk, int hdv) {
@@ -540,11 +543,15 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
                     LAMP_CK(mha_core(Yr, false, Yr, nr, L, L, d, dk, dv, l.slf_attn, &label_mask, Yr, Pslf, scr, st, false, nullptr,
                                      B, int(b0) + r_lo));
                 }
-                LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn2, Yr, Hr, st));  // lamp/Layers.py:45
-                if (i + 1 < m->n_layers_dec) LAMP_CK(int_pred());        // all but the last (lamp/Models.py:130)
+                if (i + 1 < m->n_layers_dec) {
+                    LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn2, Yr, Hr, st));  // lamp/Layers.py:45
+                    LAMP_CK(int_pred());                                         // all but the last (lamp/Models.py:130)
+                } else {
+                    // last layer: the read-out (lamp/Models.py:124-126) is fused into this LayerNorm
+                    LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn2, Yr, Hr, st, m->w_out, L, logits + (b0 + r_lo) * L));
+                }
             }
-            // read-out (lamp/Models.py:124-126)
-            return launch_diag(Yr, m->w_out, nr, L, d, logits + (b0 + r_lo) * L, st);
+            return 0;
         };
 
         if (n_ahead > 0 && nb >= 2) {

@@ -53,7 +53,8 @@ int launch_gemm(const GemmParams& p, hipStream_t s);
 int launch_attn(const AttnParams& p, hipStream_t s);
 // y = LayerNorm(x + residual[row % r_mod or row])   (residual nullable; r_mod 0 = per-row residual)
 int launch_layernorm(const float* x, int64_t M, int d, const float* g, const float* b, float eps,
-                     const float* residual, int64_t r_mod, float* y, hipStream_t s);
+                     const float* residual, int64_t r_mod, float* y, hipStream_t s, const float* w_out = nullptr,
+                     int n_labels = 0, float* logits = nullptr);  // w_out: fused read-out, y may then be NULL
 int launch_embed(const int64_t* seq, const int64_t* pos, int64_t n_tok, const float* emb, int n_vocab,
                  const float* pos_table, int n_position, int d, float* out, hipStream_t s);
 int launch_diag(const float* y, const float* w, int B, int L, int d, float* logits, hipStream_t s);

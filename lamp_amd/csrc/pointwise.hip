@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ bta, float eps,
                                                         const float* __restrict__ res, int64_t r_mod,
-                                                        float* __restrict__ y) {
+                                                        float* __restrict__ y,
+                                                        const float* __restrict__ w_out, int n_labels,
+                                                        float* __restrict__ logits) {
     const int lane = threadIdx.x & 63;
     const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -74,17 +76,29 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(ss) / float(d) + eps);
-    float4* yr = reinterpret_cast<float4*>(y + row * d);
+    float4* yr = y ? reinterpret_cast<float4*>(y + row * d) : nullptr;
     const float4* g4 = reinterpret_cast<const float4*>(g);
     const float4* b4 = reinterpret_cast<const float4*>(bta);
+    // optional fused label read-out (lamp/Models.py:124-126): logits[row] = <LN(row), w_out[row % L]>
+    const float4* w4 = w_out ? reinterpret_cast<const float4*>(w_out + (row % n_labels) * d) : nullptr;
+    float dot = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             const float4 gg = g4[c], bb = b4[c];
-            yr[c] = make_float4((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
-                                (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
+            const float4 o = make_float4((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
+                                         (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
+            if (yr) yr[c] = o;
+            if (w4) {
+                const float4 ww = w4[c];
+                dot += (o.x * ww.x + o.y * ww.y) + (o.z * ww.z + o.w * ww.w);
+            }
         }
+    }
+    if (w4) {
+        dot = wave_sum(dot);
+        if (lane == 0) logits[row] = dot;
     }
 }
 
@@ -151,26 +165,27 @@ int launch_embed(const int64_t* seq, const int64_t* pos, int64_t n_tok, const fl
 }
 
 int launch_layernorm(const float* x, int64_t M, int d, const float* g, const float* b, float eps,
-                     const float* residual, int64_t r_mod, float* y, hipStream_t s) {
+                     const float* residual, int64_t r_mod, float* y, hipStream_t s, const float* w_out, int n_labels,
+                     float* logits) {
     if (M <= 0 || d <= 0) return LAMP_E_DIMS;
     if ((d & 3) || d > 4096) return LAMP_E_UNSUPPORTED;
-    if (!x || !g || !b || !y) return LAMP_E_NULL;
-    if (!aligned16(x) || !aligned16(y) || !aligned16(g) || !aligned16(b) || (residual && !aligned16(residual)))
+    if (!x || !g || !b || (!y && !w_out) || (w_out && (!logits || n_labels <= 0))) return LAMP_E_NULL;
+    if (!aligned16(x) || (y && !aligned16(y)) || (w_out && !aligned16(w_out)) || !aligned16(g) || !aligned16(b) || (residual && !aligned16(residual)))
         return LAMP_E_ALIGN;
     unsigned grid;
     if (int e = grid4(M, &grid)) return e;
     ProfScope prof(LAMP_K_LAYERNORM, 0.0, 8.0 * double(M) * d, s);
     const int nv = (d / 4 + 63) / 64;
     if (nv <= 1)
-        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y);
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y, w_out, n_labels, logits);
     else if (nv <= 2)
-        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y);
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y, w_out, n_labels, logits);
     else if (nv <= 4)
-        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y);
+        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y, w_out, n_labels, logits);
     else if (nv <= 8)
-        hipLaunchKernelGGL(layernorm_kernel<8>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y);
+        hipLaunchKernelGGL(layernorm_kernel<8>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y, w_out, n_labels, logits);
     else
-        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y);
+        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y, w_out, n_labels, logits);
     return int(hipGetLastError());
 }
 
