@@ -98,3 +98,39 @@ def test_sigmoid_bce_kernel_vs_torch():
     ref_loss = torch.nn.functional.binary_cross_entropy_with_logits(x.double(), z.double(), reduction='none').sum(1)
     assert max_abs_diff(probs, torch.sigmoid(x.double())) < 1e-6
     assert max_abs_diff(row_loss, ref_loss) < 1e-3 * 1e-1
+
+
+def test_multilabel_metrics_known_values():
+    from lamp_amd.run_eval import multilabel_metrics
+    pred = torch.tensor([[0.9, 0.1, 0.8], [0.2, 0.7, 0.6], [float('nan')] * 3])
+    tgt = torch.tensor([[1., 0., 1.], [0., 1., 0.], [1., 0., 0.]])
+    m = multilabel_metrics(pred, tgt, 0.5)
+    assert abs(m['subset_accuracy'] - 1 / 3) < 1e-6
+    assert abs(m['hamming_accuracy'] - 7 / 9) < 1e-6
+    assert abs(m['micro_f1'] - 2 * 3 / (2 * 3 + 1 + 1)) < 1e-6
+    assert abs(m['example_f1'] - (1.0 + 2 / 3 + 0.0) / 3) < 1e-6
+
+
+@pytest.mark.gpu
+def test_run_eval_end_to_end(fx, tmp_path):
+    """The main.py -test_only flow on the MI355X path: reference-format .pt dataset + reference-format checkpoint
+    in, the reference's own test_epoch numbers out (BCE from the golden harness fixture)."""
+    import argparse
+    from lamp_amd import run_eval
+    d, sd, splits = fx
+    src = {('w%d' % i): i for i in range(d['n_src_dict'])}
+    tgt = {('l%d' % i): i for i in range(d['n_tgt_dict'])}
+    data = {'settings': argparse.Namespace(max_seq_len=d['max_seq_len']), 'dict': {'src': src, 'tgt': tgt}, **splits}
+    torch.save(data, tmp_path / 'train_valid_test.pt')
+    torch.save({'model': sd, 'epoch': 3}, tmp_path / 'model.chkpt')
+    dm = sd['decoder.tgt_word_emb.weight'].size(1)
+    for streams in (1, 2):
+        out = run_eval.main(['-data', str(tmp_path / 'train_valid_test.pt'), '-checkpoint', str(tmp_path / 'model.chkpt'),
+                             '-d_model', str(dm), '-d_inner_hid', str(2 * dm), '-n_layers_enc', '2', '-n_head',
+                             str(d['n_head']), '-label_mask', 'prior', '-batch_size', str(d['batch_size']),
+                             '-streams', str(streams)])
+        assert out['n_samples'] == len(splits['test']['src']) and out['n_batches'] == d['n_batches']
+        assert abs(out['bce_total'] - d['bce_total']) < 2e-5 * d['n_batches']
+        ref = run_eval.multilabel_metrics(d['predictions'], d['targets'], 0.5)
+        for k, v in ref.items():
+            assert abs(out[k] - v) < 1e-6, k
