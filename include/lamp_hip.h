@@ -222,6 +222,16 @@ int lamp_diag_logits_fwd(const float* y, const float* w_out, int32_t B, int32_t 
 int lamp_sigmoid_bce_fwd(const float* logits, const float* targets, int64_t n_rows, int32_t L,
                          float* probs, float* row_loss, lamp_stream_t stream);
 
+/* Prior label graph, the input of label_mask='prior' (utils/data_loader.py:37-47), built on the device from
+ * the train split's label sets in CSR form: label_ids[offsets[s] .. offsets[s+1]) are the 0-based label
+ * indices of sample s (target-vocabulary ids minus the 4 special tokens, BOS/EOS stripped).
+ *   adj     [L, L] float: 1 where i == j or labels i and j share a sample, else 0  (the reference's matrix)
+ *   blocked [L, L] u8, nullable: the decoder self-attention mask derived from it (lamp/Decoders.py:105-113;
+ *           no row of adj is empty because of the diagonal), 1 = blocked = (adj == 0).
+ * Ids outside [0, L) are skipped (the reference would index out of range); validate on the host. */
+int lamp_prior_graph_build(const int64_t* label_ids, const int64_t* offsets, int64_t n_samples, int32_t L,
+                           float* adj, uint8_t* blocked, lamp_stream_t stream);
+
 /* ---- the whole hot path ------------------------------------------------------------------- */
 
 /* Bytes of workspace lamp_forward needs to process `micro_batch` samples of padded length T at a

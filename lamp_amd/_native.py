@@ -89,6 +89,7 @@ PROTOTYPES = {
     'lamp_ffn_fwd': (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(FfnWeights), _vp, _vp, _sz, _vp]),
     'lamp_embed_fwd': (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     'lamp_diag_logits_fwd': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'lamp_prior_graph_build': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     'lamp_sigmoid_bce_fwd': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     'lamp_forward_workspace_bytes': (_sz, [C.POINTER(Model), _i32, _i32, _i32]),
     'lamp_forward': (C.c_int, [C.POINTER(Model), _vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(Aux), _vp, _sz, _vp]),
@@ -332,6 +333,29 @@ def diag_logits(y, w_out):
     check(lib().lamp_diag_logits_fwd(ptr(y), ptr(f32c(w_out)), B, L, d, ptr(out), stream()),
           'lamp_diag_logits_fwd')
     return out
+
+
+def prior_graph(label_ids, offsets, n_labels, want_blocked=False):
+    """Co-occurrence label graph on the device (utils/data_loader.py:37-47).  label_ids int64 (nnz,) 0-based,
+    offsets int64 (n_samples + 1,), both on the HIP device -> adj float (L, L) [, blocked uint8 (L, L)]."""
+    require_device(label_ids, offsets)
+    if label_ids.dtype != torch.int64 or offsets.dtype != torch.int64:
+        raise TypeError('label_ids and offsets must be int64')
+    ids, off = label_ids.contiguous(), offsets.contiguous()
+    n_samples = off.numel() - 1
+    if n_samples < 0:
+        raise ValueError('offsets needs n_samples + 1 entries')
+    if ids.numel():
+        lo, hi = int(ids.min()), int(ids.max())
+        if lo < 0 or hi >= n_labels:
+            raise IndexError('label index %d outside [0, %d)' % (lo if lo < 0 else hi, n_labels))
+        if int(off[-1]) != ids.numel() or int(off[0]) != 0 or bool((off[1:] < off[:-1]).any()):
+            raise ValueError('offsets must rise from 0 to len(label_ids)')
+    adj = torch.empty((n_labels, n_labels), dtype=torch.float32, device=ids.device)
+    blocked = torch.empty((n_labels, n_labels), dtype=torch.uint8, device=ids.device) if want_blocked else None
+    check(lib().lamp_prior_graph_build(ptr(ids), ptr(off), n_samples, n_labels, ptr(adj), ptr(blocked), stream()),
+          'lamp_prior_graph_build')
+    return (adj, blocked) if want_blocked else adj
 
 
 def sigmoid_bce(logits, targets=None):

@@ -341,6 +341,11 @@ int lamp_diag_logits_fwd(const float* y, const float* w_out, int32_t B, int32_t 
     return launch_diag(y, w_out, B, L, d_model, logits, hipStream_t(stream));
 }
 
+int lamp_prior_graph_build(const int64_t* label_ids, const int64_t* offsets, int64_t n_samples, int32_t L, float* adj,
+                           uint8_t* blocked, lamp_stream_t stream) {
+    return launch_prior_graph(label_ids, offsets, n_samples, L, adj, blocked, hipStream_t(stream));
+}
+
 int lamp_sigmoid_bce_fwd(const float* logits, const float* targets, int64_t n_rows, int32_t L, float* probs,
                          float* row_loss, lamp_stream_t stream) {
     return launch_sigmoid_bce(logits, targets, n_rows, L, probs, row_loss, hipStream_t(stream));

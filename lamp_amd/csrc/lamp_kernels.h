@@ -58,6 +58,8 @@ int launch_layernorm(const float* x, int64_t M, int d, const float* g, const flo
 int launch_embed(const int64_t* seq, const int64_t* pos, int64_t n_tok, const float* emb, int n_vocab,
                  const float* pos_table, int n_position, int d, float* out, hipStream_t s);
 int launch_diag(const float* y, const float* w, int B, int L, int d, float* logits, hipStream_t s);
+int launch_prior_graph(const int64_t* ids, const int64_t* offsets, int64_t n_samples, int L, float* adj,
+                       uint8_t* blocked, hipStream_t s);
 int launch_sigmoid_bce(const float* logits, const float* targets, int64_t n_rows, int L, float* probs,
                        float* row_loss, hipStream_t s);
 

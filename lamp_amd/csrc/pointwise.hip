@@ -143,6 +143,35 @@ __global__ __launch_bounds__(256) void sigmoid_bce_kernel(const float* __restric
     }
 }
 
+// Prior label graph (utils/data_loader.py:37-47).  Pass 1: adj = I, blocked = 1 - I.  Pass 2: one workgroup per
+// training sample walks its n^2 ordered label pairs and marks both directions; every writer stores the same
+// value, so the races are benign and the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void prior_graph_init_kernel(int L, float* __restrict__ adj,
+                                                               uint8_t* __restrict__ blocked) {
+    const int64_t n = int64_t(L) * L;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+        const bool diag = (i / L) == (i % L);
+        adj[i] = diag ? 1.f : 0.f;
+        if (blocked) blocked[i] = diag ? 0 : 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void prior_graph_pairs_kernel(const int64_t* __restrict__ ids,
+                                                                const int64_t* __restrict__ offsets,
+                                                                int64_t n_samples, int L, float* __restrict__ adj,
+                                                                uint8_t* __restrict__ blocked) {
+    for (int64_t s = blockIdx.x; s < n_samples; s += gridDim.x) {
+        const int64_t lo = offsets[s];
+        const int64_t n = offsets[s + 1] - lo;
+        for (int64_t p = threadIdx.x; p < n * n; p += 256) {
+            const int64_t a = ids[lo + p / n], b = ids[lo + p % n];
+            if (a == b || uint64_t(a) >= uint64_t(L) || uint64_t(b) >= uint64_t(L)) continue;
+            adj[a * L + b] = 1.f;
+            if (blocked) blocked[a * L + b] = 0;
+        }
+    }
+}
+
 static inline int grid4(int64_t rows, unsigned* g) {
     const int64_t n = (rows + 3) / 4;
     if (n > 0x7fffffffLL) return LAMP_E_DIMS;
@@ -209,6 +238,21 @@ int launch_diag(const float* y, const float* w, int B, int L, int d, float* logi
     if (int e = grid4(rows, &g)) return e;
     ProfScope prof(LAMP_K_DIAG, 2.0 * rows * d, 4.0 * (double(rows) * d + double(L) * d + rows), s);
     hipLaunchKernelGGL(diag_kernel, dim3(g), dim3(256), 0, s, y, w, rows, L, d, logits);
+    return int(hipGetLastError());
+}
+
+int launch_prior_graph(const int64_t* ids, const int64_t* offsets, int64_t n_samples, int L, float* adj,
+                       uint8_t* blocked, hipStream_t s) {
+    if (n_samples < 0 || L <= 0) return LAMP_E_DIMS;
+    if (!adj || (n_samples > 0 && (!ids || !offsets))) return LAMP_E_NULL;
+    const int64_t cells = int64_t(L) * L;
+    const unsigned g0 = unsigned(cells / 256 + 1 < 4096 ? cells / 256 + 1 : 4096);
+    hipLaunchKernelGGL(prior_graph_init_kernel, dim3(g0), dim3(256), 0, s, L, adj, blocked);
+    if (n_samples > 0) {
+        const unsigned g1 = unsigned(n_samples < 65536 ? n_samples : 65536);
+        hipLaunchKernelGGL(prior_graph_pairs_kernel, dim3(g1), dim3(256), 0, s, ids, offsets, n_samples, L, adj,
+                           blocked);
+    }
     return int(hipGetLastError());
 }
 

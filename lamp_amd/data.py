@@ -40,6 +40,23 @@ def prior_adjacency(train_tgt, n_tgt_dict):
     return adj
 
 
+def prior_adjacency_device(train_tgt, n_tgt_dict, device):
+    """Same matrix as prior_adjacency, built by the HIP kernel (lamp_prior_graph_build): the host only flattens
+    the label sets into CSR.  For delicious-sized splits the Python double loop above takes seconds; this does
+    not."""
+    from . import _native as N
+    L = n_tgt_dict - 4
+    lens = np.fromiter((max(len(s) - 2, 0) for s in train_tgt), dtype=np.int64, count=len(train_tgt))
+    offsets = np.zeros(len(train_tgt) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    ids = np.empty(int(offsets[-1]), dtype=np.int64)
+    for s, lo in zip(train_tgt, offsets[:-1]):
+        n = len(s) - 2
+        if n > 0:
+            ids[lo:lo + n] = np.asarray(s[1:-1], dtype=np.int64) - 4
+    return N.prior_graph(torch.from_numpy(ids).to(device), torch.from_numpy(offsets).to(device), L)
+
+
 def pad_to_longest(insts):
     """-> (ids int64 (B, T), positions int64 (B, T)); T = longest instance of the batch, PAD = 0, position
     = 1-based index on non-PAD tokens and 0 on PAD (utils/data_loader.py:261-279)."""

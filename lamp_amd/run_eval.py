@@ -84,7 +84,8 @@ def main(argv=None):
     device = torch.device('cuda', torch.cuda.current_device())
     data = D.load_dataset(opt.data)
     n_src, n_labels = D.vocabulary_sizes(data)
-    adj = D.prior_adjacency(data['train']['tgt'], len(data['dict']['tgt'])) if opt.label_mask == 'prior' else None
+    adj = (D.prior_adjacency_device(data['train']['tgt'], len(data['dict']['tgt']), device).cpu()
+           if opt.label_mask == 'prior' else None)
     d, h = opt.d_model, opt.n_head
     torch.manual_seed(opt.seed)
     model = LAMP(n_src, n_labels, data['settings'].max_seq_len, n_labels, n_layers_enc=opt.n_layers_enc,
