@@ -262,7 +262,7 @@ def main():
                    'launch': 'hip-graph replay' if args.graph else 'eager (one lamp_forward call per step)',
                    'streams_per_forward': args.streams},
         'roofline': {
-            'bound': 'mfma', 'kernel': 'gemm_nt_kernel (fp32 MFMA 32x32x2), all launches of a forward',
+            'bound': 'mfma', 'kernel': 'gemm_nt_kernel (fp32 MFMA 16x16x4), all launches of a forward',
             'achieved': gemm_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': gemm_tflops / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
             'launches_per_step': gemm['launches'] / prof_steps if prof_steps else None,

@@ -26,9 +26,9 @@
 
 namespace lamp {
 
-// MF = edge of the MFMA block a wave tile is built from: 32 (v_mfma_f32_32x32x2_f32, 16 accumulator
-// registers per block) or 16 (v_mfma_f32_16x16x4_f32, 4 registers per block; finer tiles for shapes that
-// would otherwise leave CUs idle -- needs >= 2 independent blocks per wave to cover its 40-cycle latency).
+// MF = edge of the MFMA block a wave tile is built from: 16 (v_mfma_f32_16x16x4_f32, 4 accumulator registers
+// per block; the production tiles -- see launch_gemm) or 32 (v_mfma_f32_32x32x2_f32, 16 registers per block;
+// kept as forced configurations for comparison).  Both issue 64 FLOP/cycle/SIMD.
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF = 32>
 struct GemmTile {
     static constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -303,22 +303,29 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
         case 11: return launch_cfg<64, 64, 16, 2, 2, 16>(p, s);
         case 12: return launch_cfg<64, 64, 32, 2, 2, 16>(p, s);  // waves 32x32 as 2x2 blocks of 16x16
         case 13: return launch_cfg<32, 128, 32, 1, 4, 16>(p, s); // waves 32x32 as 2x2 blocks
+        case 14: return launch_cfg<128, 128, 32, 2, 2, 16>(p, s);  // waves 64x64 as 4x4 blocks of 16x16
+        case 15: return launch_cfg<128, 128, 16, 2, 2, 16>(p, s);
+        case 16: return launch_cfg<128, 64, 32, 2, 2, 16>(p, s);
+        case 17: return launch_cfg<64, 128, 32, 2, 2, 16>(p, s);
+        case 18: return launch_cfg<128, 64, 16, 2, 2, 16>(p, s);
         default: break;
     }
-    // Tile choice, from tools/bench_kernels.py on MI355X (profiles/r01_gemm_tiles.txt).  Large
-    // problems want the 128x128x32 tile (141 TF at 4096^3); the batch-32 shapes of the benchmark are
-    // quantisation bound (a few hundred tiles on 256 CUs), where smaller tiles with BK=16 (more
-    // co-resident workgroups, finer tail) win.
+    // Tile choice, from tools/bench_kernels.py on MI355X (profiles/r01_gemm_tiles.txt).  Every configuration the
+    // heuristic may pick is built on the 16x16x4 MFMA, whose k-accumulation order (16c + {j, 4+j, 8+j, 12+j} for
+    // j = 0..3 in every 16-chunk) does not depend on BM/BN/BK -- so the choice, which depends on M (i.e. on the
+    // batch size), never changes a result bit: samples stay bit-identical across batch sizes and shards.
+    // Why 16x16x4 and not 32x32x2 (same peak rate): the unit of serial work is one wave's accumulator chain over K.
+    // A 32x32 block at K = 512 is an 8.2 us chain; the M = B*L decoder shapes have 1440 of them for 1024 SIMDs, so
+    // some SIMD runs two in sequence (16.4 us) however the blocks are grouped into workgroups -- measured 21.5 us for
+    // every 32x32x2 tile from 32x32 (1 wave) to 128x64.  16x16 blocks are 2 us chains: 5760 / 1024 -> 12.3 us,
+    // measured 17.5 us.  On the large shapes 128x64x16 with 64x32 wave tiles (4x2 blocks) reaches 135-144 TFLOP/s,
+    // also ahead of the best 32x32x2 tile (128x128x32: 128-139).  The 32x32x2 tiles remain as forced configs 1-8.
     auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nseg; };
-    if (tiles(128, 128) >= 1024) return launch_cfg<128, 128, 32, 2, 2>(p, s);
-    if (tiles(128, 64) >= 1024) return launch_cfg<128, 64, 16, 2, 2>(p, s);
-    if (tiles(64, 64) >= 512) return launch_cfg<64, 64, 16, 2, 2>(p, s);
-    // NB: every configuration the heuristic may pick is built on the 32x32x2 MFMA, whose k-accumulation
-    // order (8c+j, 8c+4+j for j = 0..3 in every 8-chunk) does not depend on BM/BN/BK -- so the choice,
-    // which depends on M (i.e. on the batch size), never changes a result bit.  The 16x16x4 variants
-    // (forced configs 9-13) order k differently and gained only ~1 us on the M = 2880 shapes; they stay
-    // out of the heuristic to keep samples bit-identical across batch sizes and shards.
-    return launch_cfg<64, 64, 32, 2, 2>(p, s);
+    const int64_t t64 = tiles(64, 64);
+    if (tiles(128, 64) >= 2048 && p.K >= 512) return launch_cfg<128, 64, 16, 2, 2, 16>(p, s);  // short K: fewer, deeper steps
+    if (t64 >= 2048) return launch_cfg<64, 64, 32, 2, 2, 16>(p, s);
+    if (t64 >= 1200) return launch_cfg<64, 64, 16, 2, 2, 16>(p, s);
+    return launch_cfg<32, 64, 32, 1, 4, 16>(p, s);  // 4 waves of 32x16 (2 blocks each)
 }
 
 }  // namespace lamp

@@ -39,7 +39,7 @@ def test_linear_vs_torch_fp64(dev, M, K, N_):
     assert max_abs_diff(N.linear(x.to(dev), w.to(dev)), ref2) < 2e-5
 
 
-@pytest.mark.parametrize('cfg', list(range(1, 14)))
+@pytest.mark.parametrize('cfg', list(range(1, 19)))
 def test_linear_every_tile_config(dev, cfg):
     """Every GEMM tile configuration (32x32x2 and 16x16x4 MFMA variants) against fp64, on shapes with
     ragged M / N edges and a K that is not a multiple of BK."""

@@ -15,7 +15,8 @@ from lamp_amd import _native as N  # noqa: E402
 
 TILES = {0: 'heuristic', 1: '128x128x32', 2: '64x64x32', 3: '128x64x32', 4: '64x128x32', 5: '128x128x16',
          6: '64x64x16', 7: '128x64x16', 8: '256x128x16(8w)', 9: 'm16:32x64x32',
-         10: 'm16:64x32x32', 11: 'm16:64x64x16', 12: 'm16:64x64x32', 13: 'm16:32x128x32'}
+         10: 'm16:64x32x32', 11: 'm16:64x64x16', 12: 'm16:64x64x32', 13: 'm16:32x128x32',
+         14: 'm16:128x128x32', 15: 'm16:128x128x16', 16: 'm16:128x64x32', 17: 'm16:64x128x32', 18: 'm16:128x64x16'}
 
 
 def time_fn(fn, iters=30, warm=5):
@@ -60,6 +61,45 @@ def gemm():
             row += '%9.1f/%5.1fT' % (us, 2.0 * M * Nn * K / us / 1e6)
         force(0)
         print(row)
+
+
+def gemm_ab(cfgs=None, rounds=7):
+    """A/B timing robust against clock / thermal drift: the configurations are timed round-robin, `rounds` times each,
+    and the median is reported (single back-to-back sweeps differ by 3-4 % between columns for the same config)."""
+    import statistics
+    lib = N.lib()
+    force = lib.lamp_debug_force_gemm_tile
+    force.argtypes = [ctypes.c_int]
+    force.restype = None
+    dev = torch.device('cuda:0')
+    cfgs = cfgs or [0, 1, 6, 9, 11, 12, 13, 15, 18]
+    shapes = [('encFFN 9664x512x512', 9664, 512, 512), ('encKV 9664x1024x512', 9664, 1024, 512),
+              ('encKVx2 9664x2048x512', 9664, 2048, 512), ('dec 2880x512x512', 2880, 512, 512),
+              ('decQKV 2880x1536x512', 2880, 1536, 512), ('bibtex dec 5088x512x512', 5088, 512, 512),
+              ('bibtex ffn 5088x1024x512', 5088, 1024, 512), ('delic ffn1 31456x2048x1024', 31456, 2048, 1024),
+              ('delic ffn2 31456x1024x2048', 31456, 1024, 2048), ('delic enc 6400x2048x1024', 6400, 2048, 1024),
+              ('syn dec 131072x256x256', 131072, 256, 256), ('sq 4096^3', 4096, 4096, 4096)]
+    print('%-28s' % 'shape (median us)' + ''.join('%16s' % TILES[c] for c in cfgs))
+    for name, M, Nn, K in shapes:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(Nn, K, device=dev) / K ** 0.5
+        b = torch.randn(Nn, device=dev)
+        r = torch.randn(M, Nn, device=dev)
+        out = torch.empty(M, Nn, device=dev)
+
+        def fn():
+            N.check(lib.lamp_linear_fwd(x.data_ptr(), M, K, K, w.data_ptr(), Nn, K, b.data_ptr(),
+                                        r.data_ptr(), Nn, 1, out.data_ptr(), Nn, N.stream()), 'linear')
+        samples = {c: [] for c in cfgs}
+        for _ in range(rounds):
+            for c in cfgs:
+                force(c)
+                samples[c].append(time_fn(fn, iters=5 if M * Nn * K > 1e11 else 20, warm=2))
+        force(0)
+        med = {c: statistics.median(samples[c]) for c in cfgs}
+        best = min(med.values())
+        print('%-28s' % name + ''.join('%9.1f/%5.1fT%s' % (med[c], 2.0 * M * Nn * K / med[c] / 1e6,
+                                                           '*' if med[c] <= best * 1.01 else ' ') for c in cfgs))
 
 
 def steady():
@@ -149,4 +189,4 @@ def attn():
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
-    {'gemm': gemm, 'attn': attn, 'steady': steady, 'sparse': sparse}[which]()
+    {'gemm': gemm, 'gemm_ab': gemm_ab, 'attn': attn, 'steady': steady, 'sparse': sparse}[which]()
