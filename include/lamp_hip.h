@@ -232,6 +232,34 @@ int lamp_sigmoid_bce_fwd(const float* logits, const float* targets, int64_t n_ro
 int lamp_prior_graph_build(const int64_t* label_ids, const int64_t* offsets, int64_t n_samples, int32_t L,
                            float* adj, uint8_t* blocked, lamp_stream_t stream);
 
+/* ---- backward-pass building blocks (training through train.py:36-48) ------------------- */
+
+/* General strided, batched GEMM:   C_z[m, n] (+)= alpha * sum_k A_z(m, k) * B_z(n, k),   z = (z0, z1),
+ *   A_z(m, k) = A[z0*a_batch0 + z1*a_batch1 + m*a_row_stride + k*a_col_stride]   (B likewise with n),
+ *   C_z[m, n] = C[z0*c_batch0 + z1*c_batch1 + m*ldc + n].
+ * For each operand one of (row_stride, col_stride) must be 1, which covers every product of the backward pass
+ * without a transpose copy: dX = dY.W, dW = dY^T.X, dP = dO.V^T, dV = P^T.dO, dQ = dS.K, dK = dS^T.Q.
+ * relu_mask (batch 1 only, nullable): result elements whose mask value is not > 0 are zeroed (ReLU backward).
+ * accumulate != 0 adds to C.  Workspace (nullable): lamp_gemm_workspace_bytes() lets deep-K / small-output
+ * products (weight gradients) split K deterministically. */
+typedef struct lamp_gemm_desc {
+    const float* A;
+    const float* B;
+    float* C;
+    int32_t M, N, K;
+    int32_t batch0, batch1;
+    int32_t accumulate;
+    int64_t a_row_stride, a_col_stride, a_batch0, a_batch1;
+    int64_t b_row_stride, b_col_stride, b_batch0, b_batch1;
+    int64_t ldc, c_batch0, c_batch1;
+    const float* relu_mask;
+    int64_t ld_mask;
+    float alpha;
+    int32_t reserved;
+} lamp_gemm_desc;
+size_t lamp_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t batch);
+int lamp_gemm(const lamp_gemm_desc* d, void* workspace, size_t workspace_bytes, lamp_stream_t stream);
+
 /* ---- the whole hot path ------------------------------------------------------------------- */
 
 /* Bytes of workspace lamp_forward needs to process `micro_batch` samples of padded length T at a

@@ -67,6 +67,15 @@ class Model(C.Structure):
                 ('dec0_query', _vp)]
 
 
+class GemmDesc(C.Structure):  # include/lamp_hip.h: lamp_gemm_desc
+    _fields_ = [('A', _vp), ('B', _vp), ('C', _vp), ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+                ('batch0', C.c_int32), ('batch1', C.c_int32), ('accumulate', C.c_int32),
+                ('a_row_stride', C.c_int64), ('a_col_stride', C.c_int64), ('a_batch0', C.c_int64), ('a_batch1', C.c_int64),
+                ('b_row_stride', C.c_int64), ('b_col_stride', C.c_int64), ('b_batch0', C.c_int64), ('b_batch1', C.c_int64),
+                ('ldc', C.c_int64), ('c_batch0', C.c_int64), ('c_batch1', C.c_int64),
+                ('relu_mask', _vp), ('ld_mask', C.c_int64), ('alpha', C.c_float), ('reserved', C.c_int32)]
+
+
 class Aux(C.Structure):
     _fields_ = [('enc_self_attn', C.POINTER(_vp)), ('dec_self_attn', C.POINTER(_vp)),
                 ('dec_enc_attn', C.POINTER(_vp)), ('int_preds', C.POINTER(_vp)),
@@ -89,6 +98,8 @@ PROTOTYPES = {
     'lamp_ffn_fwd': (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(FfnWeights), _vp, _vp, _sz, _vp]),
     'lamp_embed_fwd': (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     'lamp_diag_logits_fwd': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'lamp_gemm_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
+    'lamp_gemm': (C.c_int, [C.POINTER(GemmDesc), _vp, _sz, _vp]),
     'lamp_prior_graph_build': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     'lamp_sigmoid_bce_fwd': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     'lamp_forward_workspace_bytes': (_sz, [C.POINTER(Model), _i32, _i32, _i32]),
@@ -332,6 +343,73 @@ def diag_logits(y, w_out):
     out = torch.empty((B, L), dtype=torch.float32, device=y.device)
     check(lib().lamp_diag_logits_fwd(ptr(y), ptr(f32c(w_out)), B, L, d, ptr(out), stream()),
           'lamp_diag_logits_fwd')
+    return out
+
+
+def _as4(t):
+    """(..., r, c) view -> (b0, b1, r, c) view without copying."""
+    if t.dim() == 2:
+        return t.unsqueeze(0).unsqueeze(0)
+    if t.dim() == 3:
+        return t.unsqueeze(0)
+    if t.dim() == 4:
+        return t
+    raise ValueError('gemm operands must be 2-, 3- or 4-dimensional')
+
+
+def matmul_nt(a, b, out=None, alpha=1.0, accumulate=False, relu_mask=None):
+    """out[..., m, n] (+)= alpha * sum_k a[..., m, k] * b[..., n, k]   (lamp_gemm).
+
+    a and b are fp32 device VIEWS: any strides with a unit stride on one of the last two dims, so transposes
+    (`w.t()`, `p.transpose(-1, -2)`), head-split views of [B, l, h*d] projections etc. are passed as they are.
+    Batch dims (0, 1 or 2 of them) must match or be 1.  out, if given, is a view with unit last stride."""
+    require_device(a, b)
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise TypeError('matmul_nt needs float32 operands')
+    A, Bm = _as4(a), _as4(b)
+    M, K, Nn = A.size(2), A.size(3), Bm.size(2)
+    if Bm.size(3) != K:
+        raise ValueError('contraction sizes differ: %s vs %s' % (tuple(a.shape), tuple(b.shape)))
+    b0, b1 = max(A.size(0), Bm.size(0)), max(A.size(1), Bm.size(1))
+    for X in (A, Bm):
+        if X.size(0) not in (1, b0) or X.size(1) not in (1, b1):
+            raise ValueError('batch dims do not broadcast: %s vs %s' % (tuple(a.shape), tuple(b.shape)))
+
+    def unit(X):  # a size-1 dim may carry any stride
+        rs, cs = X.stride(2), X.stride(3)
+        if X.size(3) == 1 and rs != 1:
+            cs = 1
+        elif X.size(2) == 1 and cs != 1:
+            rs = 1
+        if rs != 1 and cs != 1:
+            X = X.contiguous()
+            rs, cs = X.stride(2), X.stride(3)
+        return X, rs, cs
+    A, ars, acs = unit(A)
+    Bm, brs, bcs = unit(Bm)
+    lead = a.shape[:-2] if a.dim() >= b.dim() else b.shape[:-2]
+    if out is None:
+        out = torch.empty(tuple(lead) + (M, Nn), dtype=torch.float32, device=a.device)
+        if accumulate:
+            raise ValueError('accumulate needs an out tensor')
+    Cm = _as4(out)
+    if Cm.stride(3) != 1 and Cm.size(3) != 1:
+        raise ValueError('out must have unit stride on its last dim')
+    if tuple(Cm.shape) != (b0, b1, M, Nn):
+        raise ValueError('out has shape %s, expected %s' % (tuple(out.shape), (b0, b1, M, Nn)))
+    bs = lambda X, i: 0 if X.size(i) == 1 else X.stride(i)  # noqa: E731
+    d = GemmDesc(ptr(A), ptr(Bm), ptr(Cm), M, Nn, K, b0, b1, int(bool(accumulate)),
+                 ars, acs, bs(A, 0), bs(A, 1), brs, bcs, bs(Bm, 0), bs(Bm, 1),
+                 Cm.stride(2), bs(Cm, 0), bs(Cm, 1), None, 0, float(alpha), 0)
+    keep = None
+    if relu_mask is not None:
+        keep = f32c(relu_mask)
+        if tuple(keep.shape[-2:]) != (M, Nn) or keep.numel() != M * Nn:
+            raise ValueError('relu_mask must be (M, N)')
+        d.relu_mask, d.ld_mask = ptr(keep), Nn
+    nb = lib().lamp_gemm_workspace_bytes(M, Nn, K, b0 * b1)
+    ws = workspace(nb, a.device) if nb else None
+    check(lib().lamp_gemm(C.byref(d), ptr(ws), nb, stream()), 'lamp_gemm')
     return out
 
 

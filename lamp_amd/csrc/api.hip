@@ -341,6 +341,15 @@ int lamp_diag_logits_fwd(const float* y, const float* w_out, int32_t B, int32_t 
     return launch_diag(y, w_out, B, L, d_model, logits, hipStream_t(stream));
 }
 
+size_t lamp_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t batch) {
+    return gemm_gen_workspace_bytes(M, N, K, batch);
+}
+
+int lamp_gemm(const lamp_gemm_desc* d, void* workspace, size_t workspace_bytes, lamp_stream_t stream) {
+    if (!d) return LAMP_E_NULL;
+    return launch_gemm_gen(*d, workspace, workspace_bytes, hipStream_t(stream));
+}
+
 int lamp_prior_graph_build(const int64_t* label_ids, const int64_t* offsets, int64_t n_samples, int32_t L, float* adj,
                            uint8_t* blocked, lamp_stream_t stream) {
     return launch_prior_graph(label_ids, offsets, n_samples, L, adj, blocked, hipStream_t(stream));

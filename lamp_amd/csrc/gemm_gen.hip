@@ -1,0 +1,313 @@
+// General strided / batched fp32 GEMM for the backward pass:
+//
+//     C_z[m, n] (+)= alpha * sum_k A_z(m, k) * B_z(n, k)          z = (z0, z1) batch index
+//
+// where each operand is addressed through element strides, A_z(m, k) = A[z0*a_b0 + z1*a_b1 + m*a_rs + k*a_cs],
+// and ONE of (a_rs, a_cs) is 1: either k is the contiguous index ("row" operand: activations times nn.Linear
+// weights, as in the forward kernel) or m is ("column" operand: the transposed reads that dgrad / wgrad /
+// attention-backward need -- dX = dY.W, dW = dY^T.X, dV = P^T.dO, dQ = dS.K, dK = dS^T.Q -- without any transpose
+// copy).  Column operands are staged k-major in LDS and their MFMA fragments are read as four ds_read_b32 per
+// 16-chunk; row operands use the forward kernel's b128 fragment trick.  Same 16x16x4 MFMA and the same
+// k-accumulation order as the forward tiles.  Split-K (for the deep-K, small-output weight gradients) writes
+// per-split partial tiles to the caller's workspace and a second kernel sums them in split order: deterministic.
+#include "lamp_kernels.h"
+
+namespace lamp {
+
+namespace {
+
+constexpr int GM = 64, GN = 64, GK = 16;  // block tile; 4 waves as 2 x 2, each 32 x 32 = 2 x 2 MFMA blocks
+constexpr int S_ROW = GK + 4;             // LDS row stride of a row operand   [64][20]
+constexpr int S_COL = GM + 4;             // LDS row stride of a column operand [16][68]
+constexpr int LDS_OPERAND = 64 * S_ROW > GK * S_COL ? 64 * S_ROW : GK * S_COL;
+
+struct Operand {
+    const float* p;
+    int64_t rs, cs;  // strides of the (m or n) index and of k
+    int64_t b0, b1;
+};
+
+struct GenParams {
+    Operand A, B;
+    float* C;
+    int64_t ldc, c_b0, c_b1;
+    int M, N, K;
+    int nb1;          // z = z0 * nb1 + z1
+    int vecA, vecB;   // 16-byte loads legal for this operand
+    float alpha;
+    int accumulate;
+    const float* mask;  // relu'(mask > 0) applied to the result, same indexing as C (ld = ldm), or nullptr
+    int64_t ldm;
+    int k_chunk;        // K range per split (multiple of GK); K when not split
+    float* part;        // split-K partials [nsplit][M][N], or nullptr
+};
+
+// One thread stages one float4 of each operand per k-tile.
+template <bool COL>
+__device__ __forceinline__ float4 stage_load(__amdgpu_buffer_rsrc_t rs, int tid, int k0, int k_end, int64_t ld, bool vec) {
+    if constexpr (!COL) {
+        const int row = tid >> 2, k = k0 + 4 * (tid & 3);
+        const unsigned off = unsigned(row * int(ld) + k) * 4u;
+        if (vec) return bload4(rs, k < k_end ? off : OOB, 0);
+        float4 v;
+        v.x = bload1(rs, k + 0 < k_end ? off : OOB);
+        v.y = bload1(rs, k + 1 < k_end ? off + 4u : OOB);
+        v.z = bload1(rs, k + 2 < k_end ? off + 8u : OOB);
+        v.w = bload1(rs, k + 3 < k_end ? off + 12u : OOB);
+        return v;
+    } else {
+        const int krow = k0 + (tid >> 4), c = 4 * (tid & 15);
+        const unsigned off = krow < k_end ? unsigned(krow * int(ld) + c) * 4u : OOB;
+        if (vec) return bload4(rs, off, 0);
+        float4 v;  // columns past the tile edge only feed output rows that are never stored
+        v.x = bload1(rs, off);
+        v.y = bload1(rs, off == OOB ? OOB : off + 4u);
+        v.z = bload1(rs, off == OOB ? OOB : off + 8u);
+        v.w = bload1(rs, off == OOB ? OOB : off + 12u);
+        return v;
+    }
+}
+
+template <bool COL>
+__device__ __forceinline__ void stage_store(float* lds, int tid, float4 v) {
+    if constexpr (!COL)
+        *reinterpret_cast<float4*>(lds + (tid >> 2) * S_ROW + 4 * (tid & 3)) = v;
+    else
+        *reinterpret_cast<float4*>(lds + (tid >> 4) * S_COL + 4 * (tid & 15)) = v;
+}
+
+// Fragment of one 16-row MFMA block: the 4 k-values {4*hi + j} of row `row` (tile-local).
+template <bool COL>
+__device__ __forceinline__ float4 frag(const float* lds, int row, int hi) {
+    if constexpr (!COL) return *reinterpret_cast<const float4*>(lds + row * S_ROW + 4 * hi);
+    float4 v;
+    const float* q = lds + (4 * hi) * S_COL + row;
+    v.x = q[0];
+    v.y = q[S_COL];
+    v.z = q[2 * S_COL];
+    v.w = q[3 * S_COL];
+    return v;
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float As[2][LDS_OPERAND];
+    __shared__ __attribute__((aligned(16))) float Bs[2][LDS_OPERAND];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, hi = lane >> 4;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * GM, n0 = tn * GN;
+    const int rows_m = p.M - m0 < GM ? p.M - m0 : GM;
+    const int rows_n = p.N - n0 < GN ? p.N - n0 : GN;
+    const int z0 = blockIdx.y / p.nb1, z1 = blockIdx.y - z0 * p.nb1;
+    const int split = blockIdx.z;
+    const int k_begin = split * p.k_chunk;
+    const int k_end = k_begin + p.k_chunk < p.K ? k_begin + p.k_chunk : p.K;
+
+    const float* Az = p.A.p + z0 * p.A.b0 + z1 * p.A.b1;
+    const float* Bz = p.B.p + z0 * p.B.b0 + z1 * p.B.b1;
+    const int64_t lda = TA ? p.A.cs : p.A.rs, ldb = TB ? p.B.cs : p.B.rs;
+    // row operand: base at the tile's first row, range = valid rows x K; column operand: base at the tile's first
+    // column, range = k_end rows x valid columns.
+    const __amdgpu_buffer_rsrc_t rsA =
+        TA ? make_rsrc(Az + m0, (uint64_t(k_end - 1) * lda + rows_m) * 4u)
+           : make_rsrc(Az + int64_t(m0) * lda, (uint64_t(rows_m - 1) * lda + p.K) * 4u);
+    const __amdgpu_buffer_rsrc_t rsB =
+        TB ? make_rsrc(Bz + n0, (uint64_t(k_end - 1) * ldb + rows_n) * 4u)
+           : make_rsrc(Bz + int64_t(n0) * ldb, (uint64_t(rows_n - 1) * ldb + p.K) * 4u);
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (k_end - k_begin + GK - 1) / GK;
+    float4 ra = stage_load<TA>(rsA, tid, k_begin, k_end, lda, p.vecA);
+    float4 rb = stage_load<TB>(rsB, tid, k_begin, k_end, ldb, p.vecB);
+    stage_store<TA>(As[0], tid, ra);
+    stage_store<TB>(Bs[0], tid, rb);
+    if (nk > 1) {
+        ra = stage_load<TA>(rsA, tid, k_begin + GK, k_end, lda, p.vecA);
+        rb = stage_load<TB>(rsB, tid, k_begin + GK, k_end, ldb, p.vecB);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        float4 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = frag<TA>(As[buf], wm * 32 + 16 * i + l15, hi);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = frag<TB>(Bs[buf], wn * 32 + 16 * j + l15, hi);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+            }
+        if (kt + 1 < nk) {
+            stage_store<TA>(As[buf ^ 1], tid, ra);
+            stage_store<TB>(Bs[buf ^ 1], tid, rb);
+        }
+        if (kt + 2 < nk) {
+            ra = stage_load<TA>(rsA, tid, k_begin + (kt + 2) * GK, k_end, lda, p.vecA);
+            rb = stage_load<TB>(rsB, tid, k_begin + (kt + 2) * GK, k_end, ldb, p.vecB);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of the 16x16 block: col = lane & 15, row = 4 * (lane >> 4) + r.
+    if (p.part) {  // split-K partial: dense [split][M][N]
+        float* base = p.part + (int64_t(split) * p.M + m0) * p.N + n0;
+        const __amdgpu_buffer_rsrc_t rsP = make_rsrc(base, (uint64_t(rows_m - 1) * p.N + rows_n) * 4u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = wn * 32 + 16 * j + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * 32 + 16 * i + 4 * hi + r;
+                    bstore1(rsP, col < rows_n ? unsigned(row * p.N + col) * 4u : OOB, acc[i][j][r]);
+                }
+            }
+        return;
+    }
+    float* Cz = p.C + z0 * p.c_b0 + z1 * p.c_b1 + int64_t(m0) * p.ldc + n0;
+    const int ldc = int(p.ldc), ldm = int(p.ldm);
+    const __amdgpu_buffer_rsrc_t rsC = make_rsrc(Cz, (uint64_t(rows_m - 1) * ldc + rows_n) * 4u);
+    const bool has_m = p.mask != nullptr;
+    const __amdgpu_buffer_rsrc_t rsM =
+        make_rsrc(has_m ? p.mask + int64_t(m0) * p.ldm + n0 : Cz, has_m ? (uint64_t(rows_m - 1) * ldm + rows_n) * 4u : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wn * 32 + 16 * j + l15;
+            const bool ok = col < rows_n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 32 + 16 * i + 4 * hi + r;
+                float v = p.alpha * acc[i][j][r];
+                if (has_m && !(bload1(rsM, ok ? unsigned(row * ldm + col) * 4u : OOB) > 0.f)) v = 0.f;
+                const unsigned off = ok ? unsigned(row * ldc + col) * 4u : OOB;
+                if (p.accumulate) v += bload1(rsC, off);
+                bstore1(rsC, off, v);
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, int M, int N,
+                                                            float alpha, const float* __restrict__ mask, int64_t ldm,
+                                                            int accumulate, float* __restrict__ C, int64_t ldc) {
+    const int64_t total = int64_t(M) * N;
+    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < total; e += int64_t(gridDim.x) * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[k * total + e];
+        const int64_t m = e / N, n = e - m * N;
+        float v = alpha * s;
+        if (mask && !(mask[m * ldm + n] > 0.f)) v = 0.f;
+        if (accumulate) v += C[m * ldc + n];
+        C[m * ldc + n] = v;
+    }
+}
+
+}  // namespace
+
+size_t gemm_gen_workspace_bytes(int M, int N, int K, int batch) {
+    // room for the deepest split the launcher may choose
+    if (batch != 1) return 0;
+    const int64_t tiles = int64_t((M + GM - 1) / GM) * ((N + GN - 1) / GN);
+    if (tiles >= 512 || K < 1024) return 0;
+    int64_t ns = (1024 + tiles - 1) / tiles;
+    if (ns > K / 256) ns = K / 256;
+    if (ns > 64) ns = 64;
+    return ns < 2 ? 0 : size_t(ns) * M * N * sizeof(float);
+}
+
+int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch0 < 1 || d.batch1 < 1) return LAMP_E_DIMS;
+    if (!d.A || !d.B || !d.C) return LAMP_E_NULL;
+    const bool ta = d.a_row_stride == 1 && d.a_col_stride != 1, tb = d.b_row_stride == 1 && d.b_col_stride != 1;
+    if ((!ta && d.a_col_stride != 1) || (!tb && d.b_col_stride != 1)) return LAMP_E_UNSUPPORTED;
+    const int64_t lda = ta ? d.a_col_stride : d.a_row_stride, ldb = tb ? d.b_col_stride : d.b_row_stride;
+    if (lda < 1 || ldb < 1 || d.ldc < d.N) return LAMP_E_DIMS;
+    // 32-bit in-tile byte offsets
+    const int64_t span_a = ta ? int64_t(d.K) * lda : int64_t(GM) * lda + d.K;
+    const int64_t span_b = tb ? int64_t(d.K) * ldb : int64_t(GN) * ldb + d.K;
+    if (span_a * 4 >= 0x7fffffffLL || span_b * 4 >= 0x7fffffffLL || int64_t(GM) * d.ldc * 4 >= 0x7fffffffLL ||
+        (d.relu_mask && int64_t(GM) * d.ld_mask * 4 >= 0x7fffffffLL))
+        return LAMP_E_UNSUPPORTED;
+    const int64_t batch = int64_t(d.batch0) * d.batch1;
+    if (batch > 65535) return LAMP_E_DIMS;
+    if (d.relu_mask && batch != 1) return LAMP_E_UNSUPPORTED;
+
+    GenParams p;
+    p.A = Operand{d.A, d.a_row_stride, d.a_col_stride, d.a_batch0, d.a_batch1};
+    p.B = Operand{d.B, d.b_row_stride, d.b_col_stride, d.b_batch0, d.b_batch1};
+    p.C = d.C;
+    p.ldc = d.ldc;
+    p.c_b0 = d.c_batch0;
+    p.c_b1 = d.c_batch1;
+    p.M = d.M;
+    p.N = d.N;
+    p.K = d.K;
+    p.nb1 = d.batch1;
+    // 16-byte loads: aligned rows, and no float4 may straddle the valid edge of its contiguous index
+    auto vec_ok = [&](const float* ptr, int64_t ld, int64_t b0, int64_t b1, int contiguous_extent) {
+        return aligned16(ptr) && (ld & 3) == 0 && (b0 & 3) == 0 && (b1 & 3) == 0 && (contiguous_extent & 3) == 0;
+    };
+    p.vecA = vec_ok(d.A, lda, d.a_batch0, d.a_batch1, ta ? d.M : d.K);
+    p.vecB = vec_ok(d.B, ldb, d.b_batch0, d.b_batch1, tb ? d.N : d.K);
+    p.alpha = d.alpha;
+    p.accumulate = d.accumulate;
+    p.mask = d.relu_mask;
+    p.ldm = d.ld_mask;
+    p.k_chunk = d.K;
+    p.part = nullptr;
+
+    const int tiles_m = (d.M + GM - 1) / GM, tiles_n = (d.N + GN - 1) / GN;
+    const int64_t tiles = int64_t(tiles_m) * tiles_n;
+    if (tiles > 0x7fffffffLL) return LAMP_E_DIMS;
+    int nsplit = 1;
+    if (batch == 1 && tiles < 512 && d.K >= 1024 && ws) {
+        int64_t ns = (1024 + tiles - 1) / tiles;
+        if (ns > d.K / 256) ns = d.K / 256;
+        if (ns > 64) ns = 64;
+        const int64_t fit = int64_t(ws_bytes / (size_t(d.M) * d.N * sizeof(float)));
+        if (ns > fit) ns = fit;
+        if (ns >= 2) {
+            nsplit = int(ns);
+            p.k_chunk = ((d.K + nsplit - 1) / nsplit + GK - 1) / GK * GK;
+            nsplit = (d.K + p.k_chunk - 1) / p.k_chunk;
+            p.part = static_cast<float*>(ws);
+        }
+    }
+    const double flops = 2.0 * double(d.M) * d.N * d.K * double(batch);
+    const double bytes = 4.0 * double(batch) * (double(d.M) * d.K + double(d.N) * d.K + double(d.M) * d.N);
+    ProfScope prof(LAMP_K_GEMM, flops, bytes, s);
+    const dim3 grid((unsigned)tiles, (unsigned)batch, (unsigned)nsplit);
+    if (ta && tb)
+        hipLaunchKernelGGL((gemm_gen_kernel<true, true>), grid, dim3(256), 0, s, p, tiles_n);
+    else if (ta)
+        hipLaunchKernelGGL((gemm_gen_kernel<true, false>), grid, dim3(256), 0, s, p, tiles_n);
+    else if (tb)
+        hipLaunchKernelGGL((gemm_gen_kernel<false, true>), grid, dim3(256), 0, s, p, tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_gen_kernel<false, false>), grid, dim3(256), 0, s, p, tiles_n);
+    if (int e = int(hipGetLastError())) return e;
+    if (p.part) {
+        const int64_t total = int64_t(d.M) * d.N;
+        const unsigned g = unsigned(total / 256 + 1 < 2048 ? total / 256 + 1 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p.part, nsplit, d.M, d.N, d.alpha, d.relu_mask,
+                           d.ld_mask, d.accumulate, d.C, d.ldc);
+        return int(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace lamp

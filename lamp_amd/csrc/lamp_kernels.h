@@ -51,6 +51,8 @@ struct AttnParams {
 
 int launch_gemm(const GemmParams& p, hipStream_t s);
 int launch_attn(const AttnParams& p, hipStream_t s);
+size_t gemm_gen_workspace_bytes(int M, int N, int K, int batch);
+int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStream_t s);
 // y = LayerNorm(x + residual[row % r_mod or row])   (residual nullable; r_mod 0 = per-row residual)
 int launch_layernorm(const float* x, int64_t M, int d, const float* g, const float* b, float eps,
                      const float* residual, int64_t r_mod, float* y, hipStream_t s, const float* w_out = nullptr,

@@ -12,7 +12,8 @@ for wl in bibtex delicious; do
   python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/bench_$wl.json" 2>/dev/null
 done
 python bench.py --workload synthetic4096 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_synthetic4096.json" 2>/dev/null
-python tools/bench_kernels.py gemm 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles.txt"
+python tools/bench_kernels.py gemm_ab 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles.txt"
+python tools/bench_kernels.py gemm 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles_sweep.txt"
 python tools/bench_kernels.py attn 2>&1 | grep -v amdgpu.ids > "$OUT/attn_variants.txt"
 python tools/bench_kernels.py sparse 2>&1 | grep -v amdgpu.ids > "$OUT/sparse_label_attention.txt"
 BENCH="python $PWD/bench.py --no-cpu-baseline --no-pipelined"

@@ -11,9 +11,11 @@ import sys
 
 
 def last_forward(rows_by_dispatch):
-    ids = list(rows_by_dispatch)
-    diag = [i for i, k in enumerate(ids) if 'diag_kernel' in rows_by_dispatch[k]['name']]
-    return ids[diag[-2] + 1:diag[-1] + 1]
+    """Dispatch ids of the last complete forward: from its embed_kernel (the first launch of lamp_forward) up to the
+    launch before the next one / the end of the trace."""
+    ids = [k for k in rows_by_dispatch if 'lamp::' in rows_by_dispatch[k]['name']]
+    emb = [i for i, k in enumerate(ids) if 'embed_kernel' in rows_by_dispatch[k]['name']]
+    return ids[emb[-2]:emb[-1]]
 
 
 def load_pmc(d):
@@ -39,6 +41,7 @@ def main():
     for wl in ('bibtex', 'delicious', 'synthetic4096'):
         cp('bench_%s.json' % wl, 'bench_%s.json' % wl)
     cp('gemm_tiles.txt', 'gemm_tiles.txt')
+    cp('gemm_tiles_sweep.txt', 'gemm_tiles_sweep.txt')
     cp('attn_variants.txt', 'attn_variants.txt')
     cp('sparse_label_attention.txt', 'sparse_label_attention.txt')
     cp('stats/p_kernel_stats.csv', 'bench_kernel_stats.csv')
@@ -47,7 +50,7 @@ def main():
     L = ['# One forward (reuters, batch 32) under rocprofv3 --pmc (SQ counters; kernels run serialized and ~4 % slower under the profiler).',
          '# clock_GHz  = SQ_BUSY_CYCLES / 32 shader engines / duration   (the sustained clock under this load, not the 2.4 GHz spec)',
          '# mfma_busy  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock)  -- fraction of the matrix pipes\' cycles spent in MFMAs',
-         '#              (the busy-cycle count equals 64 cycles x the algorithmic number of 32x32x2 MFMAs exactly: no wasted matrix work)',
+         '#              (the busy-cycle count equals 32 cycles x the algorithmic number of 16x16x4 MFMAs in the GEMMs, 64 x the 32x32x2 count in attention: no wasted matrix work)',
          '# wait_any   = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves parked on s_waitcnt / barriers);  wait_mfma = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (issue stalls, mostly the busy matrix pipe)',
          '%-46s %8s %8s %9s %9s %9s %9s' % ('kernel', 'WGs', 'us', 'clock_GHz', 'mfma_busy', 'wait_any', 'wait_mfma')]
     for k in last_forward(disp):
