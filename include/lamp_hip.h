@@ -260,6 +260,43 @@ typedef struct lamp_gemm_desc {
 size_t lamp_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t batch);
 int lamp_gemm(const lamp_gemm_desc* d, void* workspace, size_t workspace_bytes, lamp_stream_t stream);
 
+/* y = LayerNorm(x + residual[row % residual_rows]) (residual nullable; residual_rows 0 = one residual row per x
+ * row): the add & norm that closes every sub-layer (lamp/SubLayers.py:115,140), with the sum never stored. */
+int lamp_layernorm_residual_fwd(const float* x, const float* residual, int64_t residual_rows, int64_t M, int32_t d,
+                                const float* gamma, const float* beta, float eps, float* y, lamp_stream_t stream);
+
+/* Backward of the above.  z = x + residual is recomputed from the same two inputs; given dy it returns
+ *   dz [M, d] (the gradient of both x and residual), dgamma [d] = sum_rows dy * zhat, dbeta [d] = sum_rows dy.
+ * d <= 1024.  Row sums are two-stage in a fixed order (deterministic). */
+size_t lamp_layernorm_bwd_workspace_bytes(int64_t M, int32_t d);
+int lamp_layernorm_bwd(const float* x, const float* residual, int64_t residual_rows, int64_t M, int32_t d,
+                       const float* gamma, float eps, const float* dy, float* dz, float* dgamma, float* dbeta,
+                       void* workspace, size_t workspace_bytes, lamp_stream_t stream);
+
+/* out[n] = sum_m x[m*ldx + n]: bias gradients, and the label-table gradient (sum over the batch). */
+size_t lamp_colsum_workspace_bytes(int64_t M, int64_t N);
+int lamp_colsum(const float* x, int64_t M, int64_t N, int64_t ldx, float* out, void* workspace,
+                size_t workspace_bytes, lamp_stream_t stream);
+
+/* nn.Dropout in training mode (lamp/SubLayers.py:40,113,138): y[e] = keep(e, seed) ? x[e] / (1 - p) : 0 with a
+ * counter-based generator -- keep(e, seed) = mix32(e, seed) >= p * 2^32 -- so the mask is a pure function of
+ * (element index, seed) and is never stored: calling it again on the gradient with the same seed IS the backward
+ * pass.  y may alias x.  (The stream of random numbers necessarily differs from torch's Philox stream.) */
+int lamp_dropout(const float* x, int64_t n, float p, uint32_t seed, float* y, lamp_stream_t stream);
+
+/* Softmax backward per row of length lk: dS = scale * P * (dP - sum_k P * dP); dS may alias dP. */
+int lamp_softmax_bwd(const float* P, const float* dP, int64_t rows, int32_t lk, float scale, float* dS,
+                     lamp_stream_t stream);
+
+/* Backward of lamp_diag_logits_fwd: dy[b,i,:] = dlogits[b,i] * w_out[i,:], dw[i,:] = sum_b dlogits[b,i] * y[b,i,:]. */
+int lamp_diag_logits_bwd(const float* y, const float* w_out, const float* dlogits, int32_t B, int32_t L,
+                         int32_t d_model, float* dy, float* dw, lamp_stream_t stream);
+
+/* Backward of the embedding gather: d_emb[src_seq[t], :] += dout[t, :] (atomic adds; rows of pad_idx are skipped as
+ * nn.Embedding(padding_idx) does; pass -1 for none).  d_emb must be initialised by the caller. */
+int lamp_embed_bwd(const int64_t* src_seq, int64_t n_tokens, const float* dout, int32_t d_model, int32_t n_vocab,
+                   int64_t pad_idx, float* d_emb, lamp_stream_t stream);
+
 /* ---- the whole hot path ------------------------------------------------------------------- */
 
 /* Bytes of workspace lamp_forward needs to process `micro_batch` samples of padded length T at a

@@ -100,6 +100,15 @@ PROTOTYPES = {
     'lamp_diag_logits_fwd': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     'lamp_gemm_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'lamp_gemm': (C.c_int, [C.POINTER(GemmDesc), _vp, _sz, _vp]),
+    'lamp_layernorm_residual_fwd': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _f, _vp, _vp]),
+    'lamp_layernorm_bwd_workspace_bytes': (_sz, [_i64, _i32]),
+    'lamp_layernorm_bwd': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'lamp_colsum_workspace_bytes': (_sz, [_i64, _i64]),
+    'lamp_colsum': (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    'lamp_dropout': (C.c_int, [_vp, _i64, _f, C.c_uint32, _vp, _vp]),
+    'lamp_softmax_bwd': (C.c_int, [_vp, _vp, _i64, _i32, _f, _vp, _vp]),
+    'lamp_diag_logits_bwd': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'lamp_embed_bwd': (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i64, _vp, _vp]),
     'lamp_prior_graph_build': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     'lamp_sigmoid_bce_fwd': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     'lamp_forward_workspace_bytes': (_sz, [C.POINTER(Model), _i32, _i32, _i32]),
@@ -411,6 +420,110 @@ def matmul_nt(a, b, out=None, alpha=1.0, accumulate=False, relu_mask=None):
     ws = workspace(nb, a.device) if nb else None
     check(lib().lamp_gemm(C.byref(d), ptr(ws), nb, stream()), 'lamp_gemm')
     return out
+
+
+def layernorm_residual(x, residual, gamma, beta, eps=1e-5):
+    """LayerNorm(x + residual); residual (rows, d) is broadcast over x's rows when it has fewer (row % rows)."""
+    require_device(x, gamma, beta, residual)
+    xc = f32c(x)
+    d = xc.size(-1)
+    M = xc.numel() // d
+    r = f32c(residual) if residual is not None else None
+    r_rows = 0
+    if r is not None:
+        rr = r.numel() // d
+        if rr != M:
+            if M % rr:
+                raise ValueError('residual rows do not tile x rows')
+            r_rows = rr
+    y = torch.empty_like(xc)
+    check(lib().lamp_layernorm_residual_fwd(ptr(xc), ptr(r), r_rows, M, d, ptr(f32c(gamma)), ptr(f32c(beta)), eps,
+                                            ptr(y), stream()), 'lamp_layernorm_residual_fwd')
+    return y
+
+
+def layernorm_bwd(x, residual, gamma, dy, eps=1e-5):
+    """-> (dz, dgamma, dbeta) for y = LayerNorm(x + residual)."""
+    require_device(x, gamma, dy, residual)
+    xc, g = f32c(x), f32c(dy)
+    d = xc.size(-1)
+    M = xc.numel() // d
+    r = f32c(residual) if residual is not None else None
+    r_rows = 0
+    if r is not None and r.numel() // d != M:
+        r_rows = r.numel() // d
+    dz = torch.empty_like(xc)
+    dgamma = torch.empty(d, dtype=torch.float32, device=xc.device)
+    dbeta = torch.empty_like(dgamma)
+    nb = lib().lamp_layernorm_bwd_workspace_bytes(M, d)
+    ws = workspace(nb, xc.device)
+    check(lib().lamp_layernorm_bwd(ptr(xc), ptr(r), r_rows, M, d, ptr(f32c(gamma)), eps, ptr(g), ptr(dz), ptr(dgamma),
+                                   ptr(dbeta), ptr(ws), nb, stream()), 'lamp_layernorm_bwd')
+    return dz, dgamma, dbeta
+
+
+def colsum(x):
+    """(M, N) -> (N,): sum over rows (fixed order)."""
+    require_device(x)
+    xc = f32c(x)
+    M, Nn = xc.shape
+    out = torch.empty(Nn, dtype=torch.float32, device=xc.device)
+    nb = lib().lamp_colsum_workspace_bytes(M, Nn)
+    ws = workspace(nb, xc.device)
+    check(lib().lamp_colsum(ptr(xc), M, Nn, Nn, ptr(out), ptr(ws), nb, stream()), 'lamp_colsum')
+    return out
+
+
+def dropout(x, p, seed, out=None):
+    """Counter-based dropout (see include/lamp_hip.h: lamp_dropout); the same call on a gradient is its backward."""
+    require_device(x)
+    xc = f32c(x)
+    y = torch.empty_like(xc) if out is None else out
+    check(lib().lamp_dropout(ptr(xc), xc.numel(), float(p), int(seed) & 0xffffffff, ptr(y), stream()), 'lamp_dropout')
+    return y
+
+
+def dropout_keep_mask(n, p, seed, device='cpu'):
+    """The library's keep mask for elements 0..n-1, restated with torch integer ops (tests / documentation)."""
+    e = torch.arange(n, dtype=torch.int64, device=device)
+    m32 = 0xffffffff
+    h = ((e & m32) ^ (((e >> 32) * 0x9E3779B9) & m32) ^ (int(seed) & m32)) & m32
+    h = h ^ (h >> 16)
+    h = (h * 0x7feb352d) & m32
+    h = h ^ (h >> 15)
+    h = (h * 0x846ca68b) & m32
+    h = h ^ (h >> 16)
+    thr = min(int(float(torch.tensor(p, dtype=torch.float32)) * 4294967296.0), 4294967295)
+    return h >= thr
+
+
+def softmax_bwd(P, dP, scale, out=None):
+    require_device(P, dP)
+    p, g = f32c(P), f32c(dP)
+    lk = p.size(-1)
+    o = torch.empty_like(p) if out is None else out
+    check(lib().lamp_softmax_bwd(ptr(p), ptr(g), p.numel() // lk, lk, float(scale), ptr(o), stream()), 'lamp_softmax_bwd')
+    return o
+
+
+def diag_logits_bwd(y, w_out, dlogits):
+    require_device(y, w_out, dlogits)
+    yc, w, g = f32c(y), f32c(w_out), f32c(dlogits)
+    B, L, d = yc.shape
+    dy, dw = torch.empty_like(yc), torch.empty_like(w)
+    check(lib().lamp_diag_logits_bwd(ptr(yc), ptr(w), ptr(g), B, L, d, ptr(dy), ptr(dw), stream()), 'lamp_diag_logits_bwd')
+    return dy, dw
+
+
+def embed_bwd(src_seq, dout, n_vocab, pad_idx=-1):
+    require_device(src_seq, dout)
+    g = f32c(dout)
+    d = g.size(-1)
+    seq = src_seq.contiguous()
+    d_emb = torch.zeros(n_vocab, d, dtype=torch.float32, device=g.device)
+    check(lib().lamp_embed_bwd(ptr(seq), seq.numel(), ptr(g), d, n_vocab, int(pad_idx), ptr(d_emb), stream()),
+          'lamp_embed_bwd')
+    return d_emb
 
 
 def prior_graph(label_ids, offsets, n_labels, want_blocked=False):

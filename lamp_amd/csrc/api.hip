@@ -350,6 +350,47 @@ int lamp_gemm(const lamp_gemm_desc* d, void* workspace, size_t workspace_bytes, 
     return launch_gemm_gen(*d, workspace, workspace_bytes, hipStream_t(stream));
 }
 
+int lamp_layernorm_residual_fwd(const float* x, const float* residual, int64_t residual_rows, int64_t M, int32_t d,
+                                const float* gamma, const float* beta, float eps, float* y, lamp_stream_t stream) {
+    if (!y) return LAMP_E_NULL;
+    return launch_layernorm(x, M, d, gamma, beta, eps, residual, residual_rows, y, hipStream_t(stream));
+}
+
+size_t lamp_layernorm_bwd_workspace_bytes(int64_t M, int32_t d) { return layernorm_bwd_workspace_bytes(M, d); }
+
+int lamp_layernorm_bwd(const float* x, const float* residual, int64_t residual_rows, int64_t M, int32_t d,
+                       const float* gamma, float eps, const float* dy, float* dz, float* dgamma, float* dbeta,
+                       void* workspace, size_t workspace_bytes, lamp_stream_t stream) {
+    return launch_layernorm_bwd(x, residual, residual_rows, M, d, gamma, eps, dy, dz, dgamma, dbeta, workspace,
+                                workspace_bytes, hipStream_t(stream));
+}
+
+size_t lamp_colsum_workspace_bytes(int64_t M, int64_t N) { return colsum_workspace_bytes(M, N); }
+
+int lamp_colsum(const float* x, int64_t M, int64_t N, int64_t ldx, float* out, void* workspace, size_t workspace_bytes,
+                lamp_stream_t stream) {
+    return launch_colsum(x, M, N, ldx, out, workspace, workspace_bytes, hipStream_t(stream));
+}
+
+int lamp_dropout(const float* x, int64_t n, float p, uint32_t seed, float* y, lamp_stream_t stream) {
+    return launch_dropout(x, n, p, seed, y, hipStream_t(stream));
+}
+
+int lamp_softmax_bwd(const float* P, const float* dP, int64_t rows, int32_t lk, float scale, float* dS,
+                     lamp_stream_t stream) {
+    return launch_softmax_bwd(P, dP, rows, lk, scale, dS, hipStream_t(stream));
+}
+
+int lamp_diag_logits_bwd(const float* y, const float* w_out, const float* dlogits, int32_t B, int32_t L, int32_t d_model,
+                         float* dy, float* dw, lamp_stream_t stream) {
+    return launch_diag_bwd(y, w_out, dlogits, B, L, d_model, dy, dw, hipStream_t(stream));
+}
+
+int lamp_embed_bwd(const int64_t* src_seq, int64_t n_tokens, const float* dout, int32_t d_model, int32_t n_vocab,
+                   int64_t pad_idx, float* d_emb, lamp_stream_t stream) {
+    return launch_embed_bwd(src_seq, n_tokens, dout, d_model, n_vocab, pad_idx, d_emb, hipStream_t(stream));
+}
+
 int lamp_prior_graph_build(const int64_t* label_ids, const int64_t* offsets, int64_t n_samples, int32_t L, float* adj,
                            uint8_t* blocked, lamp_stream_t stream) {
     return launch_prior_graph(label_ids, offsets, n_samples, L, adj, blocked, hipStream_t(stream));

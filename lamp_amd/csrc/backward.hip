@@ -1,0 +1,295 @@
+// Bandwidth-bound pieces of the backward pass: LayerNorm backward, column sums (bias and
+// label-table gradients), dropout (counter-based, the mask is recomputed -- never stored), softmax backward, label
+// read-out backward, embedding scatter-add.  The matrix products of the backward pass are lamp_gemm (gemm_gen.hip).
+// Reductions over rows are two-stage with a fixed summation order: results do not depend on scheduling (the only
+// atomics are in the embedding scatter-add, like torch's own embedding backward).
+#include "lamp_kernels.h"
+
+namespace lamp {
+
+namespace {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+constexpr int LNB_MAX_WG = 512;
+
+// dz = d/dz LayerNorm(z) . dy, z = x + res;   partial[wg] = [sum_rows dy * zhat | sum_rows dy]  over this WG's rows
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                            int64_t r_mod, int64_t M, int d,
+                                                            const float* __restrict__ g, float eps,
+                                                            const float* __restrict__ dy, float* __restrict__ dz,
+                                                            float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = d / 4;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4 gg[NV], ag[NV], ab[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        gg[i] = c < nv ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float inv_d = 1.0f / float(d);
+    for (int64_t row = int64_t(blockIdx.x) * 4 + wave; row < M; row += int64_t(gridDim.x) * 4) {
+        const float4* xr = reinterpret_cast<const float4*>(x + row * d);
+        const float4* rr = res ? reinterpret_cast<const float4*>(res + (r_mod > 0 ? row % r_mod : row) * d) : nullptr;
+        const float4* dr = reinterpret_cast<const float4*>(dy + row * d);
+        float4 v[NV], t[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr && c < nv) {
+                const float4 w = rr[c];
+                v[i].x += w.x; v[i].y += w.y; v[i].z += w.z; v[i].w += w.w;
+            }
+            t[i] = c < nv ? dr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mean = wsum(s) * inv_d;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wsum(ss) * inv_d + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;  // zhat
+            ag[i].x += t[i].x * v[i].x; ag[i].y += t[i].y * v[i].y; ag[i].z += t[i].z * v[i].z; ag[i].w += t[i].w * v[i].w;
+            ab[i].x += t[i].x; ab[i].y += t[i].y; ab[i].z += t[i].z; ab[i].w += t[i].w;
+            t[i].x *= gg[i].x; t[i].y *= gg[i].y; t[i].z *= gg[i].z; t[i].w *= gg[i].w;  // dy * gamma
+            s1 += (t[i].x + t[i].y) + (t[i].z + t[i].w);
+            s2 += (t[i].x * v[i].x + t[i].y * v[i].y) + (t[i].z * v[i].z + t[i].w * v[i].w);
+        }
+        s1 = wsum(s1) * inv_d;
+        s2 = wsum(s2) * inv_d;
+        float4* zr = reinterpret_cast<float4*>(dz + row * d);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv)
+                zr[c] = make_float4(rstd * (t[i].x - s1 - v[i].x * s2), rstd * (t[i].y - s1 - v[i].y * s2),
+                                    rstd * (t[i].z - s1 - v[i].z * s2), rstd * (t[i].w - s1 - v[i].w * s2));
+        }
+    }
+    float4* r4 = reinterpret_cast<float4*>(red);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            r4[(wave * 2 + 0) * nv + c] = ag[i];
+            r4[(wave * 2 + 1) * nv + c] = ab[i];
+        }
+    }
+    __syncthreads();
+    float* out = partial + int64_t(blockIdx.x) * 2 * d;
+    for (int e = threadIdx.x; e < 2 * d; e += 256)
+        out[e] = (red[e] + red[2 * d + e]) + (red[4 * d + e] + red[6 * d + e]);
+}
+
+// partial[gy][col] = sum over this row chunk of x[row][col]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t M, int64_t N, int64_t ldx,
+                                                             int64_t rows_per_chunk, float* __restrict__ partial) {
+    const int64_t col = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (col >= N) return;
+    const int64_t r0 = int64_t(blockIdx.y) * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < M ? r0 + rows_per_chunk : M;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += x[r * ldx + col];
+    partial[int64_t(blockIdx.y) * N + col] = s;
+}
+
+// out_k[c] = sum_p partial[p][k * n_out + c]   for k in {0, 1}: a [P][n_out] or [P][2][n_out] partial buffer
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int P, int64_t n_out,
+                                                              int n_seg, float* __restrict__ out0,
+                                                              float* __restrict__ out1) {
+    const int64_t c = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (c >= n_out * n_seg) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += partial[int64_t(p) * n_out * n_seg + c];
+    if (c < n_out)
+        out0[c] = s;
+    else
+        out1[c - n_out] = s;
+}
+
+// Counter-based dropout: element e of site `seed` is kept iff mix32(e, seed) >= p * 2^32.  The same call with the
+// same seed applied to the gradient is the backward pass.
+__device__ __forceinline__ unsigned mix32(unsigned lo, unsigned hi, unsigned seed) {
+    unsigned h = lo ^ (hi * 0x9E3779B9u) ^ seed;
+    h ^= h >> 16; h *= 0x7feb352du;
+    h ^= h >> 15; h *= 0x846ca68bu;
+    h ^= h >> 16;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int64_t n, unsigned threshold,
+                                                      float scale, unsigned seed, float* __restrict__ y) {
+    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < n; e += int64_t(gridDim.x) * 256) {
+        const unsigned h = mix32(unsigned(e), unsigned(uint64_t(e) >> 32), seed);
+        y[e] = h >= threshold ? x[e] * scale : 0.f;
+    }
+}
+
+// dS = scale * P * (dP - sum_k P * dP) per row (softmax backward; P = 0 on blocked entries keeps them at 0)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dP,
+                                                          int64_t rows, int lk, float scale, float* __restrict__ dS) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = P + row * lk;
+    const float* g = dP + row * lk;
+    float s = 0.f;
+    for (int c = lane; c < lk; c += 64) s += p[c] * g[c];
+    s = wsum(s);
+    float* o = dS + row * lk;
+    for (int c = lane; c < lk; c += 64) o[c] = scale * p[c] * (g[c] - s);
+}
+
+// Read-out backward (lamp/Models.py:124-126): dy[b,i,:] = dl[b,i] * w[i,:];  dw[i,:] = sum_b dl[b,i] * y[b,i,:]
+__global__ __launch_bounds__(256) void diag_bwd_kernel(const float* __restrict__ y, const float* __restrict__ w,
+                                                       const float* __restrict__ dl, int B, int L, int d,
+                                                       float* __restrict__ dy, float* __restrict__ dw) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= L) return;
+    const float4* wr = reinterpret_cast<const float4*>(w + int64_t(i) * d);
+    for (int c = lane; c < d / 4; c += 64) {
+        const float4 ww = wr[c];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < B; ++b) {
+            const int64_t row = int64_t(b) * L + i;
+            const float g = dl[row];
+            const float4 yy = reinterpret_cast<const float4*>(y + row * d)[c];
+            acc.x += g * yy.x; acc.y += g * yy.y; acc.z += g * yy.z; acc.w += g * yy.w;
+            reinterpret_cast<float4*>(dy + row * d)[c] = make_float4(g * ww.x, g * ww.y, g * ww.z, g * ww.w);
+        }
+        reinterpret_cast<float4*>(dw + int64_t(i) * d)[c] = acc;
+    }
+}
+
+// d_emb[seq[t], :] += dout[t, :]   (skipping pad_idx, whose row nn.Embedding(padding_idx=...) never updates)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ seq, int64_t n_tok,
+                                                        const float* __restrict__ dout, int d, int n_vocab,
+                                                        int64_t pad_idx, float* __restrict__ d_emb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (t >= n_tok) return;
+    const int64_t tok = seq[t];
+    if (tok == pad_idx || tok < 0 || tok >= n_vocab) return;
+    const float* src = dout + t * d;
+    float* dst = d_emb + tok * d;
+    for (int c = lane; c < d; c += 64) atomicAdd(dst + c, src[c]);
+}
+
+inline int lnb_grid(int64_t M) {
+    const int64_t n = (M + 3) / 4;
+    return int(n < LNB_MAX_WG ? n : LNB_MAX_WG);
+}
+inline int colsum_chunks(int64_t M) {
+    int64_t c = (M + 127) / 128;
+    return int(c < 1 ? 1 : (c > 256 ? 256 : c));
+}
+
+}  // namespace
+
+size_t layernorm_bwd_workspace_bytes(int64_t M, int d) { return size_t(lnb_grid(M)) * 2 * d * sizeof(float); }
+
+int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_t M, int d, const float* g, float eps,
+                         const float* dy, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                         hipStream_t s) {
+    if (M <= 0 || d <= 0) return LAMP_E_DIMS;
+    if ((d & 3) || d > 1024) return LAMP_E_UNSUPPORTED;
+    if (!x || !g || !dy || !dz || !dgamma || !dbeta || !ws) return LAMP_E_NULL;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dz) || !aligned16(g) || (res && !aligned16(res)) || !aligned16(ws))
+        return LAMP_E_ALIGN;
+    if (ws_bytes < layernorm_bwd_workspace_bytes(M, d)) return LAMP_E_WORKSPACE;
+    const int grid = lnb_grid(M);
+    float* partial = static_cast<float*>(ws);
+    const size_t lds = size_t(8) * d * sizeof(float);
+    const int nv = (d / 4 + 63) / 64;
+    ProfScope prof(LAMP_K_LAYERNORM, 0.0, 12.0 * double(M) * d, s);
+    if (nv <= 1)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(grid), dim3(256), lds, s, x, res, r_mod, M, d, g, eps, dy, dz, partial);
+    else if (nv <= 2)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(grid), dim3(256), lds, s, x, res, r_mod, M, d, g, eps, dy, dz, partial);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(grid), dim3(256), lds, s, x, res, r_mod, M, d, g, eps, dy, dz, partial);
+    if (int e = int(hipGetLastError())) return e;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, s, partial, grid, int64_t(d), 2,
+                       dgamma, dbeta);
+    return int(hipGetLastError());
+}
+
+size_t colsum_workspace_bytes(int64_t M, int64_t N) { return size_t(colsum_chunks(M)) * N * sizeof(float); }
+
+int launch_colsum(const float* x, int64_t M, int64_t N, int64_t ldx, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (M <= 0 || N <= 0 || ldx < N) return LAMP_E_DIMS;
+    if (!x || !out || !ws) return LAMP_E_NULL;
+    if (ws_bytes < colsum_workspace_bytes(M, N)) return LAMP_E_WORKSPACE;
+    const int chunks = colsum_chunks(M);
+    const int64_t rows_per_chunk = (M + chunks - 1) / chunks;
+    const int64_t gx = (N + 255) / 256;
+    if (gx > 0x7fffffffLL) return LAMP_E_DIMS;
+    float* partial = static_cast<float*>(ws);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)gx, chunks), dim3(256), 0, s, x, M, N, ldx, rows_per_chunk, partial);
+    if (int e = int(hipGetLastError())) return e;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)gx), dim3(256), 0, s, partial, chunks, N, 1, out, out);
+    return int(hipGetLastError());
+}
+
+int launch_dropout(const float* x, int64_t n, float p, uint32_t seed, float* y, hipStream_t s) {
+    if (n <= 0) return LAMP_E_DIMS;
+    if (!(p >= 0.f) || !(p < 1.f)) return LAMP_E_UNSUPPORTED;
+    if (!x || !y) return LAMP_E_NULL;
+    const double t = double(p) * 4294967296.0;
+    const unsigned threshold = t >= 4294967295.0 ? 4294967295u : unsigned(t);
+    const int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(g < 8192 ? g : 8192)), dim3(256), 0, s, x, n, threshold,
+                       1.0f / (1.0f - p), seed, y);
+    return int(hipGetLastError());
+}
+
+int launch_softmax_bwd(const float* P, const float* dP, int64_t rows, int lk, float scale, float* dS, hipStream_t s) {
+    if (rows <= 0 || lk <= 0) return LAMP_E_DIMS;
+    if (!P || !dP || !dS) return LAMP_E_NULL;
+    const int64_t g = (rows + 3) / 4;
+    if (g > 0x7fffffffLL) return LAMP_E_DIMS;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)g), dim3(256), 0, s, P, dP, rows, lk, scale, dS);
+    return int(hipGetLastError());
+}
+
+int launch_diag_bwd(const float* y, const float* w, const float* dl, int B, int L, int d, float* dy, float* dw,
+                    hipStream_t s) {
+    if (B <= 0 || L <= 0 || d <= 0) return LAMP_E_DIMS;
+    if (d & 3) return LAMP_E_UNSUPPORTED;
+    if (!y || !w || !dl || !dy || !dw) return LAMP_E_NULL;
+    if (!aligned16(y) || !aligned16(w) || !aligned16(dy) || !aligned16(dw)) return LAMP_E_ALIGN;
+    hipLaunchKernelGGL(diag_bwd_kernel, dim3((L + 3) / 4), dim3(256), 0, s, y, w, dl, B, L, d, dy, dw);
+    return int(hipGetLastError());
+}
+
+int launch_embed_bwd(const int64_t* seq, int64_t n_tok, const float* dout, int d, int n_vocab, int64_t pad_idx,
+                     float* d_emb, hipStream_t s) {
+    if (n_tok <= 0 || d <= 0 || n_vocab <= 0) return LAMP_E_DIMS;
+    if (!seq || !dout || !d_emb) return LAMP_E_NULL;
+    const int64_t g = (n_tok + 3) / 4;
+    if (g > 0x7fffffffLL) return LAMP_E_DIMS;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)g), dim3(256), 0, s, seq, n_tok, dout, d, n_vocab, pad_idx, d_emb);
+    return int(hipGetLastError());
+}
+
+}  // namespace lamp

@@ -57,6 +57,18 @@ int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStrea
 int launch_layernorm(const float* x, int64_t M, int d, const float* g, const float* b, float eps,
                      const float* residual, int64_t r_mod, float* y, hipStream_t s, const float* w_out = nullptr,
                      int n_labels = 0, float* logits = nullptr);  // w_out: fused read-out, y may then be NULL
+size_t layernorm_bwd_workspace_bytes(int64_t M, int d);
+int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_t M, int d, const float* g, float eps,
+                         const float* dy, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                         hipStream_t s);
+size_t colsum_workspace_bytes(int64_t M, int64_t N);
+int launch_colsum(const float* x, int64_t M, int64_t N, int64_t ldx, float* out, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_dropout(const float* x, int64_t n, float p, uint32_t seed, float* y, hipStream_t s);
+int launch_softmax_bwd(const float* P, const float* dP, int64_t rows, int lk, float scale, float* dS, hipStream_t s);
+int launch_diag_bwd(const float* y, const float* w, const float* dl, int B, int L, int d, float* dy, float* dw,
+                    hipStream_t s);
+int launch_embed_bwd(const int64_t* seq, int64_t n_tok, const float* dout, int d, int n_vocab, int64_t pad_idx,
+                     float* d_emb, hipStream_t s);
 int launch_embed(const int64_t* seq, const int64_t* pos, int64_t n_tok, const float* emb, int n_vocab,
                  const float* pos_table, int n_position, int d, float* out, hipStream_t s);
 int launch_diag(const float* y, const float* w, int B, int L, int d, float* logits, hipStream_t s);

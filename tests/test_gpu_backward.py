@@ -95,3 +95,93 @@ def test_matmul_nt_rejects_bad_operands(dev):
         N_.matmul_nt(a.cpu(), a.cpu())
     with pytest.raises(TypeError):
         N_.matmul_nt(a.double(), a.double())
+
+
+@pytest.mark.parametrize('M,d,r_rows', [(7, 64, 0), (2880, 512, 0), (2880, 512, 90), (333, 1024, 0), (5, 36, 0), (9664, 512, 0)])
+def test_layernorm_residual_fwd_and_bwd_vs_autograd(dev, M, d, r_rows):
+    from lamp_amd import _native as N_
+    g = torch.Generator().manual_seed(M + d)
+    x = _rand(g, M, d)
+    res = _rand(g, r_rows or M, d)
+    gamma, beta, dy = 1 + 0.3 * _rand(g, d), 0.1 * _rand(g, d), _rand(g, M, d)
+    xd, rd = x.double().requires_grad_(), res.double().requires_grad_()
+    gd, bd = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    z = xd + (rd.repeat(M // r_rows, 1) if r_rows else rd)
+    y_ref = torch.nn.functional.layer_norm(z, (d,), gd, bd, 1e-5)
+    y_ref.backward(dy.double())
+    y = N_.layernorm_residual(x.to(dev), res.to(dev), gamma.to(dev), beta.to(dev))
+    assert max_abs_diff(y, y_ref.detach()) < 2e-5
+    dz, dgamma, dbeta = N_.layernorm_bwd(x.to(dev), res.to(dev), gamma.to(dev), dy.to(dev))
+    assert max_abs_diff(dz, xd.grad) < 3e-5
+    assert max_abs_diff(dgamma, gd.grad) < 1e-4 * max(1.0, (M / 100) ** 0.5)
+    assert max_abs_diff(dbeta, bd.grad) < 1e-4 * max(1.0, (M / 100) ** 0.5)
+    if r_rows:  # the broadcast residual's gradient is the sum over its repeats: colsum of the (M/r, r*d) view
+        dres = N_.colsum(dz.view(M // r_rows, r_rows * d)).view(r_rows, d)
+        assert max_abs_diff(dres, rd.grad) < 1e-4
+    # deterministic
+    dz2, dgamma2, _ = N_.layernorm_bwd(x.to(dev), res.to(dev), gamma.to(dev), dy.to(dev))
+    assert torch.equal(dz, dz2) and torch.equal(dgamma, dgamma2)
+
+
+@pytest.mark.parametrize('M,N', [(1, 5), (32, 46080), (9664, 512), (2880, 2048), (129, 257)])
+def test_colsum(dev, M, N):
+    from lamp_amd import _native as N_
+    x = torch.randn(M, N, generator=torch.Generator().manual_seed(M + N))
+    out = N_.colsum(x.to(dev))
+    assert max_abs_diff(out, x.double().sum(0)) < 1e-5 * max(1.0, M ** 0.5) * 4
+
+
+@pytest.mark.parametrize('p', [0.0, 0.1, 0.5])
+def test_dropout_is_counter_based_and_unbiased(dev, p):
+    from lamp_amd import _native as N_
+    n = 1 << 20
+    x = torch.randn(n, generator=torch.Generator().manual_seed(3)).to(dev)
+    y = N_.dropout(x, p, seed=1234)
+    keep = N_.dropout_keep_mask(n, p, 1234).to(dev)
+    assert torch.equal(y, torch.where(keep, x * (1.0 / (1.0 - p)) if p else x, torch.zeros_like(x)))
+    assert abs(keep.float().mean().item() - (1 - p)) < 3e-3
+    # another site (seed) gives an independent mask; the same seed on a gradient gives the same mask (= backward)
+    keep2 = N_.dropout_keep_mask(n, p, 1235).to(dev)
+    if p:
+        assert abs((keep & keep2).float().mean().item() - (1 - p) ** 2) < 3e-3
+    g = torch.ones(n, device=dev)
+    assert torch.equal(N_.dropout(g, p, seed=1234) != 0, keep)
+    # in place
+    z = x.clone()
+    N_.dropout(z, p, seed=1234, out=z)
+    assert torch.equal(z, y)
+
+
+@pytest.mark.parametrize('rows,lk', [(3, 5), (128 * 90, 300), (77, 90), (64, 4096)])
+def test_softmax_bwd_vs_autograd(dev, rows, lk):
+    from lamp_amd import _native as N_
+    g = torch.Generator().manual_seed(rows + lk)
+    s = _rand(g, rows, lk).double()
+    blocked = torch.rand(rows, lk, generator=g) < 0.3
+    blocked[:, 0] = False
+    s = s.masked_fill(blocked, float('-inf')).requires_grad_()
+    p = torch.softmax(s * 0.25, -1)
+    dP = _rand(g, rows, lk)
+    p.backward(dP.double())
+    dS = N_.softmax_bwd(p.detach().float().to(dev), dP.to(dev), 0.25)
+    assert max_abs_diff(dS, s.grad) < 1e-5
+    assert (dS.cpu()[blocked] == 0).all()
+
+
+def test_diag_logits_bwd_and_embed_bwd_vs_autograd(dev):
+    from lamp_amd import _native as N_
+    g = torch.Generator().manual_seed(8)
+    B, L, d, V = 5, 37, 64, 50
+    y, w, dl = _rand(g, B, L, d), _rand(g, L, d), _rand(g, B, L)
+    yd, wd = y.double().requires_grad_(), w.double().requires_grad_()
+    (yd * wd.unsqueeze(0)).sum(-1).backward(dl.double())
+    dy, dw = N_.diag_logits_bwd(y.to(dev), w.to(dev), dl.to(dev))
+    assert max_abs_diff(dy, yd.grad) < 1e-5 and max_abs_diff(dw, wd.grad) < 1e-5
+    seq = torch.randint(0, V, (B, 23), generator=g)
+    seq[:, -4:] = 0
+    emb = torch.nn.Embedding(V, d, padding_idx=0).double()
+    dout = _rand(g, B, 23, d)
+    emb(seq).backward(dout.double())
+    d_emb = N_.embed_bwd(seq.to(dev), dout.to(dev), V, pad_idx=0)
+    assert max_abs_diff(d_emb, emb.weight.grad) < 1e-4
+    assert (d_emb[0] == 0).all()
