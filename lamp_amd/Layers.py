@@ -1,7 +1,7 @@
 """Encoder / decoder layers of the LaMP graph model (reference: lamp/Layers.py:9-48)."""
 import torch.nn as nn
 
-from .SubLayers import MultiHeadAttention, PositionwiseFeedForward, _eval_only
+from .SubLayers import MultiHeadAttention, PositionwiseFeedForward
 
 
 class EncoderLayer(nn.Module):
@@ -16,7 +16,6 @@ class EncoderLayer(nn.Module):
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner_hid, dropout=dropout)
 
     def forward(self, enc_input, slf_attn_mask=None, need_attn=True):
-        _eval_only(self)
         attn = None
         if need_attn:
             _, attn = self.slf_attn(enc_input, enc_input, enc_input, attn_mask=slf_attn_mask)
@@ -38,7 +37,6 @@ class DecoderLayer(nn.Module):
         self.pos_ffn2 = PositionwiseFeedForward(d_model, d_inner_hid, dropout=dropout)
 
     def forward(self, dec_input, enc_output, slf_attn_mask=None, dec_enc_attn_mask=None, need_attn=True):
-        _eval_only(self)
         self.enc_attn.need_attn = need_attn
         out, enc_attn = self.enc_attn(dec_input, enc_output, enc_output, attn_mask=dec_enc_attn_mask)
         out = self.pos_ffn1(out)

@@ -13,7 +13,7 @@ import torch.nn as nn
 from . import _native as N
 from .Decoders import GraphDecoder, MLPDecoder, RNNDecoder
 from .Encoders import GraphEncoder, MLPEncoder, RNNEncoder
-from .SubLayers import XavierLinear, _eval_only
+from .SubLayers import XavierLinear
 
 
 class LAMP(nn.Module):
@@ -130,13 +130,19 @@ class LAMP(nn.Module):
         return self._native_cache[1]
 
     def forward(self, src, adj, tgt_seq, binary_tgt, return_attns=False, int_preds=False):
-        _eval_only(self)
         if self.decoder_type != 'graph':
             raise NotImplementedError(self.decoder_type)
         if adj:
             raise NotImplementedError('per-sample adjacency for the encoder is outside the hot path')
         src_seq, src_pos = src
         N.require_device(src_seq, src_pos)
+        if self.training:
+            # train.py:36: the autograd-recording path (HIP kernels forward and backward, lamp_amd/training.py)
+            if return_attns or int_preds:
+                raise NotImplementedError('training with -attns_loss / -int_preds is not built (SURVEY.md 8f n4)')
+            from . import training
+            logits, enc_output = training.forward_train(self, src_seq, src_pos)
+            return logits, enc_output, None
         dev = src_seq.device
         seq = src_seq.long().contiguous()
         pos = src_pos.long().contiguous()

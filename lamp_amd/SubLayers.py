@@ -4,8 +4,10 @@ Same classes, constructor signatures, parameter names/shapes and initialisers as
 lamp/SubLayers.py, so reference checkpoints load.  ``forward`` does no
 arithmetic in PyTorch: every op goes through the C ABI of liblamp_hip.so (lamp_amd/_native.py).
 
-Scope: inference (``module.eval()``) on a HIP device.  Training mode raises -- backward kernels are
-not part of this path -- and so does a CPU tensor: there is no fallback.
+Scope: a HIP device; a CPU tensor raises -- there is no fallback.  ``module.eval()`` is the fused inference
+path.  In training mode MultiHeadAttention and PositionwiseFeedForward (and LAMP.forward as a whole) run the
+autograd-recording path of lamp_amd/training.py, whose backward is HIP kernels as well; the
+bare XavierLinear / ScaledDotProductAttention wrappers stay eval-only.
 """
 import numpy as np
 import torch
@@ -17,8 +19,8 @@ from . import _native as N
 def _eval_only(module):
     if module.training:
         raise NotImplementedError(
-            '%s: lamp_amd implements the eval-mode forward path only (call .eval()); training / '
-            'backward is outside this build (SURVEY.md 8f n4).' % type(module).__name__)
+            '%s: only the eval-mode forward of this wrapper is implemented (call .eval()); training runs through '
+            'MultiHeadAttention / PositionwiseFeedForward / LAMP.forward (lamp_amd/training.py).' % type(module).__name__)
 
 
 class XavierLinear(nn.Module):
@@ -89,11 +91,14 @@ class MultiHeadAttention(nn.Module):
         return N.make_mask(attn_mask, B, lq, lk)
 
     def forward(self, q, k, v, attn_mask=None, dec_self=False):
-        _eval_only(self)
         B, lq, d = q.shape
         lk = k.size(1)
         mstruct, keep = self._mask_struct(attn_mask, B, lq, lk)
         same_kv = (k is v) or (k.data_ptr() == v.data_ptr() and k.shape == v.shape and k.stride() == v.stride())
+        if same_kv and self.training:
+            from . import training
+            N.require_device(q, k)
+            return training.mha_train(self, q, k, mstruct, keep, training._Seeds())
         if same_kv:
             out, attn = N.mha(q, k, N.mha_weights(self), self.d_k, self.d_v, mstruct, self.need_attn)
             del keep
@@ -116,5 +121,8 @@ class PositionwiseFeedForward(nn.Module):
         self.d_hid = d_hid
 
     def forward(self, x):
-        _eval_only(self)
+        if self.training:
+            from . import training
+            N.require_device(x)
+            return training.ffn_train(self, x, training._Seeds())
         return N.ffn(x, N.ffn_weights(self), self.d_hid)

@@ -291,6 +291,24 @@ def sdpa(q, k, v, mask, inv_temperature, need_attn=True):
     return out, attn
 
 
+def sdpa_fused(q, k, v, n_head, mask_struct, inv_temperature, need_attn=True):
+    """Attention on head-fused projections: q (B, lq, H*dk), k (B, lk, H*dk), v (B, lk, H*dv) ->
+    out (B, lq, H*dv), attn (H*B, lq, lk) [index head*B + b] or None.  No head split/merge copies: the
+    kernel walks the heads through lamp_attn_layout strides."""
+    require_device(q, k, v)
+    q, k, v = f32c(q), f32c(k), f32c(v)
+    B, lq, hq = q.shape
+    lk, H = k.size(1), n_head
+    dk, dv = hq // H, v.size(2) // H
+    out = torch.empty((B, lq, H * dv), dtype=torch.float32, device=q.device)
+    attn = torch.empty((H * B, lq, lk), dtype=torch.float32, device=q.device) if need_attn else None
+    lay = AttnLayout(lq * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lk * H * dv, dv, H * dv, lq * H * dv, dv, H * dv)
+    check(lib().lamp_sdpa_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(attn), B, H, lq, lk, dk, dv,
+                              float(inv_temperature), C.byref(mask_struct) if mask_struct is not None else None,
+                              C.byref(lay), stream()), 'lamp_sdpa_fwd')
+    return out, attn
+
+
 def mha_weights(mod):
     """MhaWeights struct for a lamp_amd MultiHeadAttention module (pointers into its parameters)."""
     fc = getattr(mod, 'fc', None)

@@ -1,0 +1,194 @@
+"""Training through the HIP path (reference train.py:36-48): loss.backward() on lamp_amd's LAMP in
+train() mode against torch.autograd on the fp64 CPU oracle -- every parameter's gradient -- and dropout checked
+against a plain-torch restatement that uses the library's (counter-based, reproducible) keep masks."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import max_abs_diff
+from oracle import lamp_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+CASES = {
+    # name: V, L, T, d, dff, h, mask, pos_emb, B, p_adj, lengths
+    'tiny_prior_h4': (50, 37, 23, 64, 96, 4, 'prior', True, 3, 0.2, [23, 5, 14]),
+    'tiny_none_h1': (40, 20, 17, 32, 48, 1, 'none', False, 2, 0.0, [17, 9]),
+    'inveye_h8': (60, 70, 33, 128, 256, 8, 'inveye', True, 3, 0.0, [33, 1, 20]),
+    'reuters_like': (300, 90, 60, 512, 512, 4, 'prior', True, 2, 0.1, [60, 41]),
+}
+
+
+def build(cfg, dev, dropout=0.0, seed=0):
+    from lamp_amd.Models import LAMP
+    V, L, T, d, dff, h, mask, pos, B, p, lengths = cfg
+    sd = R.make_state_dict(V, L, T, d, dff, h, 2, 2, pos_emb=pos, seed=seed)
+    adj = R.make_adjacency(L, p, seed) if mask == 'prior' else None
+    seq, spos = R.make_batch(B, V, T, lengths=lengths, seed=seed)
+    m = LAMP(V, L, T, L, n_layers_enc=2, n_layers_dec=2, n_head=h, n_head2=h, d_word_vec=d, d_model=d,
+             d_inner_hid=dff, d_k=d // h, d_v=d // h, encoder='graph', decoder='graph', dropout=dropout,
+             dec_dropout=dropout, no_enc_pos_embedding=not pos,
+             label_adj_matrix=adj.clone() if adj is not None else None, label_mask=mask, dec_dropout2=False)
+    m.load_state_dict(sd)
+    blocked = R.label_block_mask(adj, mask, L)
+    tgt = (torch.rand(B, L, generator=torch.Generator().manual_seed(seed + 1)) < 0.2).float()
+    return m.to(dev), sd, blocked, seq, spos, h, tgt
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_every_parameter_gradient_matches_oracle_autograd(dev, name):
+    m, sd, blocked, seq, spos, h, tgt = build(CASES[name], dev)
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    ref_logits, ref_enc, _ = R.forward(sd64, seq, spos, h, blocked)
+    ref_loss = F.binary_cross_entropy_with_logits(ref_logits, tgt.double())
+    ref_loss.backward()
+
+    m.train()
+    logits, enc, extra = m((seq.to(dev), spos.to(dev)), None, None, tgt.to(dev))
+    assert extra is None and logits.requires_grad and enc.requires_grad
+    assert max_abs_diff(logits, ref_logits.detach()) < 1e-4
+    assert max_abs_diff(enc, ref_enc.detach()) < 5e-5
+    loss = F.binary_cross_entropy_with_logits(logits, tgt.to(dev))     # train.py:38
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+
+    checked = 0
+    for pname, p in m.named_parameters():
+        ref = sd64[pname].grad
+        if pname == 'encoder.position_enc.weight':
+            assert p.grad is None   # frozen sinusoid table: never handed to the optimizer (lamp/Models.py:97-107)
+            continue
+        if 'encoder.layer_stack' in pname and 'slf_attn' in pname:
+            assert p.grad is None and ref is None, pname      # dead code in the reference: no gradient there either
+            continue
+        if pname == 'decoder.tgt_word_emb.weight' and 'tgt_word_proj.weight' in sd64 and sd64['tgt_word_proj.weight'].grad is not None:
+            ref = ref + sd64['tgt_word_proj.weight'].grad
+        assert p.grad is not None and ref is not None, pname
+        scale = ref.abs().max().item()
+        assert max_abs_diff(p.grad, ref) <= 3e-4 * scale + 1e-9, (pname, max_abs_diff(p.grad, ref), scale)
+        checked += 1
+    assert checked >= 40
+
+    # eval-mode forward of the same weights agrees with the train-mode forward at dropout 0
+    m.eval()
+    with torch.no_grad():
+        ev, _, _ = m((seq.to(dev), spos.to(dev)), None, None, None)
+    assert max_abs_diff(ev, logits.detach()) < 2e-5
+
+
+def test_optimizer_step_reduces_the_loss_and_invalidates_cached_query(dev):
+    """A few Adam steps of the reference's train loop (train.py:34-48) on one batch."""
+    m, sd, blocked, seq, spos, h, tgt = build(CASES['tiny_prior_h4'], dev)
+    opt = torch.optim.Adam(m.get_trainable_parameters(), lr=2e-3)
+    losses = []
+    for _ in range(8):
+        m.train()
+        opt.zero_grad()
+        pred, enc_output, *results = m((seq.to(dev), spos.to(dev)), None, None, tgt.to(dev))
+        loss = F.binary_cross_entropy_with_logits(pred, tgt.to(dev), reduction='mean')
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.8 * losses[0], losses
+    # eval after training sees the updated weights (the cached layer-0 query is keyed on parameter versions)
+    m.eval()
+    with torch.no_grad():
+        ev, _, _ = m((seq.to(dev), spos.to(dev)), None, None, None)
+    sd_now = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref, _, _ = R.forward(R.to_dtype(sd_now, torch.float64), seq, spos, h, blocked)
+    assert max_abs_diff(ev, ref) < 1e-4
+
+
+def test_dropout_forward_is_reproducible_under_manual_seed(dev):
+    m, sd, blocked, seq, spos, h, tgt = build(CASES['tiny_prior_h4'], dev, dropout=0.1)
+    m.train()
+    outs = []
+    for s in (7, 7, 8):
+        torch.manual_seed(s)
+        outs.append(m((seq.to(dev), spos.to(dev)), None, None, None)[0].detach())
+    assert torch.equal(outs[0], outs[1])
+    assert not torch.equal(outs[0], outs[2])
+    m.eval()
+    with torch.no_grad():
+        ev = m((seq.to(dev), spos.to(dev)), None, None, None)[0]
+    assert not torch.equal(ev, outs[0])
+
+
+def test_ffn_with_dropout_matches_torch_restatement_with_the_same_mask(dev):
+    from lamp_amd import _native as N
+    from lamp_amd import training
+    g = torch.Generator().manual_seed(1)
+    M, d, dff, p, seed = 77, 64, 96, 0.3, 4242
+    x = torch.randn(M, d, generator=g)
+    w1, b1 = torch.randn(dff, d, 1, generator=g) * 0.1, torch.randn(dff, generator=g) * 0.1
+    w2, b2 = torch.randn(d, dff, 1, generator=g) * 0.1, torch.randn(d, generator=g) * 0.1
+    lg, lb = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    dy = torch.randn(M, d, generator=g)
+    leaves = [t.double().requires_grad_() for t in (x, w1, b1, w2, b2, lg, lb)]
+    X, W1, B1, W2, B2, LG, LB = leaves
+    keep = N.dropout_keep_mask(M * d, p, seed).view(M, d)
+    o = torch.relu(X @ W1[:, :, 0].t() + B1) @ W2[:, :, 0].t() + B2
+    ref = F.layer_norm(o * keep / (1 - p) + X, (d,), LG, LB, 1e-5)
+    ref.backward(dy.double())
+    dl = [t.to(dev).requires_grad_() for t in (x, w1, b1, w2, b2, lg, lb)]
+    y = training._FFNFn.apply(*dl, p, seed)
+    y.backward(dy.to(dev))
+    assert max_abs_diff(y.detach(), ref.detach()) < 2e-5
+    for a, b in zip(dl, leaves):
+        assert max_abs_diff(a.grad, b.grad) <= 2e-4 * b.grad.abs().max().item() + 1e-9
+
+
+@pytest.mark.parametrize('H,p_attn,p_out', [(4, 0.0, 0.0), (4, 0.25, 0.2), (1, 0.25, 0.0)])
+def test_mha_with_dropout_matches_torch_restatement_with_the_same_masks(dev, H, p_attn, p_out):
+    from lamp_amd import _native as N
+    from lamp_amd import training
+    g = torch.Generator().manual_seed(2 + H)
+    B, lq, lk, d, dk = 3, 21, 34, 64, 16
+    xq, xkv = torch.randn(B, lq, d, generator=g), torch.randn(B, lk, d, generator=g)
+    wq, wk, wv = (torch.randn(H * dk, d, generator=g) * 0.2 for _ in range(3))
+    fc = torch.randn(d, H * dk, generator=g) * 0.2 if H > 1 else None
+    lg, lb = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    blocked = torch.rand(lq, lk, generator=g) < 0.3
+    blocked[:, 0] = False
+    dy = torch.randn(B, lq, d, generator=g)
+    s_attn, s_out = 99, 100
+    if H == 1:
+        d_out = dk  # without fc the attention output IS the sub-layer output: d_model = d_v
+        xq, dy = torch.randn(B, lq, dk, generator=g), torch.randn(B, lq, dk, generator=g)
+        xkv = torch.randn(B, lk, dk, generator=g)
+        wq, wk, wv = (torch.randn(dk, dk, generator=g) * 0.2 for _ in range(3))
+        lg, lb = 1 + 0.1 * torch.randn(dk, generator=g), 0.1 * torch.randn(dk, generator=g)
+        d = dk
+    tens = [xq, xkv, wq, wk, wv] + ([fc] if fc is not None else []) + [lg, lb]
+    leaves = [t.double().requires_grad_() for t in tens]
+    if fc is not None:
+        XQ, XKV, WQ, WK, WV, FC, LG, LB = leaves
+    else:
+        (XQ, XKV, WQ, WK, WV, LG, LB), FC = leaves, None
+    split = lambda t, l: t.view(B, l, H, dk).permute(2, 0, 1, 3)  # noqa: E731
+    q, k, v = split(XQ @ WQ.t(), lq), split(XKV @ WK.t(), lk), split(XKV @ WV.t(), lk)
+    s = (q @ k.transpose(-1, -2)) / dk ** 0.5
+    P = torch.softmax(s.masked_fill(blocked, float('-inf')), -1)                     # (H, B, lq, lk)
+    keep_a = N.dropout_keep_mask(H * B * lq * lk, p_attn, s_attn).view(H, B, lq, lk)
+    a = ((P * keep_a / (1 - p_attn)) @ v).permute(1, 2, 0, 3).reshape(B, lq, H * dk)
+    o = a @ FC.t() if FC is not None else a
+    keep_o = N.dropout_keep_mask(B * lq * d, p_out, s_out).view(B, lq, d)
+    ref = F.layer_norm(o * keep_o / (1 - p_out) + XQ, (d,), LG, LB, 1e-5)
+    ref.backward(dy.double())
+
+    dl = [t.to(dev).requires_grad_() for t in tens]
+    mask, keepalive = N.make_mask(blocked.to(dev), B, lq, lk)
+    args = dl[:5] + ([dl[5]] if fc is not None else [None]) + dl[-2:]
+    y, Pm = training._MHAFn.apply(*args, H, mask, keepalive, p_attn, p_out, s_attn, s_out)
+    y.backward(dy.to(dev))
+    assert max_abs_diff(y.detach(), ref.detach()) < 3e-5
+    assert max_abs_diff(Pm.view(H, B, lq, lk), P.detach()) < 1e-5
+    for a_, b_ in zip(dl, leaves):
+        assert max_abs_diff(a_.grad, b_.grad) <= 3e-4 * b_.grad.abs().max().item() + 1e-9

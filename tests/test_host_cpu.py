@@ -139,9 +139,13 @@ def test_product_has_no_cpu_path():
         m((d['src_seq'], d['src_pos']), None, None, None)
     with pytest.raises(RuntimeError, match='HIP device only'):
         m.encoder.layer_stack[0].pos_ffn(torch.zeros(1, 2, 64))
-    m.train()
-    with pytest.raises(NotImplementedError, match='eval-mode'):
+    m.train()  # the training path is HIP-only as well
+    with pytest.raises(RuntimeError, match='HIP device only'):
         m((d['src_seq'], d['src_pos']), None, None, None)
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        m.encoder.layer_stack[0].pos_ffn(torch.zeros(1, 2, 64))
+    with pytest.raises(NotImplementedError, match='eval-mode'):
+        m.tgt_word_proj(torch.zeros(1, 2, 64))
 
 
 def test_out_of_scope_models_raise_at_construction():
