@@ -15,7 +15,7 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
-constexpr int LNB_MAX_WG = 512;
+constexpr int LNB_MAX_WG = 256;
 
 // dz = d/dz LayerNorm(z) . dy, z = x + res;   partial[wg] = [sum_rows dy * zhat | sum_rows dy]  over this WG's rows
 template <int NV>
@@ -100,30 +100,50 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         out[e] = (red[e] + red[2 * d + e]) + (red[4 * d + e] + red[6 * d + e]);
 }
 
-// partial[gy][col] = sum over this row chunk of x[row][col]
+// partial[gy][col] = sum over this row chunk of x[row][col]; eight independent chains per thread keep loads in flight
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t M, int64_t N, int64_t ldx,
                                                              int64_t rows_per_chunk, float* __restrict__ partial) {
     const int64_t col = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (col >= N) return;
     const int64_t r0 = int64_t(blockIdx.y) * rows_per_chunk;
     const int64_t r1 = r0 + rows_per_chunk < M ? r0 + rows_per_chunk : M;
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += x[r * ldx + col];
-    partial[int64_t(blockIdx.y) * N + col] = s;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int64_t r = r0;
+    for (; r + 8 <= r1; r += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += x[(r + u) * ldx + col];
+    }
+    for (int u = 0; r < r1; ++r, ++u) s[u] += x[r * ldx + col];
+    partial[int64_t(blockIdx.y) * N + col] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
-// out_k[c] = sum_p partial[p][k * n_out + c]   for k in {0, 1}: a [P][n_out] or [P][2][n_out] partial buffer
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int P, int64_t n_out,
-                                                              int n_seg, float* __restrict__ out0,
+// out[c] = sum_p partial[p][c] for c in [0, n_total); columns < n_split go to out0, the rest to out1.  A workgroup
+// owns 32 columns; its 8 thread slices each add every 8th partial, and the slices are combined in a fixed order.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int P, int64_t n_total,
+                                                              int64_t n_split, float* __restrict__ out0,
                                                               float* __restrict__ out1) {
-    const int64_t c = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (c >= n_out * n_seg) return;
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partial[int64_t(p) * n_out * n_seg + c];
-    if (c < n_out)
-        out0[c] = s;
-    else
-        out1[c - n_out] = s;
+    __shared__ float red[8][32];
+    const int cx = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int64_t c = int64_t(blockIdx.x) * 32 + cx;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < n_total) {
+        int p = slice;
+        for (; p + 8 < P; p += 16) {
+            s0 += partial[int64_t(p) * n_total + c];
+            s1 += partial[int64_t(p + 8) * n_total + c];
+        }
+        if (p < P) s0 += partial[int64_t(p) * n_total + c];
+    }
+    red[slice][cx] = s0 + s1;
+    __syncthreads();
+    if (slice == 0 && c < n_total) {
+        const float s = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) +
+                        ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
+        if (c < n_split)
+            out0[c] = s;
+        else
+            out1[c - n_split] = s;
+    }
 }
 
 // Counter-based dropout: element e of site `seed` is kept iff mix32(e, seed) >= p * 2^32.  The same call with the
@@ -200,8 +220,8 @@ inline int lnb_grid(int64_t M) {
     return int(n < LNB_MAX_WG ? n : LNB_MAX_WG);
 }
 inline int colsum_chunks(int64_t M) {
-    int64_t c = (M + 127) / 128;
-    return int(c < 1 ? 1 : (c > 256 ? 256 : c));
+    int64_t c = (M + 63) / 64;
+    return int(c < 1 ? 1 : (c > 512 ? 512 : c));
 }
 
 }  // namespace
@@ -229,8 +249,8 @@ int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_
     else
         hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(grid), dim3(256), lds, s, x, res, r_mod, M, d, g, eps, dy, dz, partial);
     if (int e = int(hipGetLastError())) return e;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, s, partial, grid, int64_t(d), 2,
-                       dgamma, dbeta);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * d + 31) / 32), dim3(256), 0, s, partial, grid, int64_t(2 * d),
+                       int64_t(d), dgamma, dbeta);
     return int(hipGetLastError());
 }
 
@@ -247,7 +267,9 @@ int launch_colsum(const float* x, int64_t M, int64_t N, int64_t ldx, float* out,
     float* partial = static_cast<float*>(ws);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)gx, chunks), dim3(256), 0, s, x, M, N, ldx, rows_per_chunk, partial);
     if (int e = int(hipGetLastError())) return e;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)gx), dim3(256), 0, s, partial, chunks, N, 1, out, out);
+    const int64_t gr = (N + 31) / 32;
+    if (gr > 0x7fffffffLL) return LAMP_E_DIMS;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)gr), dim3(256), 0, s, partial, chunks, N, N, out, out);
     return int(hipGetLastError());
 }
 

@@ -102,6 +102,27 @@ def gemm_ab(cfgs=None, rounds=7):
                                                            '*' if med[c] <= best * 1.01 else ' ') for c in cfgs))
 
 
+def gemm_gen():
+    """lamp_gemm (backward-pass GEMM) on the shapes of a reuters training step, every operand layout, next to the
+    tuned forward kernel on the same product where it applies."""
+    dev = torch.device('cuda:0')
+    print('%-34s %10s %10s' % ('product', 'us', 'TFLOP/s'))
+    for M, Nn, K in ((2880, 512, 512), (9664, 512, 512), (31456, 1024, 2048)):
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(Nn, K, device=dev) / K ** 0.5
+        wt = w.t().contiguous()          # (K, Nn): column-stored B operand
+        xt = x.t().contiguous()          # (K, M): column-stored A operand
+        dy = torch.randn(M, Nn, device=dev)
+        cases = [('fwd kernel  x.w^T', lambda: N.linear(x, w), M, Nn, K),
+                 ('gen  row.row     x.w^T', lambda: N.matmul_nt(x, w), M, Nn, K),
+                 ('gen  row.col     x.(wt)', lambda: N.matmul_nt(x, wt.t()), M, Nn, K),
+                 ('gen  col.row     (xt)^T.w^T', lambda: N.matmul_nt(xt.t(), w), M, Nn, K),
+                 ('gen  col.col  wgrad dy^T.x', lambda: N.matmul_nt(dy.t(), x.t()), Nn, K, M)]
+        for name, fn, m_, n_, k_ in cases:
+            us = time_fn(fn, iters=20)
+            print('%-34s %10.1f %10.1f   (%d x %d x %d)' % (name, us, 2.0 * m_ * n_ * k_ / us / 1e6, m_, n_, k_))
+
+
 def steady():
     """K = 512 at growing M: separates per-tile efficiency from launch / tail / quantisation effects."""
     lib = N.lib()
@@ -189,4 +210,4 @@ def attn():
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
-    {'gemm': gemm, 'gemm_ab': gemm_ab, 'attn': attn, 'steady': steady, 'sparse': sparse}[which]()
+    {'gemm': gemm, 'gemm_ab': gemm_ab, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse}[which]()

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Training-step throughput of the HIP path: the reference's train loop body (train.py:34-48) --
+forward in train() mode with dropout, BCE-with-logits, loss.backward(), Adam step -- on one synthetic batch.
+
+    python tools/bench_train.py [--workload reuters] [--batch 32] [--steps 30] [--dropout 0.1] [--cpu]
+
+Prints one JSON line: samples/s of the whole step, the split into forward / backward / optimizer wall time, the
+summed HIP-event kernel time per class (so host overhead = wall - kernels is visible), and with --cpu the same step
+on the oracle's autograd on the host cores (bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--workload', default='reuters', choices=sorted(bench.WORKLOADS))
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--cpu', action='store_true', help='also time the oracle autograd step on the host')
+    a = ap.parse_args()
+    from lamp_amd import _native as N
+    dev = torch.device('cuda:0')
+    w = bench.WORKLOADS[a.workload]
+    model, sd, adj, seq, pos = bench.build(w, a.batch, dev)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = a.dropout
+    seq, pos = seq.to(dev), pos.to(dev)
+    tgt = (torch.rand(a.batch, w['L'], device=dev) < 0.05).float()
+    opt = torch.optim.Adam(model.get_trainable_parameters(), lr=2e-4, betas=(0.9, 0.98), eps=1e-9)
+    model.train()
+
+    def step(timers=None):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        pred, enc, *_ = model((seq, pos), None, None, tgt)
+        loss = F.binary_cross_entropy_with_logits(pred, tgt, reduction='mean')
+        if timers is not None:
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+        loss.backward()
+        if timers is not None:
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+        opt.step()
+        if timers is not None:
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            timers.append((t1 - t0, t2 - t1, t3 - t2))
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    timers = []
+    for _ in range(5):
+        step(timers)
+    fwd, bwd, optim = (sorted(t[i] for t in timers)[2] for i in range(3))
+    N.prof_reset(); N.prof_enable(True)
+    step()
+    torch.cuda.synchronize()
+    N.prof_enable(False)
+    prof = N.prof_read()
+    out = {'metric': 'training samples/sec (forward + backward + Adam), %s' % a.workload, 'value': a.batch / dt,
+           'unit': 'samples/s', 'ms_per_step': dt * 1e3, 'batch': a.batch, 'dropout': a.dropout, 'steps': a.steps,
+           'final_loss': float(loss), 'dtype': 'f32', 'data': 'synthetic',
+           'synchronised_split_ms': {'forward': fwd * 1e3, 'backward': bwd * 1e3, 'optimizer': optim * 1e3},
+           'hip_kernels_one_step': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
+                                        'tflops': round(v['flops'] / v['ms'] / 1e9, 1) if v['ms'] > 0 and v['flops'] else 0.0}
+                                    for k, v in prof.items()},
+           'note': 'only launches bracketed by the library profiler are listed (pointwise backward kernels and torch '
+                   'optimizer kernels are not); wall - kernels = host-side autograd / launch overhead'}
+    if a.cpu:
+        from oracle import lamp_ref as R
+        blocked = R.label_block_mask(adj, w['mask'], w['L'])
+        sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        seq_c, pos_c, tgt_c = seq.cpu(), pos.cpu(), tgt.cpu()
+        torch.set_num_threads(16)
+
+        def cpu_step():
+            lg, _, _ = R.forward(sdg, seq_c, pos_c, w['h'], blocked)
+            F.binary_cross_entropy_with_logits(lg, tgt_c).backward()
+        cpu_step()
+        ts = []
+        while len(ts) < 5:
+            t0 = time.perf_counter(); cpu_step(); ts.append(time.perf_counter() - t0)
+        out['cpu_oracle_autograd'] = {'value': a.batch / sorted(ts)[2], 'unit': 'samples/s', 'threads': 16,
+                                      'sample': '5 forward+backward steps (median), dropout off, no optimizer'}
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
