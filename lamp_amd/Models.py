@@ -138,11 +138,9 @@ class LAMP(nn.Module):
         N.require_device(src_seq, src_pos)
         if self.training:
             # train.py:36: the autograd-recording path (HIP kernels forward and backward, lamp_amd/training.py)
-            if return_attns or int_preds:
-                raise NotImplementedError('training with -attns_loss / -int_preds is not built (SURVEY.md 8f n4)')
             from . import training
-            logits, enc_output = training.forward_train(self, src_seq, src_pos)
-            return logits, enc_output, None
+            return training.forward_train(self, src_seq, src_pos, return_attns=bool(return_attns and not int_preds),
+                                          int_preds=bool(int_preds))
         dev = src_seq.device
         seq = src_seq.long().contiguous()
         pos = src_pos.long().contiguous()

@@ -110,6 +110,7 @@ class _MHAFn(torch.autograd.Function):
         v = N.linear(xkv, wv)
         inv_t = 1.0 / float(dk) ** 0.5
         a, P = N.sdpa_fused(q, k, v, H, mask, inv_t, need_attn=True)
+        Pd = P
         if p_attn > 0:  # the reference drops probabilities AFTER the softmax; the value product uses the dropped map
             Pd = N.dropout(P, p_attn, seed_attn)
             N.matmul_nt(Pd.view(H, B, lq, lk), v.view(B, lk, H, dv).permute(2, 0, 3, 1),
@@ -120,8 +121,9 @@ class _MHAFn(torch.autograd.Function):
         y = N.layernorm_residual(o, xq, ln_g, ln_b)
         ctx.save_for_backward(xq, xkv, wq, wk, wv, fc if fc is not None else wq.new_empty(0), ln_g, q, k, v, a, P, o)
         ctx.cfg = (B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, fc is not None)
-        ctx.mark_non_differentiable(P)
-        return y, P
+        attn = Pd if p_attn > 0 else P.clone()  # what the reference returns (lamp/SubLayers.py:40-43): the dropped map
+        ctx.mark_non_differentiable(attn)
+        return y, attn
 
     @staticmethod
     def backward(ctx, dy, _dP_unused):
@@ -186,31 +188,48 @@ def mha_train(mod, xq, xkv, mask, keep, seeds):
                         float(mod.dropout.p), seeds.next(), seeds.next())
 
 
-def forward_train(model, src_seq, src_pos):
-    """LAMP.forward (lamp/Models.py:110-137) in training mode -> (logits (B, L), enc_output (B, T, d)), both attached
-    to the autograd graph.  The encoder self-attention is skipped: the reference discards its output
-    (lamp/Layers.py:16-18), so its parameters receive no gradient there either."""
+def forward_train(model, src_seq, src_pos, return_attns=False, int_preds=False):
+    """LAMP.forward (lamp/Models.py:110-137) in training mode, attached to the autograd graph; same return tuples as
+    the reference: (logits, enc_output, None) | (..., intermediate_preds) | (..., [enc_attns], [slf_attns, enc_dec]).
+    The encoder self-attention is skipped unless its maps are requested: the reference discards its output
+    (lamp/Layers.py:16-18), so its parameters receive no gradient there either.  Intermediate predictions read out
+    through a detached copy of the projection, as the reference does (lamp/Models.py:129-132)."""
     enc, dec = model.encoder, model.decoder
     seq = src_seq.long().contiguous()
     pos = src_pos.long().contiguous()
     seeds = _Seeds()
+    B, T = seq.shape
+    pad_mask, keep = N.key_token_mask(seq, T)
     pos_w = enc.position_enc.weight if hasattr(enc, 'position_enc') else None
     x = _EmbedFn.apply(seq, pos, enc.src_word_emb.weight, pos_w)
+    enc_attns = []
     for layer in enc.layer_stack:
+        if return_attns:
+            enc_attns.append(mha_train(layer.slf_attn, x, x, pad_mask, keep, seeds)[1])
         x = ffn_train(layer.pos_ffn, x, seeds)
-    B, T = seq.shape
     y = _LabelRowsFn.apply(dec.tgt_word_emb.weight, B)
-    pad_mask, keep = N.key_token_mask(seq, T)
     label_mask = dec.label_mask_struct()
     if label_mask is not None:  # the map-writing attention variant visits every tile
         label_mask = N.Mask(label_mask.kind, 0, label_mask.ptr, label_mask.stride_b, label_mask.stride_q, None, 0)
+    int_outs, slf_attns, enc_dec_attns = [], [], []
     for layer in dec.layer_stack:
-        y, _ = mha_train(layer.enc_attn, y, x, pad_mask, keep, seeds)
+        y, a_enc = mha_train(layer.enc_attn, y, x, pad_mask, keep, seeds)
         y = ffn_train(layer.pos_ffn1, y, seeds)
+        a_slf = None
         if hasattr(layer, 'slf_attn'):
-            y, _ = mha_train(layer.slf_attn, y, y, label_mask, None, seeds)
+            int_outs.append(y)
+            y, a_slf = mha_train(layer.slf_attn, y, y, label_mask, None, seeds)
         y = ffn_train(layer.pos_ffn2, y, seeds)
+        int_outs.append(y)
+        slf_attns.append(a_slf)
+        enc_dec_attns.append(a_enc)
     w_out = model.tgt_word_proj.linear.weight
     if w_out.size(0) != model.n_labels:
         raise NotImplementedError('proj_share_weight=False read-out is not on the graph path')
-    return _ReadoutFn.apply(y, w_out), x
+    logits = _ReadoutFn.apply(y, w_out)
+    if int_preds:
+        w_copy = w_out.detach()
+        return logits, x, [_ReadoutFn.apply(o, w_copy) for o in int_outs[:-1]]
+    if return_attns:
+        return logits, x, [enc_attns], [slf_attns, enc_dec_attns]
+    return logits, x, None

@@ -189,6 +189,56 @@ def test_mha_with_dropout_matches_torch_restatement_with_the_same_masks(dev, H, 
     y, Pm = training._MHAFn.apply(*args, H, mask, keepalive, p_attn, p_out, s_attn, s_out)
     y.backward(dy.to(dev))
     assert max_abs_diff(y.detach(), ref.detach()) < 3e-5
-    assert max_abs_diff(Pm.view(H, B, lq, lk), P.detach()) < 1e-5
+    assert max_abs_diff(Pm.view(H, B, lq, lk), (P * keep_a / (1 - p_attn)).detach()) < 1e-5   # the dropped map
     for a_, b_ in zip(dl, leaves):
         assert max_abs_diff(a_.grad, b_.grad) <= 3e-4 * b_.grad.abs().max().item() + 1e-9
+
+
+def test_int_preds_training_matches_oracle_autograd(dev):
+    """train.py:40-43 (-int_preds): BCE on every intermediate read-out, through a DETACHED copy of the projection."""
+    m, sd, blocked, seq, spos, h, tgt = build(CASES['tiny_prior_h4'], dev)
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    w = sd64['tgt_word_proj.linear.weight']
+    enc_o, _ = R.encoder_forward(sd64, seq, spos, h)
+    y, _, _, int_outs = R.decoder_forward(sd64, seq, enc_o, blocked, h, None, False, True)
+    ref_logits = R.readout(y, w)
+    ref_int = [R.readout(o, w.detach()) for o in int_outs[:-1]]   # detached copy, lamp/Models.py:129
+    loss_ref = F.binary_cross_entropy_with_logits(ref_logits, tgt.double())
+    for ip in ref_int:
+        loss_ref = loss_ref + 0.2 * F.binary_cross_entropy_with_logits(ip.reshape(tgt.shape), tgt.double())
+    loss_ref.backward()
+    m.train()
+    pred, enc, ipreds = m((seq.to(dev), spos.to(dev)), None, None, tgt.to(dev), int_preds=True)
+    assert len(ipreds) == len(ref_int) == 3
+    loss = F.binary_cross_entropy_with_logits(pred, tgt.to(dev))
+    for ip in ipreds:
+        loss = loss + 0.2 * F.binary_cross_entropy_with_logits(ip, tgt.to(dev))
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-5
+    for pname, p in m.named_parameters():
+        ref = sd64[pname].grad
+        if p.grad is None:
+            continue
+        scale = ref.abs().max().item()
+        assert max_abs_diff(p.grad, ref) <= 3e-4 * scale + 1e-9, pname
+
+
+def test_return_attns_in_training_mode(dev):
+    """train.py:36 with -attns_loss: the maps come back in the reference's structure; with dropout they are the
+    DROPPED maps the reference returns (lamp/SubLayers.py:40-43)."""
+    m, sd, blocked, seq, spos, h, tgt = build(CASES['tiny_prior_h4'], dev, dropout=0.0)
+    m.train()
+    pred, enc, enc_attns, dec_attns = m((seq.to(dev), spos.to(dev)), None, None, None, return_attns=True)
+    ref = R.forward(sd, seq, spos, h, blocked, return_attns=True)
+    assert max_abs_diff(pred.detach(), ref[0]) < 1e-4
+    for got, want in zip(enc_attns[0], ref[2][0]):
+        assert max_abs_diff(got, want) < 1e-5
+    for k in (0, 1):
+        for got, want in zip(dec_attns[k], ref[3][k]):
+            assert max_abs_diff(got, want) < 1e-5
+    pred.sum().backward()   # graph is intact with the maps attached
+    m2 = build(CASES['tiny_prior_h4'], dev, dropout=0.5)[0]
+    m2.train()
+    _, _, _, dec_attns2 = m2((seq.to(dev), spos.to(dev)), None, None, None, return_attns=True)
+    frac_zero = (dec_attns2[1][0] == 0).float().mean().item()
+    assert 0.3 < frac_zero < 0.9     # about half the unblocked entries are dropped, the rest scaled by 2
