@@ -4,6 +4,7 @@
 # Writes into gpurun_out/<tag>/ ; copy what should be judged into profiles/ afterwards.
 set -u
 TAG=${1:-rXX}
+REPO=$PWD
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -24,4 +25,8 @@ BENCH="python $PWD/bench.py --no-cpu-baseline --no-pipelined"
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o p -f csv -- $BENCH --steps 5 --warmup 3 > /dev/null 2>&1 )
 done
+python tools/bench_train.py --cpu > "$OUT/train_reuters.json" 2>/dev/null
+python tools/bench_train.py --workload delicious --steps 5 --warmup 2 > "$OUT/train_delicious.json" 2>/dev/null
+python tools/bench_kernels.py gemm_gen 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_gen.txt"
+( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/train_stats" -o p -f csv -- python $REPO/tools/bench_train.py --steps 20 > /dev/null 2>&1 )
 ls -R "$OUT" | head -40

@@ -45,6 +45,11 @@ def main():
     cp('attn_variants.txt', 'attn_variants.txt')
     cp('sparse_label_attention.txt', 'sparse_label_attention.txt')
     cp('stats/p_kernel_stats.csv', 'bench_kernel_stats.csv')
+    for f in ('train_reuters.json', 'train_delicious.json', 'gemm_gen.txt'):
+        if os.path.exists(os.path.join(src, f)):
+            cp(f, f)
+    if os.path.exists(os.path.join(src, 'train_stats/p_kernel_stats.csv')):
+        cp('train_stats/p_kernel_stats.csv', 'train_kernel_stats.csv')
 
     disp, dur = load_pmc(os.path.join(src, 'pmc_sq'))
     L = ['# One forward (reuters, batch 32) under rocprofv3 --pmc (SQ counters; kernels run serialized and ~4 % slower under the profiler).',
