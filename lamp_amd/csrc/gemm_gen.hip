@@ -16,10 +16,12 @@ namespace lamp {
 
 namespace {
 
-constexpr int GM = 64, GN = 64, GK = 16;  // block tile; 4 waves as 2 x 2, each 32 x 32 = 2 x 2 MFMA blocks
-constexpr int S_ROW = GK + 4;             // LDS row stride of a row operand   [64][20]
-constexpr int S_COL = GM + 4;             // LDS row stride of a column operand [16][68]
-constexpr int LDS_OPERAND = 64 * S_ROW > GK * S_COL ? 64 * S_ROW : GK * S_COL;
+constexpr int GK = 16;        // k-tile
+constexpr int S_ROW = GK + 4;  // LDS row stride of a row operand   [rows][20]
+// Block tiles (4 waves): 64 x 64 as 2 x 2 waves of 32 x 32 (2 x 2 MFMA blocks), and -- for the M = B*L shapes that
+// would leave SIMDs idle, exactly as in the forward menu -- 32 x 64 as 1 x 4 waves of 32 x 16 (2 x 1 blocks).
+// A column operand of R rows is staged as [16][R + 4].
+constexpr int lds_operand(int rows) { return rows * S_ROW > GK * (rows + 4) ? rows * S_ROW : GK * (rows + 4); }
 
 struct Operand {
     const float* p;
@@ -42,9 +44,10 @@ struct GenParams {
     float* part;        // split-K partials [nsplit][M][N], or nullptr
 };
 
-// One thread stages one float4 of each operand per k-tile.
-template <bool COL>
+// One thread stages (at most) one float4 of each operand per k-tile; ROWS = the operand's tile extent (32 or 64).
+template <bool COL, int ROWS>
 __device__ __forceinline__ float4 stage_load(__amdgpu_buffer_rsrc_t rs, int tid, int k0, int k_end, int64_t ld, bool vec) {
+    if (ROWS < 64 && tid >= ROWS * 4) return make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (!COL) {
         const int row = tid >> 2, k = k0 + 4 * (tid & 3);
         const unsigned off = unsigned(row * int(ld) + k) * 4u;
@@ -56,7 +59,8 @@ __device__ __forceinline__ float4 stage_load(__amdgpu_buffer_rsrc_t rs, int tid,
         v.w = bload1(rs, k + 3 < k_end ? off + 12u : OOB);
         return v;
     } else {
-        const int krow = k0 + (tid >> 4), c = 4 * (tid & 15);
+        constexpr int V4 = ROWS / 4;  // float4 per k-row
+        const int krow = k0 + tid / V4, c = 4 * (tid % V4);
         const unsigned off = krow < k_end ? unsigned(krow * int(ld) + c) * 4u : OOB;
         if (vec) return bload4(rs, off, 0);
         float4 v;  // columns past the tile edge only feed output rows that are never stored
@@ -68,33 +72,37 @@ __device__ __forceinline__ float4 stage_load(__amdgpu_buffer_rsrc_t rs, int tid,
     }
 }
 
-template <bool COL>
+template <bool COL, int ROWS>
 __device__ __forceinline__ void stage_store(float* lds, int tid, float4 v) {
+    if (ROWS < 64 && tid >= ROWS * 4) return;
     if constexpr (!COL)
         *reinterpret_cast<float4*>(lds + (tid >> 2) * S_ROW + 4 * (tid & 3)) = v;
     else
-        *reinterpret_cast<float4*>(lds + (tid >> 4) * S_COL + 4 * (tid & 15)) = v;
+        *reinterpret_cast<float4*>(lds + (tid / (ROWS / 4)) * (ROWS + 4) + 4 * (tid % (ROWS / 4))) = v;
 }
 
 // Fragment of one 16-row MFMA block: the 4 k-values {4*hi + j} of row `row` (tile-local).
-template <bool COL>
+template <bool COL, int ROWS>
 __device__ __forceinline__ float4 frag(const float* lds, int row, int hi) {
     if constexpr (!COL) return *reinterpret_cast<const float4*>(lds + row * S_ROW + 4 * hi);
+    constexpr int S = ROWS + 4;
     float4 v;
-    const float* q = lds + (4 * hi) * S_COL + row;
+    const float* q = lds + (4 * hi) * S + row;
     v.x = q[0];
-    v.y = q[S_COL];
-    v.z = q[2 * S_COL];
-    v.w = q[3 * S_COL];
+    v.y = q[S];
+    v.z = q[2 * S];
+    v.w = q[3 * S];
     return v;
 }
 
-template <bool TA, bool TB>
+template <int GM, int GN, int WM, int WN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) float As[2][LDS_OPERAND];
-    __shared__ __attribute__((aligned(16))) float Bs[2][LDS_OPERAND];
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int WTM = GM / WM, WTN = GN / WN, MI = WTM / 16, NI = WTN / 16;
+    __shared__ __attribute__((aligned(16))) float As[2][lds_operand(GM)];
+    __shared__ __attribute__((aligned(16))) float Bs[2][lds_operand(GN)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, hi = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN, l15 = lane & 15, hi = lane >> 4;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * GM, n0 = tn * GN;
@@ -117,45 +125,45 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n)
         TB ? make_rsrc(Bz + n0, (uint64_t(k_end - 1) * ldb + rows_n) * 4u)
            : make_rsrc(Bz + int64_t(n0) * ldb, (uint64_t(rows_n - 1) * ldb + p.K) * 4u);
 
-    f32x4 acc[2][2];
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (k_end - k_begin + GK - 1) / GK;
-    float4 ra = stage_load<TA>(rsA, tid, k_begin, k_end, lda, p.vecA);
-    float4 rb = stage_load<TB>(rsB, tid, k_begin, k_end, ldb, p.vecB);
-    stage_store<TA>(As[0], tid, ra);
-    stage_store<TB>(Bs[0], tid, rb);
+    float4 ra = stage_load<TA, GM>(rsA, tid, k_begin, k_end, lda, p.vecA);
+    float4 rb = stage_load<TB, GN>(rsB, tid, k_begin, k_end, ldb, p.vecB);
+    stage_store<TA, GM>(As[0], tid, ra);
+    stage_store<TB, GN>(Bs[0], tid, rb);
     if (nk > 1) {
-        ra = stage_load<TA>(rsA, tid, k_begin + GK, k_end, lda, p.vecA);
-        rb = stage_load<TB>(rsB, tid, k_begin + GK, k_end, ldb, p.vecB);
+        ra = stage_load<TA, GM>(rsA, tid, k_begin + GK, k_end, lda, p.vecA);
+        rb = stage_load<TB, GN>(rsB, tid, k_begin + GK, k_end, ldb, p.vecB);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        float4 fa[2], fb[2];
+        float4 fa[MI], fb[NI];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = frag<TA>(As[buf], wm * 32 + 16 * i + l15, hi);
+        for (int i = 0; i < MI; ++i) fa[i] = frag<TA, GM>(As[buf], wm * WTM + 16 * i + l15, hi);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = frag<TB>(Bs[buf], wn * 32 + 16 * j + l15, hi);
+        for (int j = 0; j < NI; ++j) fb[j] = frag<TB, GN>(Bs[buf], wn * WTN + 16 * j + l15, hi);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NI; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
             }
         if (kt + 1 < nk) {
-            stage_store<TA>(As[buf ^ 1], tid, ra);
-            stage_store<TB>(Bs[buf ^ 1], tid, rb);
+            stage_store<TA, GM>(As[buf ^ 1], tid, ra);
+            stage_store<TB, GN>(Bs[buf ^ 1], tid, rb);
         }
         if (kt + 2 < nk) {
-            ra = stage_load<TA>(rsA, tid, k_begin + (kt + 2) * GK, k_end, lda, p.vecA);
-            rb = stage_load<TB>(rsB, tid, k_begin + (kt + 2) * GK, k_end, ldb, p.vecB);
+            ra = stage_load<TA, GM>(rsA, tid, k_begin + (kt + 2) * GK, k_end, lda, p.vecA);
+            rb = stage_load<TB, GN>(rsB, tid, k_begin + (kt + 2) * GK, k_end, ldb, p.vecB);
         }
         __syncthreads();
     }
@@ -165,13 +173,13 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n)
         float* base = p.part + (int64_t(split) * p.M + m0) * p.N + n0;
         const __amdgpu_buffer_rsrc_t rsP = make_rsrc(base, (uint64_t(rows_m - 1) * p.N + rows_n) * 4u);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = wn * 32 + 16 * j + l15;
+            for (int j = 0; j < NI; ++j) {
+                const int col = wn * WTN + 16 * j + l15;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = wm * 32 + 16 * i + 4 * hi + r;
+                    const int row = wm * WTM + 16 * i + 4 * hi + r;
                     bstore1(rsP, col < rows_n ? unsigned(row * p.N + col) * 4u : OOB, acc[i][j][r]);
                 }
             }
@@ -184,14 +192,14 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n)
     const __amdgpu_buffer_rsrc_t rsM =
         make_rsrc(has_m ? p.mask + int64_t(m0) * p.ldm + n0 : Cz, has_m ? (uint64_t(rows_m - 1) * ldm + rows_n) * 4u : 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = wn * 32 + 16 * j + l15;
+        for (int j = 0; j < NI; ++j) {
+            const int col = wn * WTN + 16 * j + l15;
             const bool ok = col < rows_n;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = wm * 32 + 16 * i + 4 * hi + r;
+                const int row = wm * WTM + 16 * i + 4 * hi + r;
                 float v = p.alpha * acc[i][j][r];
                 if (has_m && !(bload1(rsM, ok ? unsigned(row * ldm + col) * 4u : OOB) > 0.f)) v = 0.f;
                 const unsigned off = ok ? unsigned(row * ldc + col) * 4u : OOB;
@@ -218,14 +226,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace
 
-size_t gemm_gen_workspace_bytes(int M, int N, int K, int batch) {
-    // room for the deepest split the launcher may choose
-    if (batch != 1) return 0;
-    const int64_t tiles = int64_t((M + GM - 1) / GM) * ((N + GN - 1) / GN);
-    if (tiles >= 512 || K < 1024) return 0;
+namespace {
+// tile choice and split-K depth: functions of the problem shape only
+inline int pick_splits(int M, int N, int K, int64_t batch, int gm);
+inline int pick_gm(int M, int N, int K, int64_t batch) {
+    const int64_t t64 = int64_t((M + 63) / 64) * ((N + 63) / 64) * batch;
+    if (pick_splits(M, N, K, batch, 64) > 1) return 64;  // deep-K weight gradients: parallelism comes from the K split
+    return t64 < 1200 ? 32 : 64;
+}
+inline int pick_splits(int M, int N, int K, int64_t batch, int gm) {
+    const int64_t tiles = int64_t((M + gm - 1) / gm) * ((N + 63) / 64);
+    if (batch != 1 || tiles >= 512 || K < 1024) return 1;
     int64_t ns = (1024 + tiles - 1) / tiles;
     if (ns > K / 256) ns = K / 256;
     if (ns > 64) ns = 64;
+    return ns < 2 ? 1 : int(ns);
+}
+}  // namespace
+
+size_t gemm_gen_workspace_bytes(int M, int N, int K, int batch) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch < 1) return 0;
+    const int ns = pick_splits(M, N, K, batch, pick_gm(M, N, K, batch));
     return ns < 2 ? 0 : size_t(ns) * M * N * sizeof(float);
 }
 
@@ -237,10 +258,10 @@ int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStrea
     const int64_t lda = ta ? d.a_col_stride : d.a_row_stride, ldb = tb ? d.b_col_stride : d.b_row_stride;
     if (lda < 1 || ldb < 1 || d.ldc < d.N) return LAMP_E_DIMS;
     // 32-bit in-tile byte offsets
-    const int64_t span_a = ta ? int64_t(d.K) * lda : int64_t(GM) * lda + d.K;
-    const int64_t span_b = tb ? int64_t(d.K) * ldb : int64_t(GN) * ldb + d.K;
-    if (span_a * 4 >= 0x7fffffffLL || span_b * 4 >= 0x7fffffffLL || int64_t(GM) * d.ldc * 4 >= 0x7fffffffLL ||
-        (d.relu_mask && int64_t(GM) * d.ld_mask * 4 >= 0x7fffffffLL))
+    const int64_t span_a = ta ? int64_t(d.K) * lda : int64_t(64) * lda + d.K;
+    const int64_t span_b = tb ? int64_t(d.K) * ldb : int64_t(64) * ldb + d.K;
+    if (span_a * 4 >= 0x7fffffffLL || span_b * 4 >= 0x7fffffffLL || int64_t(64) * d.ldc * 4 >= 0x7fffffffLL ||
+        (d.relu_mask && int64_t(64) * d.ld_mask * 4 >= 0x7fffffffLL))
         return LAMP_E_UNSUPPORTED;
     const int64_t batch = int64_t(d.batch0) * d.batch1;
     if (batch > 65535) return LAMP_E_DIMS;
@@ -270,35 +291,42 @@ int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStrea
     p.k_chunk = d.K;
     p.part = nullptr;
 
-    const int tiles_m = (d.M + GM - 1) / GM, tiles_n = (d.N + GN - 1) / GN;
+    const int gm = pick_gm(d.M, d.N, d.K, batch);
+    const int tiles_m = (d.M + gm - 1) / gm, tiles_n = (d.N + 63) / 64;
     const int64_t tiles = int64_t(tiles_m) * tiles_n;
     if (tiles > 0x7fffffffLL) return LAMP_E_DIMS;
-    int nsplit = 1;
-    if (batch == 1 && tiles < 512 && d.K >= 1024 && ws) {
-        int64_t ns = (1024 + tiles - 1) / tiles;
-        if (ns > d.K / 256) ns = d.K / 256;
-        if (ns > 64) ns = 64;
-        const int64_t fit = int64_t(ws_bytes / (size_t(d.M) * d.N * sizeof(float)));
-        if (ns > fit) ns = fit;
-        if (ns >= 2) {
-            nsplit = int(ns);
+    int nsplit = pick_splits(d.M, d.N, d.K, batch, gm);
+    if (nsplit > 1) {
+        const int64_t fit = ws ? int64_t(ws_bytes / (size_t(d.M) * d.N * sizeof(float))) : 0;
+        if (nsplit > fit) nsplit = int(fit);
+        if (nsplit >= 2) {
             p.k_chunk = ((d.K + nsplit - 1) / nsplit + GK - 1) / GK * GK;
             nsplit = (d.K + p.k_chunk - 1) / p.k_chunk;
             p.part = static_cast<float*>(ws);
+        } else {
+            nsplit = 1;
         }
     }
     const double flops = 2.0 * double(d.M) * d.N * d.K * double(batch);
     const double bytes = 4.0 * double(batch) * (double(d.M) * d.K + double(d.N) * d.K + double(d.M) * d.N);
     ProfScope prof(LAMP_K_GEMM, flops, bytes, s);
     const dim3 grid((unsigned)tiles, (unsigned)batch, (unsigned)nsplit);
-    if (ta && tb)
-        hipLaunchKernelGGL((gemm_gen_kernel<true, true>), grid, dim3(256), 0, s, p, tiles_n);
-    else if (ta)
-        hipLaunchKernelGGL((gemm_gen_kernel<true, false>), grid, dim3(256), 0, s, p, tiles_n);
-    else if (tb)
-        hipLaunchKernelGGL((gemm_gen_kernel<false, true>), grid, dim3(256), 0, s, p, tiles_n);
+#define LAMP_GEN_LAUNCH(GM_, WM_, WN_)                                                                               \
+    do {                                                                                                              \
+        if (ta && tb)                                                                                                 \
+            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, true, true>), grid, dim3(256), 0, s, p, tiles_n);   \
+        else if (ta)                                                                                                  \
+            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, true, false>), grid, dim3(256), 0, s, p, tiles_n);  \
+        else if (tb)                                                                                                  \
+            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, false, true>), grid, dim3(256), 0, s, p, tiles_n);  \
+        else                                                                                                          \
+            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, false, false>), grid, dim3(256), 0, s, p, tiles_n); \
+    } while (0)
+    if (gm == 32)
+        LAMP_GEN_LAUNCH(32, 1, 4);
     else
-        hipLaunchKernelGGL((gemm_gen_kernel<false, false>), grid, dim3(256), 0, s, p, tiles_n);
+        LAMP_GEN_LAUNCH(64, 2, 2);
+#undef LAMP_GEN_LAUNCH
     if (int e = int(hipGetLastError())) return e;
     if (p.part) {
         const int64_t total = int64_t(d.M) * d.N;
