@@ -242,3 +242,34 @@ def test_return_attns_in_training_mode(dev):
     _, _, _, dec_attns2 = m2((seq.to(dev), spos.to(dev)), None, None, None, return_attns=True)
     frac_zero = (dec_attns2[1][0] == 0).float().mean().item()
     assert 0.3 < frac_zero < 0.9     # about half the unblocked entries are dropped, the rest scaled by 2
+
+
+def test_full_size_reuters_step_with_dropout(dev):
+    """BASELINE's reuters shape (V=23666, L=90, T=302, d=512, 4 heads, prior mask), dropout 0.1: every trainable
+    parameter but the dead encoder self-attention gets a finite gradient, the step is reproducible under
+    torch.manual_seed, and bias / LayerNorm gradients are deterministic (fixed-order reductions)."""
+    cfg = (23666, 90, 302, 512, 512, 4, 'prior', True, 8, 0.1, None)
+    m, sd, blocked, seq, spos, h, tgt = build(cfg, dev, dropout=0.1)
+    m.train()
+
+    def run(seed):
+        torch.manual_seed(seed)
+        m.zero_grad(set_to_none=True)
+        pred, enc, _ = m((seq.to(dev), spos.to(dev)), None, None, tgt.to(dev))
+        loss = F.binary_cross_entropy_with_logits(pred, tgt.to(dev))
+        loss.backward()
+        return loss.item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    l1, g1 = run(3)
+    l2, g2 = run(3)
+    l3, _ = run(4)
+    assert l1 == l2 and l1 != l3
+    trainable = {n for n, p in m.named_parameters()
+                 if not ('encoder.layer_stack' in n and 'slf_attn' in n) and n != 'encoder.position_enc.weight'}
+    assert set(g1) == trainable
+    for n in trainable:
+        assert torch.isfinite(g1[n]).all(), n
+        if n != 'encoder.src_word_emb.weight':      # the embedding scatter-add uses atomics (order may vary)
+            assert torch.equal(g1[n], g2[n]), n
+        else:
+            assert max_abs_diff(g1[n], g2[n]) < 1e-6
+    assert (g1['encoder.src_word_emb.weight'][0] == 0).all()   # PAD row
