@@ -341,6 +341,8 @@ int lamp_diag_logits_fwd(const float* y, const float* w_out, int32_t B, int32_t 
     return launch_diag(y, w_out, B, L, d_model, logits, hipStream_t(stream));
 }
 
+static_assert(sizeof(lamp_gemm_desc) == 160, "lamp_gemm_desc layout is part of the ABI");
+
 size_t lamp_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t batch) {
     return gemm_gen_workspace_bytes(M, N, K, batch);
 }

@@ -43,6 +43,7 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(N.DecLayer) == 208
     assert ctypes.sizeof(N.Model) == 120
     assert ctypes.sizeof(N.Aux) == 40
+    assert ctypes.sizeof(N.GemmDesc) == 160
 
 
 def build_from_fixture(name):
