@@ -77,7 +77,7 @@ def main():
     prof = N.prof_read()
     out = {'metric': 'training samples/sec (forward + backward + Adam), %s' % a.workload, 'value': a.batch / dt,
            'unit': 'samples/s', 'ms_per_step': dt * 1e3, 'batch': a.batch, 'dropout': a.dropout, 'steps': a.steps,
-           'final_loss': float(loss), 'dtype': 'f32', 'data': 'synthetic',
+           'final_loss': float(loss.detach()), 'dtype': 'f32', 'data': 'synthetic',
            'synchronised_split_ms': {'forward': fwd * 1e3, 'backward': bwd * 1e3, 'optimizer': optim * 1e3},
            'hip_kernels_one_step': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
                                         'tflops': round(v['flops'] / v['ms'] / 1e9, 1) if v['ms'] > 0 and v['flops'] else 0.0}
