@@ -6,9 +6,10 @@ run ``model(src, adj, None, None)`` on the MI355X, sigmoid + BCE-with-logits on 
 (lamp_sigmoid_bce_fwd), gold-binary targets on the host.
 
 Unlike the reference, which pulls every batch's predictions to the CPU before starting the next forward
-(test.py:49-56), results stay on the device until the end of the epoch; with ``streams=2`` consecutive
-batches are issued on alternating HIP streams, so one batch's launch gaps / kernel tails are filled by the
-next batch's kernels (the batch-32 forward is a chain of ~40 short kernels: +23 % samples/s measured).
+(test.py:49-56), results stay on the device until the end of the epoch; with ``streams=n`` consecutive
+batches are issued round-robin on n HIP streams, so one batch's kernel ramps / tails are filled by the
+other batches' kernels (the batch-32 forward is a chain of ~35 short kernels: 38k -> 46k / 50k samples/s with
+2 / 4 batches in flight on reuters).
 Each sample's numbers are identical in every mode.
 """
 import torch

@@ -42,7 +42,7 @@ def parse(argv=None):
     ap.add_argument('-no_dec_self_att', action='store_true')
     ap.add_argument('-no_enc_pos_embedding', action='store_true')
     ap.add_argument('-br_threshold', type=float, default=0.5)
-    ap.add_argument('-streams', type=int, default=1, choices=[1, 2], help='batches in flight (HIP streams)')
+    ap.add_argument('-streams', type=int, default=2, choices=[1, 2, 3, 4], help='batches in flight (HIP streams)')
     ap.add_argument('-seed', type=int, default=0, help='weight init seed when no checkpoint is given')
     opt = ap.parse_args(argv)
     if opt.n_layers_dec is None:
