@@ -58,3 +58,23 @@ def test_reference_main_reaches_our_forward_through_the_shim(tmp_path):
     assert 'reference/test.py", line 41' in err          # reached the hot-path call site of the eval loop
     assert os.path.join('lamp_amd', 'Models.py') in err   # ... inside OUR LAMP.forward, not the reference's
     assert 'reference/lamp/' not in err                   # the reference's own lamp package was never imported
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REF, 'main.py')), reason='reference not present')
+def test_reference_training_loop_reaches_our_training_forward(tmp_path):
+    """Same, without -test_only: main.py -> runner.run_model -> train_epoch's `model(src, adj, None, gold_binary, ...)`
+    (train.py:36) in train() mode, i.e. the autograd-recording path of lamp_amd/training.py."""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1',
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, 'dropin'), ROOT, REF]))
+    r = subprocess.run([sys.executable, '-c', MAKE_DATA], cwd=tmp_path, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # train.py:34 hard-codes `.cuda()` on the targets; on this GPU-less box make it a no-op so the loop gets to line 36
+    script = RUN_MAIN.replace("'-test_only', ", "'-epoch', '1', ").replace(
+        "sys.argv = [", "torch.Tensor.cuda = lambda self, *a, **k: self\nsys.argv = [")
+    r = subprocess.run([sys.executable, '-c', script], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    err = r.stderr
+    assert r.returncode != 0
+    assert 'lamp_amd runs on an MI355X HIP device only' in err, err[-3000:]
+    assert 'reference/train.py", line 36' in err
+    assert os.path.join('lamp_amd', 'Models.py') in err
+    assert 'reference/lamp/' not in err
