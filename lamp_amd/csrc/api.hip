@@ -203,6 +203,29 @@ static int project_kv(const float* xkv, int64_t Mk, int d, int dk, int dv, const
     return linear(xkv, Mk, d, d, Wv, 1, hdv, d, nullptr, nullptr, 0, 0, Cv, hdv, s);
 }
 
+// K and V projections of the first n decoder layers' enc-attention from the same encoder output: ONE launch when the
+// 2n weight matrices fit the GEMM's segment list (n <= 2) -- 4 x more tiles per launch than layer by layer.
+static int project_kv_layers(const float* x, int64_t Me, int d, int dk, int dv, const lamp_dec_layer* layers, int n,
+                             float* const* K, float* const* V, hipStream_t s) {
+    const int h = layers[0].enc_attn.n_head;
+    bool uniform = 2 * n <= GEMM_MAX_SEG && h * dk == h * dv;
+    for (int i = 1; i < n && uniform; ++i) uniform = layers[i].enc_attn.n_head == h;
+    if (uniform) {
+        const float* W[GEMM_MAX_SEG];
+        float* C[GEMM_MAX_SEG];
+        for (int i = 0; i < n; ++i) {
+            if (!layers[i].enc_attn.w_ks || !layers[i].enc_attn.w_vs) return LAMP_E_NULL;
+            W[2 * i] = layers[i].enc_attn.w_ks;
+            W[2 * i + 1] = layers[i].enc_attn.w_vs;
+            C[2 * i] = K[i];
+            C[2 * i + 1] = V[i];
+        }
+        return linear(x, Me, d, d, W, 2 * n, h * dk, d, nullptr, nullptr, 0, 0, C, h * dk, s);
+    }
+    for (int i = 0; i < n; ++i) LAMP_CK(project_kv(x, Me, d, dk, dv, layers[i].enc_attn, K[i], V[i], s));
+    return 0;
+}
+
 // PositionwiseFeedForward.forward (lamp/SubLayers.py:133-142); out may alias x.
 static int ffn_core(const float* x, int64_t M, int d, int dff, const lamp_ffn_weights& w, float* out,
                     float* hidden, hipStream_t s, const float* w_out = nullptr, int n_labels = 0,
@@ -493,11 +516,12 @@ int side_state(SideState** out) {
 // results are bit-identical to the one-stream order.
 static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* src_seq, const int64_t* src_pos,
                          int32_t B, int32_t T, float* logits, float* enc_output, const lamp_aux* aux,
-                         void* workspace, size_t workspace_bytes, hipStream_t s, SideState* side) {
+                         void* workspace, size_t workspace_bytes, hipStream_t s, SideState* side, bool kv_ahead) {
     const bool want_enc_attn = aux && aux->enc_self_attn;
     const int d = m->d_model, dff = m->d_inner, dk = m->d_k, dv = m->d_v, L = m->n_labels;
-    const int n_ahead = side ? m->n_layers_dec : 0;  // layers whose enc K/V are projected before the decoder starts
-    const size_t per_sample = pl.per_sample_floats + (side ? pl.side_kv_floats : 0);
+    // layers whose enc K/V are projected (together) before the decoder starts
+    const int n_ahead = (side || kv_ahead) ? m->n_layers_dec : 0;
+    const size_t per_sample = pl.per_sample_floats + (n_ahead ? pl.side_kv_floats : 0);
     const size_t ws_floats = workspace_bytes / sizeof(float);
     if (ws_floats < pl.fixed_floats + per_sample) return LAMP_E_WORKSPACE;
     int64_t mb = int64_t((ws_floats - pl.fixed_floats) / per_sample);
@@ -611,9 +635,8 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             return 0;
         };
 
-        if (n_ahead > 0 && nb >= 2) {
-            for (int i = 0; i < n_ahead; ++i)
-                LAMP_CK(project_kv(x, Me, d, dk, dv, m->dec_layers[i].enc_attn, Kahead[i], Vahead[i], s));
+        if (n_ahead > 0 && side && nb >= 2) {
+            LAMP_CK(project_kv_layers(x, Me, d, dk, dv, m->dec_layers, n_ahead, Kahead, Vahead, s));
             hipError_t e;
             if ((e = hipEventRecord(side->fork, s)) != hipSuccess) return int(e);
             if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return int(e);
@@ -627,8 +650,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             if (e1 != hipSuccess) return int(e1);
             if (e2 != hipSuccess) return int(e2);
         } else if (n_ahead > 0) {
-            for (int i = 0; i < n_ahead; ++i)
-                LAMP_CK(project_kv(x, Me, d, dk, dv, m->dec_layers[i].enc_attn, Kahead[i], Vahead[i], s));
+            LAMP_CK(project_kv_layers(x, Me, d, dk, dv, m->dec_layers, n_ahead, Kahead, Vahead, s));
             LAMP_CK(decoder_range(0, nb, s));
         } else {
             LAMP_CK(decoder_range(0, nb, s));
@@ -662,7 +684,13 @@ int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src
         const size_t need = (pl.fixed_floats + pl.per_sample_floats + pl.side_kv_floats) * sizeof(float);
         if (workspace_bytes >= need) LAMP_CK(side_state(&side));
     }
-    return forward_range(m, pl, src_seq, src_pos, B, T, logits, enc_output, aux, workspace, workspace_bytes, s, side);
+    // One launch for every decoder layer's enc-attention K/V projection (they all read the finished encoder output)
+    // when the whole batch still fits the workspace with the extra K/V buffers and the weights fit one segment list.
+    const bool kv_ahead = 2 * m->n_layers_dec <= GEMM_MAX_SEG && m->n_layers_dec > 1 && m->n_layers_dec <= MAX_SIDE_EVENTS &&
+                          workspace_bytes >= (pl.fixed_floats + (pl.per_sample_floats + pl.side_kv_floats) * size_t(B) +
+                                              size_t(64) * (8 + 2 * m->n_layers_dec)) * sizeof(float);
+    return forward_range(m, pl, src_seq, src_pos, B, T, logits, enc_output, aux, workspace, workspace_bytes, s, side,
+                         kv_ahead);
 }
 
 // ------------------------------------------------------------------ profiling ABI
