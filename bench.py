@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
 
+RAGGED = {'reuters': (20, 302), 'bibtex': (10, 150), 'delicious': (5, 60)}  # SURVEY.md 8d length variant (ii)
 WORKLOADS = {
     # name: V, L, T, d, d_ff, heads, label_mask, pos_emb, prior p
     'reuters': dict(V=23666, L=90, T=302, d=512, dff=512, h=4, mask='prior', pos=True, p=0.10),
@@ -49,14 +50,15 @@ def f_live(w, n_enc=2, n_dec=2):
             n_dec * (8 * L * d * d + 4 * L * L * d) + n_dec * 8 * L * d * dff + 2 * L * d)
 
 
-def build(w, batch, device, seed=0):
+def build(w, batch, device, seed=0, lengths=None):
     from lamp_amd import synthetic as R
     from lamp_amd.Models import LAMP
-    sd = R.make_state_dict(w['V'], w['L'], w['T'], w['d'], w['dff'], w['h'], 2, 2, pos_emb=w['pos'], seed=seed)
+    n_max = max([w['T']] + list(lengths or []))
+    sd = R.make_state_dict(w['V'], w['L'], n_max, w['d'], w['dff'], w['h'], 2, 2, pos_emb=w['pos'], seed=seed)
     adj = R.make_adjacency(w['L'], w['p'], seed) if w['mask'] == 'prior' else None
-    seq, pos = R.make_batch(batch, w['V'], w['T'], seed=seed)
+    seq, pos = R.make_batch(batch, w['V'], w['T'], lengths=lengths, seed=seed)
     h, d = w['h'], w['d']
-    model = LAMP(w['V'], w['L'], w['T'], w['L'], n_layers_enc=2, n_layers_dec=2, n_head=h, n_head2=h,
+    model = LAMP(w['V'], w['L'], n_max, w['L'], n_layers_enc=2, n_layers_dec=2, n_head=h, n_head2=h,
                  d_word_vec=d, d_model=d, d_inner_hid=w['dff'], d_k=d // h, d_v=d // h, encoder='graph',
                  decoder='graph', no_enc_pos_embedding=not w['pos'],
                  label_adj_matrix=adj.clone() if adj is not None else None, label_mask=w['mask'],
@@ -127,6 +129,9 @@ def main():
     ap.add_argument('--no-pipelined', action='store_true',
                     help='skip the extra two-batches-in-flight measurement (use under rocprofv3: overlapping '
                          'kernels inflate per-kernel durations)')
+    ap.add_argument('--ragged', action='store_true',
+                    help='sequence lengths U{lo..hi} padded to the batch maximum (SURVEY.md 8d variant ii) instead of fixed T')
+    ap.add_argument('--mask', default=None, choices=['prior', 'none', 'inveye'], help='override the workload label mask')
     ap.add_argument('--streams', type=int, default=1, choices=[1, 2],
                     help='HIP streams one forward spreads its batch over (lamp_set_forward_streams)')
     args = ap.parse_args()
@@ -156,8 +161,16 @@ def main():
     from lamp_amd import _native as N
     N.lib()
     N.set_forward_streams(args.streams)
-    w = WORKLOADS[args.workload]
-    model, sd, adj, seq, pos = build(w, args.batch, device, seed=rank)
+    w = dict(WORKLOADS[args.workload])
+    if args.mask:
+        w['mask'] = args.mask
+    lengths = None
+    if args.ragged:
+        lo, hi = RAGGED[args.workload]
+        g = torch.Generator().manual_seed(1000 + rank)
+        lengths = torch.randint(lo, hi + 1, (args.batch,), generator=g).tolist()
+        w['T'] = max(lengths)  # padded length of this batch: what the kernels process and what F_live counts
+    model, sd, adj, seq, pos = build(w, args.batch, device, seed=rank, lengths=lengths)
     src = (seq.to(device), pos.to(device))
 
     def step():
@@ -194,6 +207,16 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+
+    # per-step latency with a device sync after every step (median and min), outside the timed region
+    lat = []
+    for _ in range(min(args.steps, 50)):
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - ts) * 1e3)
+    lat.sort()
 
     # sanity: the timed work produced finite logits
     logits = out[0]
@@ -256,13 +279,17 @@ def main():
                 'algorithmic_gbs': r['bytes'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else None,
             }
     result = {
-        'metric': 'forward samples/sec, reuters d512 2+2L 4h',
+        'metric': 'forward samples/sec, reuters d512 2+2L 4h' if args.workload == 'reuters' else
+                  'forward samples/sec, %s d%d 2+2L %dh' % (args.workload, w['d'], w['h']),
         'value': value, 'unit': 'samples/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'ms_per_step': ms_per_step, 'step_ms_synced': {'median': lat[len(lat) // 2], 'min': lat[0], 'n': len(lat)},
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': '%s: batch %d/GPU, T=%d fixed, L=%d, d_model=%d, d_ff=%d, 2 enc + 2 dec graph '
-                               'layers, %d heads, label_mask=%s, fp32' %
-                               (args.workload, args.batch, w['T'], w['L'], w['d'], w['dff'], w['h'], w['mask']),
+        'config': {'workload': '%s: batch %d/GPU, T=%d %s, L=%d, d_model=%d, d_ff=%d, 2 enc + 2 dec graph layers, '
+                               '%d heads, label_mask=%s, fp32' %
+                               (args.workload, args.batch, w['T'],
+                                '(lengths U{%d..%d} padded to the batch maximum)' % RAGGED[args.workload] if args.ragged
+                                else 'fixed', w['L'], w['d'], w['dff'], w['h'], w['mask']),
                    'batch_per_gpu': args.batch, 'parallelism': 'batch-sharded x%d, no collectives' % n_gpus,
                    'launch': 'hip-graph replay' if args.graph else 'eager (one lamp_forward call per step)',
                    'streams_per_forward': args.streams},

@@ -13,6 +13,9 @@ for wl in bibtex delicious; do
   python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/bench_$wl.json" 2>/dev/null
 done
 python bench.py --workload synthetic4096 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_synthetic4096.json" 2>/dev/null
+python bench.py --ragged --no-cpu-baseline > "$OUT/bench_reuters_ragged.json" 2>/dev/null
+python bench.py --workload synthetic4096 --batch 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined > "$OUT/bench_synthetic4096_b1024.json" 2>/dev/null
+python bench.py --workload synthetic4096 --mask none --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined > "$OUT/bench_synthetic4096_none.json" 2>/dev/null
 python tools/bench_kernels.py gemm_ab 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles.txt"
 python tools/bench_kernels.py gemm 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles_sweep.txt"
 python tools/bench_kernels.py attn 2>&1 | grep -v amdgpu.ids > "$OUT/attn_variants.txt"

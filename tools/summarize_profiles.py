@@ -38,7 +38,9 @@ def main():
     cp = lambda a, b: shutil.copy(os.path.join(src, a), os.path.join(dst, '%s_%s' % (tag, b)))
     cp('bench.json', 'bench.json')
     cp('bench_under_rocprof.json', 'bench_under_rocprof.json')
-    for wl in ('bibtex', 'delicious', 'synthetic4096'):
+    for wl in ('bibtex', 'delicious', 'synthetic4096', 'reuters_ragged', 'synthetic4096_b1024', 'synthetic4096_none'):
+        if not os.path.exists(os.path.join(src, 'bench_%s.json' % wl)):
+            continue
         cp('bench_%s.json' % wl, 'bench_%s.json' % wl)
     cp('gemm_tiles.txt', 'gemm_tiles.txt')
     cp('gemm_tiles_sweep.txt', 'gemm_tiles_sweep.txt')
