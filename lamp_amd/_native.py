@@ -169,7 +169,14 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    """Raw hipStream_t of torch's current stream on the current device (what every launch is enqueued on).
+    torch.cuda.current_stream() builds a Python Stream object per call (~10 us); the raw getter is ~0.5 us."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -373,15 +380,32 @@ def diag_logits(y, w_out):
     return out
 
 
-def _as4(t):
-    """(..., r, c) view -> (b0, b1, r, c) view without copying."""
-    if t.dim() == 2:
-        return t.unsqueeze(0).unsqueeze(0)
-    if t.dim() == 3:
-        return t.unsqueeze(0)
-    if t.dim() == 4:
-        return t
+def _dims4(t):
+    """shape and strides of a (..., r, c) tensor padded to (b0, b1, r, c) -- plain ints, no view objects."""
+    sh, st = tuple(t.shape), t.stride()
+    n = len(sh)
+    if n == 2:
+        return (1, 1) + sh, (0, 0) + st
+    if n == 3:
+        return (1,) + sh, (0,) + st
+    if n == 4:
+        return sh, st
     raise ValueError('gemm operands must be 2-, 3- or 4-dimensional')
+
+
+def _operand(t):
+    """-> (tensor to keep alive, shape4, row stride, col stride, batch strides) with one unit stride among (row, col)."""
+    sh, st = _dims4(t)
+    rs, cs = st[2], st[3]
+    if sh[3] == 1 and rs != 1:   # a size-1 dim may carry any stride
+        cs = 1
+    elif sh[2] == 1 and cs != 1:
+        rs = 1
+    if rs != 1 and cs != 1:
+        t = t.contiguous()
+        sh, st = _dims4(t)
+        rs, cs = st[2], st[3]
+    return t, sh, rs, cs, (0 if sh[0] == 1 else st[0], 0 if sh[1] == 1 else st[1])
 
 
 def matmul_nt(a, b, out=None, alpha=1.0, accumulate=False, relu_mask=None):
@@ -390,53 +414,41 @@ def matmul_nt(a, b, out=None, alpha=1.0, accumulate=False, relu_mask=None):
     a and b are fp32 device VIEWS: any strides with a unit stride on one of the last two dims, so transposes
     (`w.t()`, `p.transpose(-1, -2)`), head-split views of [B, l, h*d] projections etc. are passed as they are.
     Batch dims (0, 1 or 2 of them) must match or be 1.  out, if given, is a view with unit last stride."""
-    require_device(a, b)
+    if not (a.is_cuda and b.is_cuda):
+        require_device(a, b)
     if a.dtype != torch.float32 or b.dtype != torch.float32:
         raise TypeError('matmul_nt needs float32 operands')
-    A, Bm = _as4(a), _as4(b)
-    M, K, Nn = A.size(2), A.size(3), Bm.size(2)
-    if Bm.size(3) != K:
+    A, ash, ars, acs, abs_ = _operand(a)
+    Bm, bsh, brs, bcs, bbs = _operand(b)
+    M, K, Nn = ash[2], ash[3], bsh[2]
+    if bsh[3] != K:
         raise ValueError('contraction sizes differ: %s vs %s' % (tuple(a.shape), tuple(b.shape)))
-    b0, b1 = max(A.size(0), Bm.size(0)), max(A.size(1), Bm.size(1))
-    for X in (A, Bm):
-        if X.size(0) not in (1, b0) or X.size(1) not in (1, b1):
-            raise ValueError('batch dims do not broadcast: %s vs %s' % (tuple(a.shape), tuple(b.shape)))
-
-    def unit(X):  # a size-1 dim may carry any stride
-        rs, cs = X.stride(2), X.stride(3)
-        if X.size(3) == 1 and rs != 1:
-            cs = 1
-        elif X.size(2) == 1 and cs != 1:
-            rs = 1
-        if rs != 1 and cs != 1:
-            X = X.contiguous()
-            rs, cs = X.stride(2), X.stride(3)
-        return X, rs, cs
-    A, ars, acs = unit(A)
-    Bm, brs, bcs = unit(Bm)
-    lead = a.shape[:-2] if a.dim() >= b.dim() else b.shape[:-2]
+    b0, b1 = max(ash[0], bsh[0]), max(ash[1], bsh[1])
+    if ash[0] not in (1, b0) or ash[1] not in (1, b1) or bsh[0] not in (1, b0) or bsh[1] not in (1, b1):
+        raise ValueError('batch dims do not broadcast: %s vs %s' % (tuple(a.shape), tuple(b.shape)))
     if out is None:
-        out = torch.empty(tuple(lead) + (M, Nn), dtype=torch.float32, device=a.device)
         if accumulate:
             raise ValueError('accumulate needs an out tensor')
-    Cm = _as4(out)
-    if Cm.stride(3) != 1 and Cm.size(3) != 1:
+        lead = a.shape[:-2] if a.dim() >= b.dim() else b.shape[:-2]
+        out = torch.empty(tuple(lead) + (M, Nn), dtype=torch.float32, device=a.device)
+    csh, cst = _dims4(out)
+    if cst[3] != 1 and csh[3] != 1:
         raise ValueError('out must have unit stride on its last dim')
-    if tuple(Cm.shape) != (b0, b1, M, Nn):
+    if csh != (b0, b1, M, Nn):
         raise ValueError('out has shape %s, expected %s' % (tuple(out.shape), (b0, b1, M, Nn)))
-    bs = lambda X, i: 0 if X.size(i) == 1 else X.stride(i)  # noqa: E731
-    d = GemmDesc(ptr(A), ptr(Bm), ptr(Cm), M, Nn, K, b0, b1, int(bool(accumulate)),
-                 ars, acs, bs(A, 0), bs(A, 1), brs, bcs, bs(Bm, 0), bs(Bm, 1),
-                 Cm.stride(2), bs(Cm, 0), bs(Cm, 1), None, 0, float(alpha), 0)
+    d = GemmDesc(A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, Nn, K, b0, b1, 1 if accumulate else 0,
+                 ars, acs, abs_[0], abs_[1], brs, bcs, bbs[0], bbs[1],
+                 cst[2], 0 if csh[0] == 1 else cst[0], 0 if csh[1] == 1 else cst[1], None, 0, float(alpha), 0)
     keep = None
     if relu_mask is not None:
         keep = f32c(relu_mask)
         if tuple(keep.shape[-2:]) != (M, Nn) or keep.numel() != M * Nn:
             raise ValueError('relu_mask must be (M, N)')
-        d.relu_mask, d.ld_mask = ptr(keep), Nn
-    nb = lib().lamp_gemm_workspace_bytes(M, Nn, K, b0 * b1)
+        d.relu_mask, d.ld_mask = keep.data_ptr(), Nn
+    L = lib()
+    nb = L.lamp_gemm_workspace_bytes(M, Nn, K, b0 * b1)
     ws = workspace(nb, a.device) if nb else None
-    check(lib().lamp_gemm(C.byref(d), ptr(ws), nb, stream()), 'lamp_gemm')
+    check(L.lamp_gemm(C.byref(d), ptr(ws), nb, stream()), 'lamp_gemm')
     return out
 
 
