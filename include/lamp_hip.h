@@ -260,18 +260,26 @@ typedef struct lamp_gemm_desc {
 size_t lamp_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t batch);
 int lamp_gemm(const lamp_gemm_desc* d, void* workspace, size_t workspace_bytes, lamp_stream_t stream);
 
-/* y = LayerNorm(x + residual[row % residual_rows]) (residual nullable; residual_rows 0 = one residual row per x
- * row): the add & norm that closes every sub-layer (lamp/SubLayers.py:115,140), with the sum never stored. */
+/* y = LayerNorm(dropout(x) + residual[row % residual_rows]) (residual nullable; residual_rows 0 = one residual row
+ * per x row): the dropout, add & norm that closes every sub-layer (lamp/SubLayers.py:113-115,138-140), with neither
+ * the dropped tensor nor the sum ever stored.  dropout_p = 0: plain add & norm; otherwise lamp_dropout's counter-based
+ * mask for `seed`, element index = row * d + column. */
 int lamp_layernorm_residual_fwd(const float* x, const float* residual, int64_t residual_rows, int64_t M, int32_t d,
-                                const float* gamma, const float* beta, float eps, float* y, lamp_stream_t stream);
+                                const float* gamma, const float* beta, float eps, float dropout_p, uint32_t seed,
+                                float* y, lamp_stream_t stream);
 
-/* Backward of the above.  z = x + residual is recomputed from the same two inputs; given dy it returns
- *   dz [M, d] (the gradient of both x and residual), dgamma [d] = sum_rows dy * zhat, dbeta [d] = sum_rows dy.
+/* Backward of the above; z = dropout(x) + residual is recomputed from the same inputs.  Given dy it returns
+ *   dz [M, d]      gradient of z, i.e. of the residual branch,
+ *   dx [M, d]      gradient of x = dropout(dz) with the same mask (written only when dropout_p > 0; with p = 0 the
+ *                  gradient of x is dz itself and dx may be NULL),
+ *   dgamma, dbeta  [d]: sum_rows dy * zhat, sum_rows dy,
+ *   dbias [d]      (nullable): sum_rows of the gradient of x -- the bias gradient of the linear map that produced x.
  * d <= 1024.  Row sums are two-stage in a fixed order (deterministic). */
 size_t lamp_layernorm_bwd_workspace_bytes(int64_t M, int32_t d);
 int lamp_layernorm_bwd(const float* x, const float* residual, int64_t residual_rows, int64_t M, int32_t d,
-                       const float* gamma, float eps, const float* dy, float* dz, float* dgamma, float* dbeta,
-                       void* workspace, size_t workspace_bytes, lamp_stream_t stream);
+                       const float* gamma, float eps, float dropout_p, uint32_t seed, const float* dy, float* dz,
+                       float* dx, float* dgamma, float* dbeta, float* dbias, void* workspace, size_t workspace_bytes,
+                       lamp_stream_t stream);
 
 /* out[n] = sum_m x[m*ldx + n]: bias gradients, and the label-table gradient (sum over the batch). */
 size_t lamp_colsum_workspace_bytes(int64_t M, int64_t N);

@@ -100,9 +100,10 @@ PROTOTYPES = {
     'lamp_diag_logits_fwd': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     'lamp_gemm_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'lamp_gemm': (C.c_int, [C.POINTER(GemmDesc), _vp, _sz, _vp]),
-    'lamp_layernorm_residual_fwd': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _f, _vp, _vp]),
+    'lamp_layernorm_residual_fwd': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _f, _f, C.c_uint32, _vp, _vp]),
     'lamp_layernorm_bwd_workspace_bytes': (_sz, [_i64, _i32]),
-    'lamp_layernorm_bwd': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'lamp_layernorm_bwd': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _f, _f, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _sz, _vp]),
     'lamp_colsum_workspace_bytes': (_sz, [_i64, _i64]),
     'lamp_colsum': (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     'lamp_dropout': (C.c_int, [_vp, _i64, _f, C.c_uint32, _vp, _vp]),
@@ -452,8 +453,9 @@ def matmul_nt(a, b, out=None, alpha=1.0, accumulate=False, relu_mask=None):
     return out
 
 
-def layernorm_residual(x, residual, gamma, beta, eps=1e-5):
-    """LayerNorm(x + residual); residual (rows, d) is broadcast over x's rows when it has fewer (row % rows)."""
+def layernorm_residual(x, residual, gamma, beta, eps=1e-5, dropout_p=0.0, seed=0):
+    """LayerNorm(dropout(x) + residual); residual (rows, d) is broadcast over x's rows when it has fewer (row % rows).
+    dropout_p > 0 applies lamp_dropout's counter-based mask for `seed` to x inside the kernel."""
     require_device(x, gamma, beta, residual)
     xc = f32c(x)
     d = xc.size(-1)
@@ -468,12 +470,15 @@ def layernorm_residual(x, residual, gamma, beta, eps=1e-5):
             r_rows = rr
     y = torch.empty_like(xc)
     check(lib().lamp_layernorm_residual_fwd(ptr(xc), ptr(r), r_rows, M, d, ptr(f32c(gamma)), ptr(f32c(beta)), eps,
-                                            ptr(y), stream()), 'lamp_layernorm_residual_fwd')
+                                            float(dropout_p), int(seed) & 0xffffffff, ptr(y), stream()),
+          'lamp_layernorm_residual_fwd')
     return y
 
 
-def layernorm_bwd(x, residual, gamma, dy, eps=1e-5):
-    """-> (dz, dgamma, dbeta) for y = LayerNorm(x + residual)."""
+def layernorm_bwd(x, residual, gamma, dy, eps=1e-5, dropout_p=0.0, seed=0, want_dbias=False):
+    """Backward of y = LayerNorm(dropout(x) + residual) -> (dz, dx, dgamma, dbeta, dbias):
+    dz = gradient of the residual branch, dx = gradient of x (the same tensor as dz when dropout_p == 0),
+    dbias = column sums of dx (None unless want_dbias)."""
     require_device(x, gamma, dy, residual)
     xc, g = f32c(x), f32c(dy)
     d = xc.size(-1)
@@ -483,13 +488,16 @@ def layernorm_bwd(x, residual, gamma, dy, eps=1e-5):
     if r is not None and r.numel() // d != M:
         r_rows = r.numel() // d
     dz = torch.empty_like(xc)
+    dx = torch.empty_like(xc) if dropout_p > 0 else None
     dgamma = torch.empty(d, dtype=torch.float32, device=xc.device)
     dbeta = torch.empty_like(dgamma)
+    dbias = torch.empty_like(dgamma) if want_dbias else None
     nb = lib().lamp_layernorm_bwd_workspace_bytes(M, d)
     ws = workspace(nb, xc.device)
-    check(lib().lamp_layernorm_bwd(ptr(xc), ptr(r), r_rows, M, d, ptr(f32c(gamma)), eps, ptr(g), ptr(dz), ptr(dgamma),
-                                   ptr(dbeta), ptr(ws), nb, stream()), 'lamp_layernorm_bwd')
-    return dz, dgamma, dbeta
+    check(lib().lamp_layernorm_bwd(ptr(xc), ptr(r), r_rows, M, d, ptr(f32c(gamma)), eps, float(dropout_p),
+                                   int(seed) & 0xffffffff, ptr(g), ptr(dz), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dbias),
+                                   ptr(ws), nb, stream()), 'lamp_layernorm_bwd')
+    return dz, (dx if dx is not None else dz), dgamma, dbeta, dbias
 
 
 def colsum(x):

@@ -376,18 +376,25 @@ int lamp_gemm(const lamp_gemm_desc* d, void* workspace, size_t workspace_bytes, 
 }
 
 int lamp_layernorm_residual_fwd(const float* x, const float* residual, int64_t residual_rows, int64_t M, int32_t d,
-                                const float* gamma, const float* beta, float eps, float* y, lamp_stream_t stream) {
+                                const float* gamma, const float* beta, float eps, float dropout_p, uint32_t seed,
+                                float* y, lamp_stream_t stream) {
     if (!y) return LAMP_E_NULL;
-    return launch_layernorm(x, M, d, gamma, beta, eps, residual, residual_rows, y, hipStream_t(stream));
+    if (!(dropout_p >= 0.f) || !(dropout_p < 1.f)) return LAMP_E_UNSUPPORTED;
+    const DropoutSpec ds = make_dropout(dropout_p, seed);
+    return launch_layernorm(x, M, d, gamma, beta, eps, residual, residual_rows, y, hipStream_t(stream), nullptr, 0,
+                            nullptr, dropout_p > 0.f ? &ds : nullptr);
 }
 
 size_t lamp_layernorm_bwd_workspace_bytes(int64_t M, int32_t d) { return layernorm_bwd_workspace_bytes(M, d); }
 
 int lamp_layernorm_bwd(const float* x, const float* residual, int64_t residual_rows, int64_t M, int32_t d,
-                       const float* gamma, float eps, const float* dy, float* dz, float* dgamma, float* dbeta,
-                       void* workspace, size_t workspace_bytes, lamp_stream_t stream) {
-    return launch_layernorm_bwd(x, residual, residual_rows, M, d, gamma, eps, dy, dz, dgamma, dbeta, workspace,
-                                workspace_bytes, hipStream_t(stream));
+                       const float* gamma, float eps, float dropout_p, uint32_t seed, const float* dy, float* dz,
+                       float* dx, float* dgamma, float* dbeta, float* dbias, void* workspace, size_t workspace_bytes,
+                       lamp_stream_t stream) {
+    if (!(dropout_p >= 0.f) || !(dropout_p < 1.f)) return LAMP_E_UNSUPPORTED;
+    const DropoutSpec ds = make_dropout(dropout_p, seed);
+    return launch_layernorm_bwd(x, residual, residual_rows, M, d, gamma, eps, dropout_p > 0.f ? &ds : nullptr, dy, dz, dx,
+                                dgamma, dbeta, dbias, workspace, workspace_bytes, hipStream_t(stream));
 }
 
 size_t lamp_colsum_workspace_bytes(int64_t M, int64_t N) { return colsum_workspace_bytes(M, N); }

@@ -17,23 +17,26 @@ __device__ __forceinline__ float wsum(float v) {
 
 constexpr int LNB_MAX_WG = 256;
 
-// dz = d/dz LayerNorm(z) . dy, z = x + res;   partial[wg] = [sum_rows dy * zhat | sum_rows dy]  over this WG's rows
-template <int NV>
+// dz = d/dz LayerNorm(z) . dy, z = dropout(x) + res;  dz_drop = dropout(dz) (the gradient of x; DROP only);
+// partial[wg] = [sum_rows dy * zhat | sum_rows dy | sum_rows (gradient of x)]  over this WG's rows (third part: NP == 3)
+template <int NV, bool DROP, int NP>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             int64_t r_mod, int64_t M, int d,
                                                             const float* __restrict__ g, float eps,
                                                             const float* __restrict__ dy, float* __restrict__ dz,
-                                                            float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][d]
+                                                            float* __restrict__ dz_drop, float* __restrict__ partial,
+                                                            DropoutSpec drop) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NP][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d / 4;
     const float4* g4 = reinterpret_cast<const float4*>(g);
-    float4 gg[NV], ag[NV], ab[NV];
+    float4 gg[NV], ag[NV], ab[NV], ax[NP == 3 ? NV : 1];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         gg[i] = c < nv ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (NP == 3) ax[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float inv_d = 1.0f / float(d);
     for (int64_t row = int64_t(blockIdx.x) * 4 + wave; row < M; row += int64_t(gridDim.x) * 4) {
@@ -46,6 +49,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
             v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (DROP) v[i] = drop4(v[i], row * d + 4 * c, drop);
             if (rr && c < nv) {
                 const float4 w = rr[c];
                 v[i].x += w.x; v[i].y += w.y; v[i].z += w.z; v[i].w += w.w;
@@ -77,12 +81,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s1 = wsum(s1) * inv_d;
         s2 = wsum(s2) * inv_d;
         float4* zr = reinterpret_cast<float4*>(dz + row * d);
+        float4* zd = DROP ? reinterpret_cast<float4*>(dz_drop + row * d) : nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv)
-                zr[c] = make_float4(rstd * (t[i].x - s1 - v[i].x * s2), rstd * (t[i].y - s1 - v[i].y * s2),
-                                    rstd * (t[i].z - s1 - v[i].z * s2), rstd * (t[i].w - s1 - v[i].w * s2));
+            if (c < nv) {
+                float4 o = make_float4(rstd * (t[i].x - s1 - v[i].x * s2), rstd * (t[i].y - s1 - v[i].y * s2),
+                                       rstd * (t[i].z - s1 - v[i].z * s2), rstd * (t[i].w - s1 - v[i].w * s2));
+                zr[c] = o;
+                if constexpr (DROP) {
+                    o = drop4(o, row * d + 4 * c, drop);
+                    zd[c] = o;
+                }
+                if constexpr (NP == 3) {
+                    ax[i].x += o.x; ax[i].y += o.y; ax[i].z += o.z; ax[i].w += o.w;
+                }
+            }
         }
     }
     float4* r4 = reinterpret_cast<float4*>(red);
@@ -90,14 +104,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            r4[(wave * 2 + 0) * nv + c] = ag[i];
-            r4[(wave * 2 + 1) * nv + c] = ab[i];
+            r4[(wave * NP + 0) * nv + c] = ag[i];
+            r4[(wave * NP + 1) * nv + c] = ab[i];
+            if constexpr (NP == 3) r4[(wave * NP + 2) * nv + c] = ax[i];
         }
     }
     __syncthreads();
-    float* out = partial + int64_t(blockIdx.x) * 2 * d;
-    for (int e = threadIdx.x; e < 2 * d; e += 256)
-        out[e] = (red[e] + red[2 * d + e]) + (red[4 * d + e] + red[6 * d + e]);
+    float* out = partial + int64_t(blockIdx.x) * NP * d;
+    for (int e = threadIdx.x; e < NP * d; e += 256)
+        out[e] = (red[e] + red[NP * d + e]) + (red[2 * NP * d + e] + red[3 * NP * d + e]);
 }
 
 // partial[gy][col] = sum over this row chunk of x[row][col]; eight independent chains per thread keep loads in flight
@@ -117,11 +132,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     partial[int64_t(blockIdx.y) * N + col] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
-// out[c] = sum_p partial[p][c] for c in [0, n_total); columns < n_split go to out0, the rest to out1.  A workgroup
+// out[c] = sum_p partial[p][c] for c in [0, n_total); segment c / n_seg goes to out0 / out1 / out2.  A workgroup
 // owns 32 columns; its 8 thread slices each add every 8th partial, and the slices are combined in a fixed order.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int P, int64_t n_total,
-                                                              int64_t n_split, float* __restrict__ out0,
-                                                              float* __restrict__ out1) {
+                                                              int64_t n_seg, float* __restrict__ out0,
+                                                              float* __restrict__ out1, float* __restrict__ out2) {
     __shared__ float red[8][32];
     const int cx = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int64_t c = int64_t(blockIdx.x) * 32 + cx;
@@ -139,23 +154,14 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     if (slice == 0 && c < n_total) {
         const float s = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) +
                         ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
-        if (c < n_split)
-            out0[c] = s;
-        else
-            out1[c - n_split] = s;
+        const int64_t seg = c / n_seg;
+        float* o = seg == 0 ? out0 : (seg == 1 ? out1 : out2);
+        o[c - seg * n_seg] = s;
     }
 }
 
-// Counter-based dropout: element e of site `seed` is kept iff mix32(e, seed) >= p * 2^32.  The same call with the
-// same seed applied to the gradient is the backward pass.
-__device__ __forceinline__ unsigned mix32(unsigned lo, unsigned hi, unsigned seed) {
-    unsigned h = lo ^ (hi * 0x9E3779B9u) ^ seed;
-    h ^= h >> 16; h *= 0x7feb352du;
-    h ^= h >> 15; h *= 0x846ca68bu;
-    h ^= h >> 16;
-    return h;
-}
-
+// Counter-based dropout (mix32 / DropoutSpec in lamp_kernels.h).  The same call with the same seed applied to the
+// gradient is the backward pass.
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int64_t n, unsigned threshold,
                                                       float scale, unsigned seed, float* __restrict__ y) {
     for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < n; e += int64_t(gridDim.x) * 256) {
@@ -226,31 +232,51 @@ inline int colsum_chunks(int64_t M) {
 
 }  // namespace
 
-size_t layernorm_bwd_workspace_bytes(int64_t M, int d) { return size_t(lnb_grid(M)) * 2 * d * sizeof(float); }
+size_t layernorm_bwd_workspace_bytes(int64_t M, int d) { return size_t(lnb_grid(M)) * 3 * d * sizeof(float); }
 
 int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_t M, int d, const float* g, float eps,
-                         const float* dy, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                         hipStream_t s) {
+                         const DropoutSpec* drop, const float* dy, float* dz, float* dz_drop, float* dgamma, float* dbeta,
+                         float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
     if (M <= 0 || d <= 0) return LAMP_E_DIMS;
     if ((d & 3) || d > 1024) return LAMP_E_UNSUPPORTED;
-    if (!x || !g || !dy || !dz || !dgamma || !dbeta || !ws) return LAMP_E_NULL;
-    if (!aligned16(x) || !aligned16(dy) || !aligned16(dz) || !aligned16(g) || (res && !aligned16(res)) || !aligned16(ws))
+    const bool dr = drop && drop->threshold > 0;
+    if (!x || !g || !dy || !dz || !dgamma || !dbeta || !ws || (dr && !dz_drop)) return LAMP_E_NULL;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dz) || !aligned16(g) || (res && !aligned16(res)) || !aligned16(ws) ||
+        (dr && !aligned16(dz_drop)))
         return LAMP_E_ALIGN;
     if (ws_bytes < layernorm_bwd_workspace_bytes(M, d)) return LAMP_E_WORKSPACE;
     const int grid = lnb_grid(M);
     float* partial = static_cast<float*>(ws);
-    const size_t lds = size_t(8) * d * sizeof(float);
+    const int np = dbias ? 3 : 2;
+    const size_t lds = size_t(4) * np * d * sizeof(float);
     const int nv = (d / 4 + 63) / 64;
+    const DropoutSpec ds = dr ? *drop : DropoutSpec{0u, 1.f, 0u};
     ProfScope prof(LAMP_K_LAYERNORM, 0.0, 12.0 * double(M) * d, s);
+#define LAMP_LNB(NV_, DROP_, NP_)                                                                                       \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<NV_, DROP_, NP_>), dim3(grid), dim3(256), lds, s, x, res, r_mod, M, d, g, eps, \
+                       dy, dz, dz_drop, partial, ds)
+#define LAMP_LNB_NV(NV_)                    \
+    do {                                    \
+        if (dr && np == 3)                  \
+            LAMP_LNB(NV_, true, 3);         \
+        else if (dr)                        \
+            LAMP_LNB(NV_, true, 2);         \
+        else if (np == 3)                   \
+            LAMP_LNB(NV_, false, 3);        \
+        else                                \
+            LAMP_LNB(NV_, false, 2);        \
+    } while (0)
     if (nv <= 1)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(grid), dim3(256), lds, s, x, res, r_mod, M, d, g, eps, dy, dz, partial);
+        LAMP_LNB_NV(1);
     else if (nv <= 2)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(grid), dim3(256), lds, s, x, res, r_mod, M, d, g, eps, dy, dz, partial);
+        LAMP_LNB_NV(2);
     else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(grid), dim3(256), lds, s, x, res, r_mod, M, d, g, eps, dy, dz, partial);
+        LAMP_LNB_NV(4);
+#undef LAMP_LNB_NV
+#undef LAMP_LNB
     if (int e = int(hipGetLastError())) return e;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * d + 31) / 32), dim3(256), 0, s, partial, grid, int64_t(2 * d),
-                       int64_t(d), dgamma, dbeta);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((np * d + 31) / 32), dim3(256), 0, s, partial, grid, int64_t(np) * d,
+                       int64_t(d), dgamma, dbeta, dbias);
     return int(hipGetLastError());
 }
 
@@ -269,7 +295,7 @@ int launch_colsum(const float* x, int64_t M, int64_t N, int64_t ldx, float* out,
     if (int e = int(hipGetLastError())) return e;
     const int64_t gr = (N + 31) / 32;
     if (gr > 0x7fffffffLL) return LAMP_E_DIMS;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)gr), dim3(256), 0, s, partial, chunks, N, N, out, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)gr), dim3(256), 0, s, partial, chunks, N, N, out, out, out);
     return int(hipGetLastError());
 }
 
@@ -277,11 +303,10 @@ int launch_dropout(const float* x, int64_t n, float p, uint32_t seed, float* y, 
     if (n <= 0) return LAMP_E_DIMS;
     if (!(p >= 0.f) || !(p < 1.f)) return LAMP_E_UNSUPPORTED;
     if (!x || !y) return LAMP_E_NULL;
-    const double t = double(p) * 4294967296.0;
-    const unsigned threshold = t >= 4294967295.0 ? 4294967295u : unsigned(t);
+    const DropoutSpec ds = make_dropout(p, seed);
     const int64_t g = (n + 255) / 256;
-    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(g < 8192 ? g : 8192)), dim3(256), 0, s, x, n, threshold,
-                       1.0f / (1.0f - p), seed, y);
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(g < 8192 ? g : 8192)), dim3(256), 0, s, x, n, ds.threshold, ds.scale,
+                       ds.seed, y);
     return int(hipGetLastError());
 }
 

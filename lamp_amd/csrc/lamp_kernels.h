@@ -53,14 +53,40 @@ int launch_gemm(const GemmParams& p, hipStream_t s);
 int launch_attn(const AttnParams& p, hipStream_t s);
 size_t gemm_gen_workspace_bytes(int M, int N, int K, int batch);
 int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStream_t s);
-// y = LayerNorm(x + residual[row % r_mod or row])   (residual nullable; r_mod 0 = per-row residual)
+// Counter-based dropout (lamp_dropout): element e of a site is kept iff mix32(e, seed) >= threshold, kept values are
+// multiplied by scale = 1 / (1 - p).  threshold == 0: dropout off.
+struct DropoutSpec {
+    unsigned threshold;
+    float scale;
+    unsigned seed;
+};
+inline DropoutSpec make_dropout(float p, uint32_t seed) {
+    const double t = double(p) * 4294967296.0;
+    return DropoutSpec{t >= 4294967295.0 ? 4294967295u : unsigned(t), 1.0f / (1.0f - p), seed};
+}
+__device__ __forceinline__ unsigned mix32(unsigned lo, unsigned hi, unsigned seed) {
+    unsigned h = lo ^ (hi * 0x9E3779B9u) ^ seed;
+    h ^= h >> 16; h *= 0x7feb352du;
+    h ^= h >> 15; h *= 0x846ca68bu;
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ float drop1(float v, int64_t e, const DropoutSpec& d) {
+    return mix32(unsigned(e), unsigned(uint64_t(e) >> 32), d.seed) >= d.threshold ? v * d.scale : 0.f;
+}
+__device__ __forceinline__ float4 drop4(float4 v, int64_t e, const DropoutSpec& d) {
+    return make_float4(drop1(v.x, e, d), drop1(v.y, e + 1, d), drop1(v.z, e + 2, d), drop1(v.w, e + 3, d));
+}
+
+// y = LayerNorm(dropout(x) + residual[row % r_mod or row])   (residual nullable; r_mod 0 = per-row residual; drop nullable)
 int launch_layernorm(const float* x, int64_t M, int d, const float* g, const float* b, float eps,
                      const float* residual, int64_t r_mod, float* y, hipStream_t s, const float* w_out = nullptr,
-                     int n_labels = 0, float* logits = nullptr);  // w_out: fused read-out, y may then be NULL
+                     int n_labels = 0, float* logits = nullptr,  // w_out: fused read-out, y may then be NULL
+                     const DropoutSpec* drop = nullptr);
 size_t layernorm_bwd_workspace_bytes(int64_t M, int d);
 int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_t M, int d, const float* g, float eps,
-                         const float* dy, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                         hipStream_t s);
+                         const DropoutSpec* drop, const float* dy, float* dz, float* dz_drop, float* dgamma, float* dbeta,
+                         float* dbias, void* ws, size_t ws_bytes, hipStream_t s);
 size_t colsum_workspace_bytes(int64_t M, int64_t N);
 int launch_colsum(const float* x, int64_t M, int64_t N, int64_t ldx, float* out, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_dropout(const float* x, int64_t n, float p, uint32_t seed, float* y, hipStream_t s);

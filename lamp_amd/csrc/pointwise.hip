@@ -39,14 +39,14 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
 
 // y = (x - mean) / sqrt(var_biased + eps) * g + b over the last dim.  Two-pass (mean, then centred
 // sum of squares) on a register-resident row; NV float4 per lane.
-template <int NV>
+template <int NV, bool DROP>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t M, int d,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ bta, float eps,
                                                         const float* __restrict__ res, int64_t r_mod,
                                                         float* __restrict__ y,
                                                         const float* __restrict__ w_out, int n_labels,
-                                                        float* __restrict__ logits) {
+                                                        float* __restrict__ logits, DropoutSpec drop) {
     const int lane = threadIdx.x & 63;
     const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (DROP) v[i] = drop4(v[i], row * d + 4 * c, drop);  // training: dropout on the sub-layer output
         if (rr && c < nv) {
             const float4 w = rr[c];
             v[i].x += w.x; v[i].y += w.y; v[i].z += w.z; v[i].w += w.w;
@@ -195,26 +196,39 @@ int launch_embed(const int64_t* seq, const int64_t* pos, int64_t n_tok, const fl
 
 int launch_layernorm(const float* x, int64_t M, int d, const float* g, const float* b, float eps,
                      const float* residual, int64_t r_mod, float* y, hipStream_t s, const float* w_out, int n_labels,
-                     float* logits) {
+                     float* logits, const DropoutSpec* drop) {
     if (M <= 0 || d <= 0) return LAMP_E_DIMS;
     if ((d & 3) || d > 4096) return LAMP_E_UNSUPPORTED;
     if (!x || !g || !b || (!y && !w_out) || (w_out && (!logits || n_labels <= 0))) return LAMP_E_NULL;
-    if (!aligned16(x) || (y && !aligned16(y)) || (w_out && !aligned16(w_out)) || !aligned16(g) || !aligned16(b) || (residual && !aligned16(residual)))
+    if (!aligned16(x) || (y && !aligned16(y)) || !aligned16(g) || !aligned16(b) || (residual && !aligned16(residual)) ||
+        (w_out && !aligned16(w_out)))
         return LAMP_E_ALIGN;
     unsigned grid;
     if (int e = grid4(M, &grid)) return e;
     ProfScope prof(LAMP_K_LAYERNORM, 0.0, 8.0 * double(M) * d, s);
     const int nv = (d / 4 + 63) / 64;
+    const bool dr = drop && drop->threshold > 0;
+    const DropoutSpec ds = dr ? *drop : DropoutSpec{0u, 1.f, 0u};
+#define LAMP_LN_LAUNCH(NV_)                                                                                          \
+    do {                                                                                                              \
+        if (dr)                                                                                                       \
+            hipLaunchKernelGGL((layernorm_kernel<NV_, true>), dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, \
+                               r_mod, y, w_out, n_labels, logits, ds);                                                \
+        else                                                                                                          \
+            hipLaunchKernelGGL((layernorm_kernel<NV_, false>), dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps,        \
+                               residual, r_mod, y, w_out, n_labels, logits, ds);                                      \
+    } while (0)
     if (nv <= 1)
-        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y, w_out, n_labels, logits);
+        LAMP_LN_LAUNCH(1);
     else if (nv <= 2)
-        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y, w_out, n_labels, logits);
+        LAMP_LN_LAUNCH(2);
     else if (nv <= 4)
-        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y, w_out, n_labels, logits);
+        LAMP_LN_LAUNCH(4);
     else if (nv <= 8)
-        hipLaunchKernelGGL(layernorm_kernel<8>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y, w_out, n_labels, logits);
+        LAMP_LN_LAUNCH(8);
     else
-        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, r_mod, y, w_out, n_labels, logits);
+        LAMP_LN_LAUNCH(16);
+#undef LAMP_LN_LAUNCH
     return int(hipGetLastError());
 }
 

@@ -74,9 +74,7 @@ class _FFNFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.size(-1))
         h = N.linear(x2, _w2d(w1), b1, relu=True)
         o = N.linear(h, _w2d(w2), b2)
-        if p > 0:
-            N.dropout(o, p, seed, out=o)
-        y = N.layernorm_residual(o, x2, ln_g, ln_b)
+        y = N.layernorm_residual(o, x2, ln_g, ln_b, dropout_p=p, seed=seed)  # dropout + add & norm in one kernel
         ctx.save_for_backward(x2, h, o, w1, w2, ln_g)
         ctx.p, ctx.seed, ctx.shape = p, seed, x.shape
         return y.view(x.shape)
@@ -85,9 +83,8 @@ class _FFNFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, h, o, w1, w2, ln_g = ctx.saved_tensors
         W1, W2 = _w2d(w1), _w2d(w2)
-        dz, dg, db = N.layernorm_bwd(o, x2, ln_g, dy.reshape(x2.shape))
-        do = N.dropout(dz, ctx.p, ctx.seed) if ctx.p > 0 else dz
-        db2 = N.colsum(do)
+        dz, do, dg, db, db2 = N.layernorm_bwd(o, x2, ln_g, dy.reshape(x2.shape), dropout_p=ctx.p, seed=ctx.seed,
+                                              want_dbias=True)
         dW2 = N.matmul_nt(do.t(), h.t())
         dh = N.matmul_nt(do, W2.t(), relu_mask=h)
         db1 = N.colsum(dh)
@@ -115,10 +112,8 @@ class _MHAFn(torch.autograd.Function):
             Pd = N.dropout(P, p_attn, seed_attn)
             N.matmul_nt(Pd.view(H, B, lq, lk), v.view(B, lk, H, dv).permute(2, 0, 3, 1),
                         out=a.view(B, lq, H, dv).permute(2, 0, 1, 3))
-        o = N.linear(a, fc) if fc is not None else a.clone()
-        if p_out > 0:
-            N.dropout(o, p_out, seed_out, out=o)
-        y = N.layernorm_residual(o, xq, ln_g, ln_b)
+        o = N.linear(a, fc) if fc is not None else a
+        y = N.layernorm_residual(o, xq, ln_g, ln_b, dropout_p=p_out, seed=seed_out)
         ctx.save_for_backward(xq, xkv, wq, wk, wv, fc if fc is not None else wq.new_empty(0), ln_g, q, k, v, a, P, o)
         ctx.cfg = (B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, fc is not None)
         attn = Pd if p_attn > 0 else P.clone()  # what the reference returns (lamp/SubLayers.py:40-43): the dropped map
@@ -131,8 +126,8 @@ class _MHAFn(torch.autograd.Function):
         B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, has_fc = ctx.cfg
         d = xq.size(-1)
         xq2, xkv2 = xq.reshape(-1, d), xkv.reshape(-1, d)
-        dz, dg, db = N.layernorm_bwd(o.view(xq2.shape), xq2, ln_g, dy.reshape(xq2.shape))
-        do = N.dropout(dz, p_out, seed_out) if p_out > 0 else dz
+        dz, do, dg, db, _ = N.layernorm_bwd(o.view(xq2.shape), xq2, ln_g, dy.reshape(xq2.shape), dropout_p=p_out,
+                                            seed=seed_out)
         a2 = a.view(-1, H * dv)
         if has_fc:
             dfc = N.matmul_nt(do.t(), a2.t())

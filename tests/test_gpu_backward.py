@@ -111,16 +111,36 @@ def test_layernorm_residual_fwd_and_bwd_vs_autograd(dev, M, d, r_rows):
     y_ref.backward(dy.double())
     y = N_.layernorm_residual(x.to(dev), res.to(dev), gamma.to(dev), beta.to(dev))
     assert max_abs_diff(y, y_ref.detach()) < 2e-5
-    dz, dgamma, dbeta = N_.layernorm_bwd(x.to(dev), res.to(dev), gamma.to(dev), dy.to(dev))
-    assert max_abs_diff(dz, xd.grad) < 3e-5
+    dz, dx, dgamma, dbeta, dbias = N_.layernorm_bwd(x.to(dev), res.to(dev), gamma.to(dev), dy.to(dev), want_dbias=True)
+    assert dx is dz and max_abs_diff(dz, xd.grad) < 3e-5
+    assert max_abs_diff(dbias, xd.grad.sum(0)) < 1e-4 * max(1.0, (M / 100) ** 0.5)
     assert max_abs_diff(dgamma, gd.grad) < 1e-4 * max(1.0, (M / 100) ** 0.5)
     assert max_abs_diff(dbeta, bd.grad) < 1e-4 * max(1.0, (M / 100) ** 0.5)
     if r_rows:  # the broadcast residual's gradient is the sum over its repeats: colsum of the (M/r, r*d) view
         dres = N_.colsum(dz.view(M // r_rows, r_rows * d)).view(r_rows, d)
         assert max_abs_diff(dres, rd.grad) < 1e-4
     # deterministic
-    dz2, dgamma2, _ = N_.layernorm_bwd(x.to(dev), res.to(dev), gamma.to(dev), dy.to(dev))
+    dz2, _, dgamma2, _, _ = N_.layernorm_bwd(x.to(dev), res.to(dev), gamma.to(dev), dy.to(dev))
     assert torch.equal(dz, dz2) and torch.equal(dgamma, dgamma2)
+    # with dropout on x inside the kernels: against autograd on the restatement that uses the library's keep mask
+    p, seed = 0.3, 77
+    keep = N_.dropout_keep_mask(M * d, p, seed).view(M, d)
+    xd2, rd2 = x.double().requires_grad_(), res.double().requires_grad_()
+    gd2, bd2 = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    z2 = xd2 * keep / (1 - p) + (rd2.repeat(M // r_rows, 1) if r_rows else rd2)
+    y2 = torch.nn.functional.layer_norm(z2, (d,), gd2, bd2, 1e-5)
+    y2.backward(dy.double())
+    yk = N_.layernorm_residual(x.to(dev), res.to(dev), gamma.to(dev), beta.to(dev), dropout_p=p, seed=seed)
+    assert max_abs_diff(yk, y2.detach()) < 3e-5
+    dzk, dxk, dgk, dbk, dbiask = N_.layernorm_bwd(x.to(dev), res.to(dev), gamma.to(dev), dy.to(dev), dropout_p=p, seed=seed,
+                                                  want_dbias=True)
+    assert max_abs_diff(dxk, xd2.grad) < 5e-5
+    assert max_abs_diff(dgk, gd2.grad) < 1e-4 * max(1.0, (M / 100) ** 0.5)
+    assert max_abs_diff(dbiask, xd2.grad.sum(0)) < 1e-4 * max(1.0, (M / 100) ** 0.5)
+    if r_rows:   # broadcast residual: its gradient is dz summed over the repeats
+        assert max_abs_diff(N_.colsum(dzk.view(M // r_rows, r_rows * d)).view(r_rows, d), rd2.grad) < 1e-4
+    else:
+        assert max_abs_diff(dzk, rd2.grad) < 5e-5
 
 
 @pytest.mark.parametrize('M,N', [(1, 5), (32, 46080), (9664, 512), (2880, 2048), (129, 257)])
