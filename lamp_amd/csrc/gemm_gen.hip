@@ -132,17 +132,15 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n)
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (k_end - k_begin + GK - 1) / GK;
-    float4 ra = stage_load<TA, GM>(rsA, tid, k_begin, k_end, lda, p.vecA);
-    float4 rb = stage_load<TB, GN>(rsB, tid, k_begin, k_end, ldb, p.vecB);
-    stage_store<TA, GM>(As[0], tid, ra);
-    stage_store<TB, GN>(Bs[0], tid, rb);
-    if (nk > 1) {
-        ra = stage_load<TA, GM>(rsA, tid, k_begin + GK, k_end, lda, p.vecA);
-        rb = stage_load<TB, GN>(rsB, tid, k_begin + GK, k_end, ldb, p.vecB);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    auto gload = [&](int kt, float4& ra, float4& rb) {
+        ra = stage_load<TA, GM>(rsA, tid, k_begin + kt * GK, k_end, lda, p.vecA);
+        rb = stage_load<TB, GN>(rsB, tid, k_begin + kt * GK, k_end, ldb, p.vecB);
+    };
+    auto lstore = [&](int buf, const float4& ra, const float4& rb) {
+        stage_store<TA, GM>(As[buf], tid, ra);
+        stage_store<TB, GN>(Bs[buf], tid, rb);
+    };
+    auto compute = [&](int buf) {
         float4 fa[MI], fb[NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) fa[i] = frag<TA, GM>(As[buf], wm * WTM + 16 * i + l15, hi);
@@ -157,14 +155,23 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
             }
-        if (kt + 1 < nk) {
-            stage_store<TA, GM>(As[buf ^ 1], tid, ra);
-            stage_store<TB, GN>(Bs[buf ^ 1], tid, rb);
-        }
-        if (kt + 2 < nk) {
-            ra = stage_load<TA, GM>(rsA, tid, k_begin + (kt + 2) * GK, k_end, lda, p.vecA);
-            rb = stage_load<TB, GN>(rsB, tid, k_begin + (kt + 2) * GK, k_end, ldb, p.vecB);
-        }
+    };
+    // Two register sets, as in the forward kernel: tiles kt+1 and kt+2 are in flight while tile kt is multiplied.
+    float4 ra0, rb0, ra1, rb1;
+    gload(0, ra0, rb0);
+    lstore(0, ra0, rb0);
+    if (nk > 1) gload(1, ra0, rb0);
+    if (nk > 2) gload(2, ra1, rb1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        compute(0);  // tile kt in LDS[0]; tile kt+1 in set 0, tile kt+2 in set 1
+        if (kt + 1 < nk) lstore(1, ra0, rb0);
+        if (kt + 3 < nk) gload(kt + 3, ra0, rb0);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        compute(1);  // tile kt+1 in LDS[1]; tile kt+2 in set 1, tile kt+3 in set 0
+        if (kt + 2 < nk) lstore(0, ra1, rb1);
+        if (kt + 4 < nk) gload(kt + 4, ra1, rb1);
         __syncthreads();
     }
 
