@@ -184,6 +184,16 @@ int lamp_sdpa_fwd(const float* q, const float* k, const float* v, float* out, fl
                   float inv_temperature, const lamp_mask* mask, const lamp_attn_layout* layout,
                   lamp_stream_t stream);
 
+/* Same outputs as lamp_sdpa_fwd with attn != NULL, at the speed of the map-less kernel: one pass over the keys writes
+ * the scaled scores into `attn` and every row's log2-sum-exp into `lse` [(H*B) * lq] (caller-provided, also an
+ * output), then `attn` is normalised in place by a second launch.  The maps agree with lamp_sdpa_fwd's exact
+ * two-pass softmax to rounding; a fully blocked row is NaN in both.  The training forward uses this (the maps are
+ * the backward pass's input); a mask's tile list is ignored (every tile is visited). */
+int lamp_sdpa_fwd_fast_maps(const float* q, const float* k, const float* v, float* out, float* attn, float* lse,
+                            int32_t B, int32_t H, int32_t lq, int32_t lk, int32_t d_k, int32_t d_v,
+                            float inv_temperature, const lamp_mask* mask, const lamp_attn_layout* layout,
+                            lamp_stream_t stream);
+
 /* MultiHeadAttention.forward (lamp/SubLayers.py:77-121), eval mode:
  *   out = LayerNorm( concat_heads(SDPA(xq Wq^T, xkv Wk^T, xkv Wv^T)) Wfc^T + xq )
  * xq [B, lq, d_model], xkv [B, lk, d_model] (may alias xq), out [B, lq, d_model];

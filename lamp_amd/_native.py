@@ -91,6 +91,8 @@ PROTOTYPES = {
     'lamp_layernorm_fwd': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _f, _vp, _vp]),
     'lamp_sdpa_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f,
                                 C.POINTER(Mask), C.POINTER(AttnLayout), _vp]),
+    'lamp_sdpa_fwd_fast_maps': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f,
+                                          C.POINTER(Mask), C.POINTER(AttnLayout), _vp]),
     'lamp_mha_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     'lamp_mha_fwd': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(MhaWeights),
                                C.POINTER(Mask), _vp, _vp, _vp, _sz, _vp]),
@@ -299,10 +301,11 @@ def sdpa(q, k, v, mask, inv_temperature, need_attn=True):
     return out, attn
 
 
-def sdpa_fused(q, k, v, n_head, mask_struct, inv_temperature, need_attn=True):
+def sdpa_fused(q, k, v, n_head, mask_struct, inv_temperature, need_attn=True, fast_maps=False):
     """Attention on head-fused projections: q (B, lq, H*dk), k (B, lk, H*dk), v (B, lk, H*dv) ->
     out (B, lq, H*dv), attn (H*B, lq, lk) [index head*B + b] or None.  No head split/merge copies: the
-    kernel walks the heads through lamp_attn_layout strides."""
+    kernel walks the heads through lamp_attn_layout strides.  fast_maps: single-pass map write-out
+    (lamp_sdpa_fwd_fast_maps) instead of the exact two-pass variant."""
     require_device(q, k, v)
     q, k, v = f32c(q), f32c(k), f32c(v)
     B, lq, hq = q.shape
@@ -311,9 +314,14 @@ def sdpa_fused(q, k, v, n_head, mask_struct, inv_temperature, need_attn=True):
     out = torch.empty((B, lq, H * dv), dtype=torch.float32, device=q.device)
     attn = torch.empty((H * B, lq, lk), dtype=torch.float32, device=q.device) if need_attn else None
     lay = AttnLayout(lq * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lk * H * dv, dv, H * dv, lq * H * dv, dv, H * dv)
+    m = C.byref(mask_struct) if mask_struct is not None else None
+    if fast_maps and need_attn:
+        lse = torch.empty((H * B * lq,), dtype=torch.float32, device=q.device)
+        check(lib().lamp_sdpa_fwd_fast_maps(ptr(q), ptr(k), ptr(v), ptr(out), ptr(attn), ptr(lse), B, H, lq, lk, dk, dv,
+                                            float(inv_temperature), m, C.byref(lay), stream()), 'lamp_sdpa_fwd_fast_maps')
+        return out, attn
     check(lib().lamp_sdpa_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(attn), B, H, lq, lk, dk, dv,
-                              float(inv_temperature), C.byref(mask_struct) if mask_struct is not None else None,
-                              C.byref(lay), stream()), 'lamp_sdpa_fwd')
+                              float(inv_temperature), m, C.byref(lay), stream()), 'lamp_sdpa_fwd')
     return out, attn
 
 

@@ -258,6 +258,28 @@ static size_t mha_ws_floats(int64_t B, int64_t lq, int64_t lk, int hdk, int hdv)
 
 using namespace lamp;
 
+namespace {
+int sdpa_impl(const float* q, const float* k, const float* v, float* out, float* attn, float* lse, int32_t B, int32_t H,
+              int32_t lq, int32_t lk, int32_t d_k, int32_t d_v, float inv_temperature, const lamp_mask* mask,
+                  const lamp_attn_layout* layout, lamp_stream_t stream) {
+    if (!layout) return LAMP_E_NULL;
+    LAMP_CK(check_mask(mask));
+    AttnParams a{};
+    a.Q = q; a.K = k; a.V = v; a.O = out; a.P = attn; a.lse = lse;
+    a.B = B; a.H = H; a.lq = lq; a.lk = lk; a.dk = d_k; a.dv = d_v;
+    a.P_batch = B; a.P_b0 = 0;
+    a.lay = *layout;
+    a.scale_log2e = float(double(inv_temperature) * 1.4426950408889634);
+    a.mask_kind = mask ? mask->kind : LAMP_MASK_NONE;
+    a.mask = mask ? mask->ptr : nullptr;
+    a.m_sb = mask ? mask->stride_b : 0;
+    a.m_sq = mask ? mask->stride_q : 0;
+    a.tiles = (mask && !attn) ? mask->tile_list : nullptr;
+    a.tiles_stride = mask ? mask->tile_list_stride : 0;
+    return launch_attn(a, hipStream_t(stream));
+}
+}  // namespace
+
 // ================================================================== C ABI
 extern "C" {
 
@@ -295,21 +317,15 @@ int lamp_layernorm_fwd(const float* x, int64_t M, int32_t d, const float* gamma,
 int lamp_sdpa_fwd(const float* q, const float* k, const float* v, float* out, float* attn, int32_t B, int32_t H,
                   int32_t lq, int32_t lk, int32_t d_k, int32_t d_v, float inv_temperature, const lamp_mask* mask,
                   const lamp_attn_layout* layout, lamp_stream_t stream) {
-    if (!layout) return LAMP_E_NULL;
-    LAMP_CK(check_mask(mask));
-    AttnParams a{};
-    a.Q = q; a.K = k; a.V = v; a.O = out; a.P = attn;
-    a.B = B; a.H = H; a.lq = lq; a.lk = lk; a.dk = d_k; a.dv = d_v;
-    a.P_batch = B; a.P_b0 = 0;
-    a.lay = *layout;
-    a.scale_log2e = float(double(inv_temperature) * 1.4426950408889634);
-    a.mask_kind = mask ? mask->kind : LAMP_MASK_NONE;
-    a.mask = mask ? mask->ptr : nullptr;
-    a.m_sb = mask ? mask->stride_b : 0;
-    a.m_sq = mask ? mask->stride_q : 0;
-    a.tiles = (mask && !attn) ? mask->tile_list : nullptr;
-    a.tiles_stride = mask ? mask->tile_list_stride : 0;
-    return launch_attn(a, hipStream_t(stream));
+    return sdpa_impl(q, k, v, out, attn, nullptr, B, H, lq, lk, d_k, d_v, inv_temperature, mask, layout, stream);
+}
+
+int lamp_sdpa_fwd_fast_maps(const float* q, const float* k, const float* v, float* out, float* attn, float* lse,
+                            int32_t B, int32_t H, int32_t lq, int32_t lk, int32_t d_k, int32_t d_v,
+                            float inv_temperature, const lamp_mask* mask, const lamp_attn_layout* layout,
+                            lamp_stream_t stream) {
+    if (!attn || !lse || !out || !v) return LAMP_E_NULL;
+    return sdpa_impl(q, k, v, out, attn, lse, B, H, lq, lk, d_k, d_v, inv_temperature, mask, layout, stream);
 }
 
 size_t lamp_mha_workspace_bytes(int32_t B, int32_t lq, int32_t lk, int32_t d_model, int32_t n_head, int32_t d_k,

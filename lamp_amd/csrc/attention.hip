@@ -40,8 +40,13 @@ namespace lamp {
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
 // MK = mask kind (LAMP_MASK_*), a compile-time parameter so that each variant carries only its own mask code.
-template <int DP, int KSPLIT, bool WRITE_P, int MK>
+// PM = what is written beside O:  0 nothing;  1 the probability maps, exact two-pass softmax (return_attns in eval);
+// 2 the raw scaled scores (log2 domain, -inf where blocked) into the map buffer plus each row's log2-sum-exp --
+// the single-pass kernel at full speed; softmax_from_scores_kernel then turns the scores into probabilities in
+// place (training forward: the maps are needed for the backward pass).
+template <int DP, int KSPLIT, int PM, int MK>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+    constexpr bool WRITE_P = PM == 1;
     static_assert(!WRITE_P || KSPLIT == 1, "probability write-out uses unsplit keys");
     constexpr int DKC = DP / 8, DVB = DP / 32, QB = 4 / KSPLIT, QS = DP + 4;
     constexpr int QG = DKC >= 4 ? 4 : DKC;  // Q fragments read ahead per group
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         constexpr float RESCALE_THR = 32.0f;
         // Key tiles to visit: all of them, or -- for a shared mask with a sparsity hint -- only the tiles of this
         // 32-query block that hold at least one unblocked entry (skipped tiles would contribute exp2(-inf) = 0).
-        const int* tl = p.tiles ? p.tiles + int64_t(q0 >> 5) * p.tiles_stride : nullptr;  // wave-uniform
+        const int* tl = (p.tiles && PM != 2) ? p.tiles + int64_t(q0 >> 5) * p.tiles_stride : nullptr;  // wave-uniform
         const int n_act = tl ? tl[0] : nt;
         auto tile_at = [&](int idx) { return idx < n_act ? (tl ? tl[1 + idx] : idx) : nt; };  // nt = past the end
         if (wave_active && ks < n_act) {
@@ -264,6 +269,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                 scores(kt, s);
                 load_k(kn);     // unconditional prefetch, flies under softmax + PV
                 load_mask(kn);
+                if constexpr (PM == 2) {
+                    float* Srow = p.P + (int64_t(h) * p.P_batch + p.P_b0 + b) * int64_t(p.lq) * p.lk + int64_t(qi) * p.lk;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                        if (qi < p.lq && key < p.lk) Srow[key] = s[r];
+                    }
+                }
                 float tmax = s[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
@@ -329,7 +342,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                         for (int r = 0; r < 16; ++r)
                             o[e][r] += other[(e * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] * ws;
                 }
+                m_run = m_all;  // l_run is now relative to the merged maximum
             }
+        }
+        if constexpr (PM == 2) {
+            // row log2-sum-exp of the scaled scores: probabilities = exp2(score - lse).  A fully blocked row has
+            // l = 0 -> lse = -inf -> exp2(-inf - -inf) = NaN, as the reference's softmax gives.
+            if (wave_active && ks == 0 && hi == 0 && qi < p.lq)
+                p.lse[(int64_t(h) * p.P_batch + p.P_b0 + b) * int64_t(p.lq) + qi] =
+                    ((m_run == -INFINITY) ? 0.f : m_run) + log2f(l_run);
         }
         const float inv_l = 1.0f / l_run;
 #pragma unroll
@@ -358,13 +379,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     }
 }
 
-template <int DP, int KSPLIT, bool WRITE_P, int MK>
+template <int DP, int KSPLIT, int PM, int MK>
 static int launch_attn_mk(const AttnParams& p, hipStream_t s) {
     constexpr int QB = 4 / KSPLIT;
     constexpr size_t lds_q = size_t(QB) * 32 * (DP + 4) * sizeof(float);
     constexpr size_t lds_c = KSPLIT > 1 ? size_t(4) * (DP + 2) * 32 * sizeof(float) : 0;
     constexpr size_t lds = lds_q > lds_c ? lds_q : lds_c;
-    auto kern = attn_kernel<DP, KSPLIT, WRITE_P, MK>;
+    auto kern = attn_kernel<DP, KSPLIT, PM, MK>;
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -380,22 +401,34 @@ static int launch_attn_mk(const AttnParams& p, hipStream_t s) {
     return int(hipGetLastError());
 }
 
-template <int DP, int KSPLIT, bool WRITE_P>
+template <int DP, int KSPLIT, int PM>
 static int launch_attn_ks(const AttnParams& p, hipStream_t s) {
     switch (p.mask_kind) {
-        case LAMP_MASK_U8: return launch_attn_mk<DP, KSPLIT, WRITE_P, LAMP_MASK_U8>(p, s);
-        case LAMP_MASK_KEY_TOKENS_I64: return launch_attn_mk<DP, KSPLIT, WRITE_P, LAMP_MASK_KEY_TOKENS_I64>(p, s);
-        case LAMP_MASK_BITS_U32: return launch_attn_mk<DP, KSPLIT, WRITE_P, LAMP_MASK_BITS_U32>(p, s);
-        default: return launch_attn_mk<DP, KSPLIT, WRITE_P, LAMP_MASK_NONE>(p, s);
+        case LAMP_MASK_U8: return launch_attn_mk<DP, KSPLIT, PM, LAMP_MASK_U8>(p, s);
+        case LAMP_MASK_KEY_TOKENS_I64: return launch_attn_mk<DP, KSPLIT, PM, LAMP_MASK_KEY_TOKENS_I64>(p, s);
+        case LAMP_MASK_BITS_U32: return launch_attn_mk<DP, KSPLIT, PM, LAMP_MASK_BITS_U32>(p, s);
+        default: return launch_attn_mk<DP, KSPLIT, PM, LAMP_MASK_NONE>(p, s);
     }
 }
 
 template <int DP>
 static int launch_attn_dp(const AttnParams& p, int ksplit, hipStream_t s) {
-    if (p.P) return launch_attn_ks<DP, 1, true>(p, s);
-    if (ksplit >= 4) return launch_attn_ks<DP, 4, false>(p, s);
-    if (ksplit == 2) return launch_attn_ks<DP, 2, false>(p, s);
-    return launch_attn_ks<DP, 1, false>(p, s);
+    if (p.P && p.lse) return ksplit == 2 ? launch_attn_ks<DP, 2, 2>(p, s) : launch_attn_ks<DP, 1, 2>(p, s);
+    if (p.P) return launch_attn_ks<DP, 1, 1>(p, s);
+    if (ksplit >= 4) return launch_attn_ks<DP, 4, 0>(p, s);
+    if (ksplit == 2) return launch_attn_ks<DP, 2, 0>(p, s);
+    return launch_attn_ks<DP, 1, 0>(p, s);
+}
+
+// P[row][k] = exp2(S[row][k] - lse[row]) in place: the second half of the single-pass map write-out (PM == 2).
+__global__ __launch_bounds__(256) void softmax_from_scores_kernel(float* __restrict__ P, const float* __restrict__ lse,
+                                                                  int64_t rows, int lk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float l = lse[row];
+    float* p = P + row * lk;
+    for (int c = lane; c < lk; c += 64) p[c] = __builtin_amdgcn_exp2f(p[c] - l);
 }
 
 // Debug/tuning hook (not part of the ABI header): 0 = heuristic, 1/2/4 = force that key split.
@@ -408,6 +441,7 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     if ((p.dk & 3) || (p.dv & 3)) return LAMP_E_UNSUPPORTED;
     if (!p.Q || !p.K) return LAMP_E_NULL;
     if ((!p.V || !p.O) && !(p.P && !p.V && !p.O)) return LAMP_E_NULL;  // V, O optional only with P
+    if (p.lse && (!p.P || !p.V || !p.O)) return LAMP_E_NULL;             // single-pass map write-out needs everything
     if (p.mask_kind != LAMP_MASK_NONE && !p.mask) return LAMP_E_NULL;
     const lamp_attn_layout& L = p.lay;
     if (((L.q_b | L.q_h | L.q_r | L.k_b | L.k_h | L.k_r | L.v_b | L.v_h | L.v_r) & 3) ||
@@ -430,9 +464,32 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
         return LAMP_E_UNSUPPORTED;  // the sparsity hint belongs to shared masks
     int ksplit = g_force_attn;
     if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = (p.lq <= 128 && nt >= 4) ? 2 : 1;
-    if (dmax <= 32) return launch_attn_dp<32>(p, ksplit, s);
-    if (dmax <= 64) return launch_attn_dp<64>(p, ksplit, s);
-    return launch_attn_dp<128>(p, ksplit, s);
+    if (ksplit == 4 && p.lse) ksplit = 2;
+    int rc;
+    if (dmax <= 32)
+        rc = launch_attn_dp<32>(p, ksplit, s);
+    else if (dmax <= 64)
+        rc = launch_attn_dp<64>(p, ksplit, s);
+    else
+        rc = launch_attn_dp<128>(p, ksplit, s);
+    if (rc || !p.lse) return rc;
+    // NB: only the rows of THIS call's (P_b0 .. P_b0 + B) samples are normalised, head by head
+    const int64_t rows_per_head = int64_t(p.B) * p.lq;
+    const int64_t g = (rows_per_head + 3) / 4;
+    if (g > 0x7fffffffLL) return LAMP_E_DIMS;
+    if (p.P_batch == p.B && p.P_b0 == 0) {  // the maps of all heads are one contiguous block of rows
+        const int64_t g_all = (rows_per_head * p.H + 3) / 4;
+        if (g_all > 0x7fffffffLL) return LAMP_E_DIMS;
+        hipLaunchKernelGGL(softmax_from_scores_kernel, dim3(unsigned(g_all)), dim3(256), 0, s, p.P, p.lse,
+                           rows_per_head * p.H, p.lk);
+        return int(hipGetLastError());
+    }
+    for (int h = 0; h < p.H; ++h) {
+        const int64_t off = (int64_t(h) * p.P_batch + p.P_b0) * p.lq;
+        hipLaunchKernelGGL(softmax_from_scores_kernel, dim3(unsigned(g)), dim3(256), 0, s, p.P + off * p.lk, p.lse + off,
+                           rows_per_head, p.lk);
+    }
+    return int(hipGetLastError());
 }
 
 }  // namespace lamp

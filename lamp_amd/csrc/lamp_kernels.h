@@ -38,6 +38,8 @@ struct AttnParams {
     float* O;
     float* P;  // nullable: (H*B, lq, lk) probabilities, index h*B + b.  With P given, V and O may
                // both be NULL: probabilities only (the reference's dead encoder self-attention).
+    float* lse;  // nullable; with P: single-pass write-out -- scores into P, row log2-sum-exp here [(H*P_batch), lq],
+                 // then normalised in place by a second launch (training forward)
     int B, H, lq, lk, dk, dv;
     int P_batch, P_b0;  // P is indexed (h * P_batch + P_b0 + b): the maps of a micro-batch inside a larger batch
     lamp_attn_layout lay;

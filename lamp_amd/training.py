@@ -106,7 +106,7 @@ class _MHAFn(torch.autograd.Function):
         k = N.linear(xkv, wk)
         v = N.linear(xkv, wv)
         inv_t = 1.0 / float(dk) ** 0.5
-        a, P = N.sdpa_fused(q, k, v, H, mask, inv_t, need_attn=True)
+        a, P = N.sdpa_fused(q, k, v, H, mask, inv_t, need_attn=True, fast_maps=True)
         Pd = P
         if p_attn > 0:  # the reference drops probabilities AFTER the softmax; the value product uses the dropped map
             Pd = N.dropout(P, p_attn, seed_attn)

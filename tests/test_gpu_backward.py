@@ -205,3 +205,32 @@ def test_diag_logits_bwd_and_embed_bwd_vs_autograd(dev):
     d_emb = N_.embed_bwd(seq.to(dev), dout.to(dev), V, pad_idx=0)
     assert max_abs_diff(d_emb, emb.weight.grad) < 1e-4
     assert (d_emb[0] == 0).all()
+
+
+@pytest.mark.parametrize('B,H,lq,lk,dk,kind', [(3, 4, 90, 300, 128, 'keys'), (2, 4, 90, 90, 128, 'shared'), (2, 2, 37, 70, 32, 'none'),
+                                               (1, 8, 200, 983, 64, 'shared'), (2, 1, 33, 5, 16, 'keys')])
+def test_fast_maps_attention_equals_exact_two_pass(dev, B, H, lq, lk, dk, kind):
+    """lamp_sdpa_fwd_fast_maps (single pass: scores + row log-sum-exp, normalised in place) against lamp_sdpa_fwd's exact
+    two-pass maps and output, for every mask kind, with a key split (reuters' shape) and without, incl. a fully
+    blocked row (NaN in both)."""
+    from lamp_amd import _native as N_
+    g = torch.Generator().manual_seed(B * 100 + lq)
+    q, k, v = (_rand(g, B, l, H * dk).to(dev) for l in (lq, lk, lk))
+    mask, keep = None, None
+    if kind == 'keys':
+        seq = torch.randint(1, 50, (B, lk), generator=g)
+        seq[0, lk // 2:] = 0
+        if B > 1:
+            seq[1, :] = 0          # a sample whose keys are ALL padding: NaN rows
+        mask, keep = N_.key_token_mask(seq.to(dev), lk)
+    elif kind == 'shared':
+        blocked = torch.rand(lq, lk, generator=g) < 0.6
+        blocked[:, 0] = False
+        mask, keep = N_.make_mask(blocked.to(dev), B, lq, lk)
+    o1, p1 = N_.sdpa_fused(q, k, v, H, mask, 1.0 / dk ** 0.5, need_attn=True)
+    o2, p2 = N_.sdpa_fused(q, k, v, H, mask, 1.0 / dk ** 0.5, need_attn=True, fast_maps=True)
+    assert torch.equal(torch.isnan(p1), torch.isnan(p2)) and torch.equal(torch.isnan(o1), torch.isnan(o2))
+    assert max_abs_diff(torch.nan_to_num(p2), torch.nan_to_num(p1)) < 2e-6
+    assert max_abs_diff(torch.nan_to_num(o2), torch.nan_to_num(o1)) < 2e-5
+    ok = ~torch.isnan(p2.sum(-1))
+    assert max_abs_diff(p2.sum(-1)[ok], torch.ones_like(p2.sum(-1)[ok])) < 1e-5
