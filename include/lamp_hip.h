@@ -40,7 +40,7 @@ enum lamp_status {
     LAMP_E_DIMS = -1,        /* non-positive or inconsistent dimensions */
     LAMP_E_ALIGN = -2,       /* pointer / leading dimension not 16-byte aligned where required */
     LAMP_E_WORKSPACE = -3,   /* workspace too small */
-    LAMP_E_UNSUPPORTED = -4, /* valid request this build has no kernel for (e.g. d_k > 128) */
+    LAMP_E_UNSUPPORTED = -4, /* valid request this build has no kernel for (e.g. d_k not a multiple of 4) */
     LAMP_E_NULL = -5         /* required pointer is NULL */
 };
 
@@ -178,7 +178,9 @@ int lamp_layernorm_fwd(const float* x, int64_t M, int32_t d, const float* gamma,
 /* ScaledDotProductAttention.forward (lamp/SubLayers.py:27-43), eval mode:
  *   S = (Q K^T) * inv_temperature ; S[blocked] = -inf ; P = softmax_k(S) ; O = P V
  * for B samples x H heads.  `attn` (nullable) receives P as (H*B, lq, lk), index head*B + b.
- * A fully blocked row yields NaN in O and P, as in the reference.  d_k, d_v <= 128, multiples of 4. */
+ * A fully blocked row yields NaN in O and P, as in the reference.  d_k, d_v multiples of 4; up to 128 the fused
+ * single-kernel path runs, beyond that a general three-launch path (S = QK^T, masked softmax, PV) that keeps its
+ * scores in `attn` -- which must then be given (LAMP_E_WORKSPACE otherwise). */
 int lamp_sdpa_fwd(const float* q, const float* k, const float* v, float* out, float* attn,
                   int32_t B, int32_t H, int32_t lq, int32_t lk, int32_t d_k, int32_t d_v,
                   float inv_temperature, const lamp_mask* mask, const lamp_attn_layout* layout,

@@ -291,14 +291,15 @@ def sdpa(q, k, v, mask, inv_temperature, need_attn=True):
     N, lq, dk = q.shape
     lk, dv = k.size(1), v.size(2)
     out = torch.empty((N, lq, dv), dtype=torch.float32, device=q.device)
-    attn = torch.empty((N, lq, lk), dtype=torch.float32, device=q.device) if need_attn else None
+    wide = dk > 128 or dv > 128  # the general path keeps its scores in the map buffer
+    attn = torch.empty((N, lq, lk), dtype=torch.float32, device=q.device) if (need_attn or wide) else None
     mstruct, keep = make_mask(mask, N, lq, lk)
     lay = AttnLayout(lq * dk, 0, dk, lk * dk, 0, dk, lk * dv, 0, dv, lq * dv, 0, dv)
     check(lib().lamp_sdpa_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(attn), N, 1, lq, lk, dk, dv,
                               float(inv_temperature), C.byref(mstruct) if mstruct is not None else None,
                               C.byref(lay), stream()), 'lamp_sdpa_fwd')
     del keep
-    return out, attn
+    return out, (attn if need_attn else None)
 
 
 def sdpa_fused(q, k, v, n_head, mask_struct, inv_temperature, need_attn=True, fast_maps=False):
@@ -312,7 +313,8 @@ def sdpa_fused(q, k, v, n_head, mask_struct, inv_temperature, need_attn=True, fa
     lk, H = k.size(1), n_head
     dk, dv = hq // H, v.size(2) // H
     out = torch.empty((B, lq, H * dv), dtype=torch.float32, device=q.device)
-    attn = torch.empty((H * B, lq, lk), dtype=torch.float32, device=q.device) if need_attn else None
+    wide = dk > 128 or dv > 128  # the general path keeps its scores in the map buffer
+    attn = torch.empty((H * B, lq, lk), dtype=torch.float32, device=q.device) if (need_attn or wide) else None
     lay = AttnLayout(lq * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lk * H * dv, dv, H * dv, lq * H * dv, dv, H * dv)
     m = C.byref(mask_struct) if mask_struct is not None else None
     if fast_maps and need_attn:
@@ -322,7 +324,7 @@ def sdpa_fused(q, k, v, n_head, mask_struct, inv_temperature, need_attn=True, fa
         return out, attn
     check(lib().lamp_sdpa_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(attn), B, H, lq, lk, dk, dv,
                               float(inv_temperature), m, C.byref(lay), stream()), 'lamp_sdpa_fwd')
-    return out, attn
+    return out, (attn if need_attn else None)
 
 
 def mha_weights(mod):

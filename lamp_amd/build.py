@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'liblamp_hip.so')
-SOURCES = ['gemm.hip', 'gemm_gen.hip', 'attention.hip', 'pointwise.hip', 'backward.hip', 'api.hip']
+SOURCES = ['gemm.hip', 'gemm_gen.hip', 'attention.hip', 'attention_general.hip', 'pointwise.hip', 'backward.hip', 'api.hip']
 HEADERS = [os.path.join(CSRC, 'lamp_kernels.h'), os.path.join(HERE, '..', 'include', 'lamp_hip.h')]
 
 

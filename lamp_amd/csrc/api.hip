@@ -103,7 +103,9 @@ static int check_mask(const lamp_mask* m) {
 // Scratch of one MultiHeadAttention call on B samples.
 struct MhaScratch {
     float *Q, *K, *V, *A;
+    float* S = nullptr;  // (h*B, lq, lk) score scratch, only for d_k or d_v > 128 (attention_general.hip)
 };
+static inline bool wide_heads(int dk, int dv) { return dk > 128 || dv > 128; }
 
 // MultiHeadAttention.forward (lamp/SubLayers.py:77-121).  `xq_shared`: xq is ONE [lq, d] block used
 // by every sample (decoder layer 0: the label embeddings) -- its projection is then
@@ -154,6 +156,7 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
 
     AttnParams a{};
     a.Q = q_ready ? q_ready : sc.Q; a.K = sc.K; a.V = need_v ? sc.V : nullptr; a.O = need_v ? sc.A : nullptr; a.P = attn;
+    a.scratch = sc.S;
     a.B = B; a.H = h; a.lq = lq; a.lk = lk; a.dk = dk; a.dv = dv;
     a.P_batch = P_batch > 0 ? P_batch : B; a.P_b0 = P_b0;
     a.lay.q_b = xq_shared ? 0 : int64_t(lq) * hdk; a.lay.q_h = dk; a.lay.q_r = hdk;
@@ -248,10 +251,11 @@ static int ffn_core(const float* x, int64_t M, int d, int dff, const lamp_ffn_we
                             logits);
 }
 
-static size_t mha_ws_floats(int64_t B, int64_t lq, int64_t lk, int hdk, int hdv) {
-    // Q, K, V, A -- each rounded to 256 bytes by the carver
+static size_t mha_ws_floats(int64_t B, int64_t lq, int64_t lk, int hdk, int hdv, int64_t score_floats = 0) {
+    // Q, K, V, A (+ the score scratch of wide heads) -- each rounded to 256 bytes by the carver
     auto r = [](size_t n) { return align_up(n * sizeof(float), 256) / sizeof(float); };
-    return r(size_t(B) * lq * hdk) + r(size_t(B) * lk * hdk) + r(size_t(B) * lk * hdv) + r(size_t(B) * lq * hdv);
+    return r(size_t(B) * lq * hdk) + r(size_t(B) * lk * hdk) + r(size_t(B) * lk * hdv) + r(size_t(B) * lq * hdv) +
+           (score_floats ? r(size_t(score_floats)) : 0);
 }
 
 }  // namespace lamp
@@ -332,7 +336,8 @@ size_t lamp_mha_workspace_bytes(int32_t B, int32_t lq, int32_t lk, int32_t d_mod
                                 int32_t d_v) {
     (void)d_model;
     if (B <= 0 || lq <= 0 || lk <= 0 || n_head <= 0 || d_k <= 0 || d_v <= 0) return 0;
-    return mha_ws_floats(B, lq, lk, n_head * d_k, n_head * d_v) * sizeof(float);
+    return mha_ws_floats(B, lq, lk, n_head * d_k, n_head * d_v,
+                         wide_heads(d_k, d_v) ? int64_t(n_head) * B * lq * lk : 0) * sizeof(float);
 }
 
 int lamp_mha_fwd(const float* xq, const float* xkv, int32_t B, int32_t lq, int32_t lk, int32_t d_model,
@@ -349,6 +354,7 @@ int lamp_mha_fwd(const float* xq, const float* xkv, int32_t B, int32_t lq, int32
     sc.K = c.take(size_t(B) * lk * hdk);
     sc.V = c.take(size_t(B) * lk * hdv);
     sc.A = c.take(size_t(B) * lq * hdv);
+    if (wide_heads(d_k, d_v)) sc.S = c.take(size_t(w->n_head) * B * lq * lk);
     if (!c.ok) return LAMP_E_WORKSPACE;
     return mha_core(xq, false, xkv, B, lq, lk, d_model, d_k, d_v, *w, mask, out, attn, sc, hipStream_t(stream));
 }
@@ -468,6 +474,7 @@ struct FwdPlan {
     int R;                     // rows per sample of the widest activation
     int hdk, hdv;
     size_t side_kv_floats;     // per sample; only carved in two-stream mode
+    size_t score_floats;       // per sample; (h, Rq, R) score scratch of wide heads, else 0
 };
 
 static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
@@ -488,6 +495,9 @@ static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
     pl->fixed_floats = 64 * 8;
     pl->per_sample_floats = size_t(R) * m->d_inner + size_t(Rq) * pl->hdk + size_t(R) * pl->hdk +
                             size_t(R) * pl->hdv + size_t(Rq) * pl->hdv + size_t(L) * m->d_model;
+    // wide heads (d_k or d_v > 128): the scores of the largest attention of the forward go through this scratch
+    pl->score_floats = wide_heads(m->d_k, m->d_v) ? size_t(h) * Rq * R : 0;
+    pl->per_sample_floats += pl->score_floats;
     // K/V of decoder layers >= 1, projected ahead on the side stream (lamp_set_forward_streams(2))
     pl->side_kv_floats = size_t(m->n_layers_dec) * T * (pl->hdk + pl->hdv);
     return 0;
@@ -562,6 +572,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         sc.K = c.take(size_t(mb) * pl.R * pl.hdk);
         sc.V = c.take(size_t(mb) * pl.R * pl.hdv);
         sc.A = c.take(size_t(mb) * Rq * pl.hdv);
+        sc.S = pl.score_floats ? c.take(size_t(mb) * pl.score_floats) : nullptr;
         Y = c.take(size_t(mb) * L * d);
         for (int i = 0; i < n_ahead; ++i) {
             Kahead[i] = c.take(size_t(mb) * T * pl.hdk);
@@ -607,6 +618,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             scr.K = sc.K + int64_t(r_lo) * pl.R * pl.hdk;
             scr.V = sc.V + int64_t(r_lo) * pl.R * pl.hdv;
             scr.A = sc.A + int64_t(r_lo) * Rq * pl.hdv;
+            scr.S = sc.S ? sc.S + int64_t(r_lo) * pl.score_floats : nullptr;
             lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq + int64_t(r_lo) * T, T, 0, nullptr, 0};
             // the label graph: bit-packed rows when the caller provides them (one dword per 32-key tile), else bytes
             lamp_mask label_mask{LAMP_MASK_NONE, 0, nullptr, 0, 0, nullptr, 0};

@@ -437,7 +437,6 @@ extern "C" void lamp_debug_force_attn(int v) { g_force_attn = v; }
 
 int launch_attn(const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.H <= 0 || p.lq <= 0 || p.lk <= 0 || p.dk <= 0 || p.dv <= 0) return LAMP_E_DIMS;
-    if (p.dk > 128 || p.dv > 128) return LAMP_E_UNSUPPORTED;
     if ((p.dk & 3) || (p.dv & 3)) return LAMP_E_UNSUPPORTED;
     if (!p.Q || !p.K) return LAMP_E_NULL;
     if ((!p.V || !p.O) && !(p.P && !p.V && !p.O)) return LAMP_E_NULL;  // V, O optional only with P
@@ -447,6 +446,7 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     if (((L.q_b | L.q_h | L.q_r | L.k_b | L.k_h | L.k_r | L.v_b | L.v_h | L.v_r) & 3) ||
         !aligned16(p.Q) || !aligned16(p.K) || (p.V && !aligned16(p.V)))
         return LAMP_E_ALIGN;
+    if (p.dk > 128 || p.dv > 128) return launch_attn_general(p, s);  // beyond the fused kernel's register budget
     const double flops = 2.0 * p.B * p.H * double(p.lq) * p.lk * (p.dk + p.dv) * (p.P ? 1.5 : 1.0);
     const double bytes = 4.0 * p.B * p.H * (double(p.lq) * (p.dk + p.dv) + double(p.lk) * (p.dk + p.dv)) +
                          (p.P ? 4.0 * p.B * p.H * double(p.lq) * p.lk : 0.0);

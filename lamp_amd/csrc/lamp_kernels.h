@@ -40,6 +40,7 @@ struct AttnParams {
                // both be NULL: probabilities only (the reference's dead encoder self-attention).
     float* lse;  // nullable; with P: single-pass write-out -- scores into P, row log2-sum-exp here [(H*P_batch), lq],
                  // then normalised in place by a second launch (training forward)
+    float* scratch;  // (H*B, lq, lk) floats: score scratch of the general path (d_k or d_v > 128) when P is not given
     int B, H, lq, lk, dk, dv;
     int P_batch, P_b0;  // P is indexed (h * P_batch + P_b0 + b): the maps of a micro-batch inside a larger batch
     lamp_attn_layout lay;
@@ -53,6 +54,7 @@ struct AttnParams {
 
 int launch_gemm(const GemmParams& p, hipStream_t s);
 int launch_attn(const AttnParams& p, hipStream_t s);
+int launch_attn_general(const AttnParams& p, hipStream_t s);  // any d_k / d_v: scores through memory
 size_t gemm_gen_workspace_bytes(int M, int N, int K, int batch);
 int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStream_t s);
 // Counter-based dropout (lamp_dropout): element e of a site is kept iff mix32(e, seed) >= threshold, kept values are

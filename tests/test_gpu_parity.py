@@ -578,11 +578,16 @@ def test_errors_surface_as_status_codes_not_crashes(dev):
     buf = torch.randn(8 * 64 + 4, device=dev)
     assert lib.lamp_linear_fwd(buf.data_ptr() + 4, 8, 64, 64, w.data_ptr(), 32, 64, None, None, 0, 0,
                                out.data_ptr(), 32, N.stream()) == -2
-    # d_k = 132 > 128: LAMP_E_UNSUPPORTED, raised as LampError by the wrapper
-    q = torch.randn(2, 5, 132, device=dev)
+    # d_k = 130 is not a multiple of 4: LAMP_E_UNSUPPORTED, raised as LampError by the wrapper
+    q = torch.randn(2, 5, 130, device=dev)
     with pytest.raises(N.LampError) as ei:
         N.sdpa(q, q, q, None, 1.0)
     assert ei.value.status == -4 and 'not supported' in str(ei.value)
+    # d_k = 132 > 128 runs through the general path
+    q = torch.randn(2, 5, 132, device=dev)
+    o, a = N.sdpa(q, q, q, None, 1.0 / 132 ** 0.5)
+    ref_o, ref_a = R.sdpa(q.cpu(), q.cpu(), q.cpu(), None, 132 ** 0.5)
+    assert max_abs_diff(o, ref_o) < 5e-5 and max_abs_diff(a, ref_a) < TOL_ATTN
     # workspace one byte short of a single sample: LAMP_E_WORKSPACE
     m, sd, blocked, seq, spos, h = make_case(CONFIGS['inveye_8h'], dev)
     model, enc_arr, dec_arr, _q0 = m._native_model()
@@ -600,3 +605,68 @@ def test_errors_surface_as_status_codes_not_crashes(dev):
     assert torch.equal(logits, ref)
     # the earlier failures left no sticky error behind
     assert max_abs_diff(N.linear(x, w), x.double() @ w.double().t()) < 1e-4
+
+
+# ------------------------------------------------------------------ wide heads (d_k, d_v > 128): the general path
+@pytest.mark.parametrize('kind', ['none', 'keys', 'shared_u8', 'shared_bits'])
+def test_sdpa_wide_heads_vs_oracle(dev, kind):
+    """d_k = d_v = 256 (e.g. d_model 512 with 2 heads): S = QK^T, masked softmax, PV as three launches."""
+    from lamp_amd import _native as N
+    g = torch.Generator().manual_seed(41)
+    B, H, lq, lk, dk = 3, 2, 45, 70, 256
+    q, k, v = (torch.randn(B, l, H * dk, generator=g) for l in (lq, lk, lk))
+    blocked = None
+    mask, keep = None, None
+    if kind == 'keys':
+        seq = torch.randint(1, 9, (B, lk), generator=g)
+        seq[0, 40:] = 0
+        seq[2, :] = 0                                  # fully padded sample -> NaN rows
+        blocked = seq.eq(0).unsqueeze(1).expand(B, lq, lk)
+        mask, keep = N.key_token_mask(seq.to(dev), lk)
+    elif kind.startswith('shared'):
+        m2 = torch.rand(lq, lk, generator=g) < 0.5
+        m2[:, 1] = False
+        blocked = m2.unsqueeze(0).expand(B, lq, lk)
+        if kind == 'shared_u8':
+            mask, keep = N.make_mask(m2.to(dev), B, lq, lk)
+        else:
+            bits = N.pack_mask_bits(m2.to(torch.uint8)).to(dev)
+            mask, keep = N.Mask(N.LAMP_MASK_BITS_U32, 0, bits.data_ptr(), 0, bits.size(1), None, 0), bits
+    split = lambda t, l: t.view(B, l, H, dk).permute(2, 0, 1, 3).reshape(H * B, l, dk)  # noqa: E731
+    ref_out, ref_attn = R.sdpa(split(q, lq), split(k, lk), split(v, lk),
+                               blocked.repeat(H, 1, 1) if blocked is not None else None, dk ** 0.5)
+    for need_attn in (True, False):
+        if not need_attn and kind != 'none':
+            continue
+        out, attn = N.sdpa_fused(q.to(dev), k.to(dev), v.to(dev), H, mask, 1.0 / dk ** 0.5, need_attn=need_attn)
+        got = out.view(B, lq, H, dk).permute(2, 0, 1, 3).reshape(H * B, lq, dk)
+        assert torch.equal(torch.isnan(got.cpu()), torch.isnan(ref_out))
+        assert max_abs_diff(torch.nan_to_num(got), torch.nan_to_num(ref_out)) < 5e-5
+        if need_attn:
+            assert max_abs_diff(torch.nan_to_num(attn), torch.nan_to_num(ref_attn)) < TOL_ATTN
+        else:
+            assert attn is None
+    # head-major API (the reference's own layout) and the C boundary without a map buffer
+    o2, _ = N.sdpa(split(q, lq).to(dev), split(k, lk).to(dev), split(v, lk).to(dev),
+                   blocked.repeat(H, 1, 1).to(dev) if blocked is not None else None, 1.0 / dk ** 0.5, need_attn=False)
+    assert max_abs_diff(torch.nan_to_num(o2), torch.nan_to_num(ref_out)) < 5e-5
+
+
+def test_model_with_wide_heads_vs_oracle(dev):
+    """d_model 512 with 2 heads (d_k = 256) and d_model 320 with 1 head: whole-model logits, maps and int_preds."""
+    for cfg in ((300, 37, 40, 512, 512, 2, 'prior', True, 3, 0.2, [40, 11, 25]),
+                (200, 20, 30, 320, 256, 1, 'none', False, 2, 0.0, [30, 7])):
+        m, sd, blocked, seq, spos, h = make_case(cfg, dev)
+        with torch.no_grad():
+            ref = R.forward(sd, seq, spos, h, blocked, return_attns=True)
+            logits, enc, _ = m((seq.to(dev), spos.to(dev)), None, None, None)
+            got = m((seq.to(dev), spos.to(dev)), None, None, None, return_attns=True)
+        assert max_abs_diff(enc, ref[1]) < TOL_ACT and max_abs_diff(logits, ref[0]) < TOL_LOGIT
+        assert max_abs_diff(got[0], ref[0]) < TOL_LOGIT
+        for a, b_ in zip(got[3][1], ref[3][1]):
+            assert max_abs_diff(a, b_) < TOL_ATTN
+        # micro-batching keeps samples bit-identical on this path too
+        m.workspace_limit_bytes = 1
+        with torch.no_grad():
+            lg2, _, _ = m((seq.to(dev), spos.to(dev)), None, None, None)
+        assert torch.equal(lg2, logits)

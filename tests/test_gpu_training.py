@@ -273,3 +273,21 @@ def test_full_size_reuters_step_with_dropout(dev):
         else:
             assert max_abs_diff(g1[n], g2[n]) < 1e-6
     assert (g1['encoder.src_word_emb.weight'][0] == 0).all()   # PAD row
+
+
+def test_gradients_with_wide_heads(dev):
+    """d_k = 160 > 128: the training path through the general attention (scores through memory)."""
+    cfg = (60, 23, 19, 320, 256, 2, 'prior', True, 2, 0.2, [19, 8])
+    m, sd, blocked, seq, spos, h, tgt = build(cfg, dev)
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    ref_logits, _, _ = R.forward(sd64, seq, spos, h, blocked)
+    F.binary_cross_entropy_with_logits(ref_logits, tgt.double()).backward()
+    m.train()
+    logits, _, _ = m((seq.to(dev), spos.to(dev)), None, None, tgt.to(dev))
+    F.binary_cross_entropy_with_logits(logits, tgt.to(dev)).backward()
+    assert max_abs_diff(logits, ref_logits.detach()) < 1e-4
+    for pname, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        ref = sd64[pname].grad
+        assert max_abs_diff(p.grad, ref) <= 3e-4 * ref.abs().max().item() + 1e-9, pname

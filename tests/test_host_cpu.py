@@ -164,7 +164,9 @@ def test_argument_errors_come_back_as_status_codes_without_a_gpu():
     assert lib.lamp_linear_fwd(16, 0, 8, 8, 16, 4, 8, None, None, 0, 0, 16, 4, None) == -1
     assert lib.lamp_layernorm_fwd(16, 4, 6, 16, 16, 1e-5, 16, None) == -4
     lay = N.AttnLayout(*([4] * 12))
-    assert lib.lamp_sdpa_fwd(16, 16, 16, 16, None, 1, 1, 4, 4, 256, 256, 1.0, None, ctypes.byref(lay), None) == -4
+    assert lib.lamp_sdpa_fwd(16, 16, 16, 16, None, 1, 1, 4, 4, 130, 130, 1.0, None, ctypes.byref(lay), None) == -4
+    # wide heads need the map buffer (or scratch) for their scores: reported before any launch
+    assert lib.lamp_sdpa_fwd(16, 16, 16, 16, None, 1, 1, 4, 4, 256, 256, 1.0, None, ctypes.byref(lay), None) == -3
     assert lib.lamp_forward_workspace_bytes(None, 1, 4, 0) == 0
 
 
