@@ -286,7 +286,7 @@ int lamp_layernorm_residual_fwd(const float* x, const float* residual, int64_t r
  *                  gradient of x is dz itself and dx may be NULL),
  *   dgamma, dbeta  [d]: sum_rows dy * zhat, sum_rows dy,
  *   dbias [d]      (nullable): sum_rows of the gradient of x -- the bias gradient of the linear map that produced x.
- * d <= 1024.  Row sums are two-stage in a fixed order (deterministic). */
+ * d <= 4096.  Row sums are two-stage in a fixed order (deterministic). */
 size_t lamp_layernorm_bwd_workspace_bytes(int64_t M, int32_t d);
 int lamp_layernorm_bwd(const float* x, const float* residual, int64_t residual_rows, int64_t M, int32_t d,
                        const float* gamma, float eps, float dropout_p, uint32_t seed, const float* dy, float* dz,

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dy, float* __restrict__ dz,
                                                             float* __restrict__ dz_drop, float* __restrict__ partial,
                                                             DropoutSpec drop) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NP][d]
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [NP][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d / 4;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -99,20 +99,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
+    // combine the four waves' column sums in a fixed order (wave 0, 1, 2, 3) through one [NP][d] LDS block
     float4* r4 = reinterpret_cast<float4*>(red);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            r4[(wave * NP + 0) * nv + c] = ag[i];
-            r4[(wave * NP + 1) * nv + c] = ab[i];
-            if constexpr (NP == 3) r4[(wave * NP + 2) * nv + c] = ax[i];
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + i * 64;
+                if (c < nv) {
+                    if (w == 0) {
+                        r4[0 * nv + c] = ag[i];
+                        r4[1 * nv + c] = ab[i];
+                        if constexpr (NP == 3) r4[2 * nv + c] = ax[i];
+                    } else {
+                        float4 a = r4[0 * nv + c], b = r4[1 * nv + c];
+                        a.x += ag[i].x; a.y += ag[i].y; a.z += ag[i].z; a.w += ag[i].w;
+                        b.x += ab[i].x; b.y += ab[i].y; b.z += ab[i].z; b.w += ab[i].w;
+                        r4[0 * nv + c] = a;
+                        r4[1 * nv + c] = b;
+                        if constexpr (NP == 3) {
+                            float4 x3 = r4[2 * nv + c];
+                            x3.x += ax[i].x; x3.y += ax[i].y; x3.z += ax[i].z; x3.w += ax[i].w;
+                            r4[2 * nv + c] = x3;
+                        }
+                    }
+                }
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     float* out = partial + int64_t(blockIdx.x) * NP * d;
-    for (int e = threadIdx.x; e < NP * d; e += 256)
-        out[e] = (red[e] + red[NP * d + e]) + (red[2 * NP * d + e] + red[3 * NP * d + e]);
+    for (int e = threadIdx.x; e < NP * d; e += 256) out[e] = red[e];
 }
 
 // partial[gy][col] = sum over this row chunk of x[row][col]; eight independent chains per thread keep loads in flight
@@ -238,7 +256,7 @@ int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_
                          const DropoutSpec* drop, const float* dy, float* dz, float* dz_drop, float* dgamma, float* dbeta,
                          float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
     if (M <= 0 || d <= 0) return LAMP_E_DIMS;
-    if ((d & 3) || d > 1024) return LAMP_E_UNSUPPORTED;
+    if ((d & 3) || d > 4096) return LAMP_E_UNSUPPORTED;
     const bool dr = drop && drop->threshold > 0;
     if (!x || !g || !dy || !dz || !dgamma || !dbeta || !ws || (dr && !dz_drop)) return LAMP_E_NULL;
     if (!aligned16(x) || !aligned16(dy) || !aligned16(dz) || !aligned16(g) || (res && !aligned16(res)) || !aligned16(ws) ||
@@ -248,7 +266,7 @@ int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_
     const int grid = lnb_grid(M);
     float* partial = static_cast<float*>(ws);
     const int np = dbias ? 3 : 2;
-    const size_t lds = size_t(4) * np * d * sizeof(float);
+    const size_t lds = size_t(np) * d * sizeof(float);
     const int nv = (d / 4 + 63) / 64;
     const DropoutSpec ds = dr ? *drop : DropoutSpec{0u, 1.f, 0u};
     ProfScope prof(LAMP_K_LAYERNORM, 0.0, 12.0 * double(M) * d, s);
@@ -270,8 +288,12 @@ int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_
         LAMP_LNB_NV(1);
     else if (nv <= 2)
         LAMP_LNB_NV(2);
-    else
+    else if (nv <= 4)
         LAMP_LNB_NV(4);
+    else if (nv <= 8)
+        LAMP_LNB_NV(8);
+    else
+        LAMP_LNB_NV(16);
 #undef LAMP_LNB_NV
 #undef LAMP_LNB
     if (int e = int(hipGetLastError())) return e;

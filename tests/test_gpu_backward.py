@@ -97,7 +97,8 @@ def test_matmul_nt_rejects_bad_operands(dev):
         N_.matmul_nt(a.double(), a.double())
 
 
-@pytest.mark.parametrize('M,d,r_rows', [(7, 64, 0), (2880, 512, 0), (2880, 512, 90), (333, 1024, 0), (5, 36, 0), (9664, 512, 0)])
+@pytest.mark.parametrize('M,d,r_rows', [(7, 64, 0), (2880, 512, 0), (2880, 512, 90), (333, 1024, 0), (5, 36, 0), (9664, 512, 0),
+                                        (130, 2048, 0), (67, 4096, 0)])
 def test_layernorm_residual_fwd_and_bwd_vs_autograd(dev, M, d, r_rows):
     from lamp_amd import _native as N_
     g = torch.Generator().manual_seed(M + d)
