@@ -103,7 +103,8 @@ static int check_mask(const lamp_mask* m) {
 // Scratch of one MultiHeadAttention call on B samples.
 struct MhaScratch {
     float *Q, *K, *V, *A;
-    float* S = nullptr;  // (h*B, lq, lk) score scratch, only for d_k or d_v > 128 (attention_general.hip)
+    float* S = nullptr;    // (h*B, lq, lk) score scratch, only for d_k or d_v > 128 (attention_general.hip)
+    float* lse = nullptr;  // [h][B][lq] row log-sum-exp: lets requested attention maps come from the single-pass kernel
 };
 static inline bool wide_heads(int dk, int dv) { return dk > 128 || dv > 128; }
 
@@ -157,6 +158,8 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     AttnParams a{};
     a.Q = q_ready ? q_ready : sc.Q; a.K = sc.K; a.V = need_v ? sc.V : nullptr; a.O = need_v ? sc.A : nullptr; a.P = attn;
     a.scratch = sc.S;
+    // maps + output: single-pass kernel (same O bits as without maps), scores normalised in place afterwards
+    if (attn && need_v && sc.lse) a.lse = sc.lse;
     a.B = B; a.H = h; a.lq = lq; a.lk = lk; a.dk = dk; a.dv = dv;
     a.P_batch = P_batch > 0 ? P_batch : B; a.P_b0 = P_b0;
     a.lay.q_b = xq_shared ? 0 : int64_t(lq) * hdk; a.lay.q_h = dk; a.lay.q_r = hdk;
@@ -336,8 +339,9 @@ size_t lamp_mha_workspace_bytes(int32_t B, int32_t lq, int32_t lk, int32_t d_mod
                                 int32_t d_v) {
     (void)d_model;
     if (B <= 0 || lq <= 0 || lk <= 0 || n_head <= 0 || d_k <= 0 || d_v <= 0) return 0;
-    return mha_ws_floats(B, lq, lk, n_head * d_k, n_head * d_v,
-                         wide_heads(d_k, d_v) ? int64_t(n_head) * B * lq * lk : 0) * sizeof(float);
+    return (mha_ws_floats(B, lq, lk, n_head * d_k, n_head * d_v,
+                          wide_heads(d_k, d_v) ? int64_t(n_head) * B * lq * lk : 0) +
+            align_up(size_t(n_head) * B * lq * sizeof(float), 256) / sizeof(float)) * sizeof(float);
 }
 
 int lamp_mha_fwd(const float* xq, const float* xkv, int32_t B, int32_t lq, int32_t lk, int32_t d_model,
@@ -355,6 +359,7 @@ int lamp_mha_fwd(const float* xq, const float* xkv, int32_t B, int32_t lq, int32
     sc.V = c.take(size_t(B) * lk * hdv);
     sc.A = c.take(size_t(B) * lq * hdv);
     if (wide_heads(d_k, d_v)) sc.S = c.take(size_t(w->n_head) * B * lq * lk);
+    sc.lse = c.take(size_t(w->n_head) * B * lq);
     if (!c.ok) return LAMP_E_WORKSPACE;
     return mha_core(xq, false, xkv, B, lq, lk, d_model, d_k, d_v, *w, mask, out, attn, sc, hipStream_t(stream));
 }
@@ -475,6 +480,7 @@ struct FwdPlan {
     int hdk, hdv;
     size_t side_kv_floats;     // per sample; only carved in two-stream mode
     size_t score_floats;       // per sample; (h, Rq, R) score scratch of wide heads, else 0
+    size_t lse_floats;         // per sample; (h, Rq)
 };
 
 static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
@@ -492,12 +498,14 @@ static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
     pl->hdv = h * m->d_v;
     const int Rq = want_attn ? R : L;  // the Q / A buffers only see encoder rows when maps are wanted
     // + 64 floats of slack per region for the carver's 256-byte rounding
-    pl->fixed_floats = 64 * 8;
+    pl->fixed_floats = 64 * 10;
     pl->per_sample_floats = size_t(R) * m->d_inner + size_t(Rq) * pl->hdk + size_t(R) * pl->hdk +
                             size_t(R) * pl->hdv + size_t(Rq) * pl->hdv + size_t(L) * m->d_model;
     // wide heads (d_k or d_v > 128): the scores of the largest attention of the forward go through this scratch
     pl->score_floats = wide_heads(m->d_k, m->d_v) ? size_t(h) * Rq * R : 0;
     pl->per_sample_floats += pl->score_floats;
+    pl->lse_floats = size_t(h) * Rq;  // row log-sum-exp of an attention whose maps are requested
+    pl->per_sample_floats += pl->lse_floats;
     // K/V of decoder layers >= 1, projected ahead on the side stream (lamp_set_forward_streams(2))
     pl->side_kv_floats = size_t(m->n_layers_dec) * T * (pl->hdk + pl->hdv);
     return 0;
@@ -573,6 +581,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         sc.V = c.take(size_t(mb) * pl.R * pl.hdv);
         sc.A = c.take(size_t(mb) * Rq * pl.hdv);
         sc.S = pl.score_floats ? c.take(size_t(mb) * pl.score_floats) : nullptr;
+        sc.lse = c.take(size_t(mb) * pl.lse_floats);
         Y = c.take(size_t(mb) * L * d);
         for (int i = 0; i < n_ahead; ++i) {
             Kahead[i] = c.take(size_t(mb) * T * pl.hdk);
@@ -619,6 +628,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             scr.V = sc.V + int64_t(r_lo) * pl.R * pl.hdv;
             scr.A = sc.A + int64_t(r_lo) * Rq * pl.hdv;
             scr.S = sc.S ? sc.S + int64_t(r_lo) * pl.score_floats : nullptr;
+            scr.lse = sc.lse + int64_t(r_lo) * pl.lse_floats;
             lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq + int64_t(r_lo) * T, T, 0, nullptr, 0};
             // the label graph: bit-packed rows when the caller provides them (one dword per 32-key tile), else bytes
             lamp_mask label_mask{LAMP_MASK_NONE, 0, nullptr, 0, 0, nullptr, 0};

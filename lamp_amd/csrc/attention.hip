@@ -335,12 +335,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                 for (int s2 = 1; s2 < KSPLIT; ++s2) {
                     const float* other = smem + (wave + s2) * CW;
                     const float ws = exp2f(other[DP * 32 + l31] - m_use);
-                    l_run += other[(DP + 1) * 32 + l31] * ws;
+                    l_run = fmaf(other[(DP + 1) * 32 + l31], ws, l_run);  // explicit fma: same bits in every variant
 #pragma unroll
                     for (int e = 0; e < DVB; ++e)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            o[e][r] += other[(e * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] * ws;
+                            o[e][r] = fmaf(other[(e * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31], ws, o[e][r]);
                 }
                 m_run = m_all;  // l_run is now relative to the merged maximum
             }
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             // row log2-sum-exp of the scaled scores: probabilities = exp2(score - lse).  A fully blocked row has
             // l = 0 -> lse = -inf -> exp2(-inf - -inf) = NaN, as the reference's softmax gives.
             if (wave_active && ks == 0 && hi == 0 && qi < p.lq)
-                p.lse[(int64_t(h) * p.P_batch + p.P_b0 + b) * int64_t(p.lq) + qi] =
+                p.lse[(int64_t(h) * p.B + b) * int64_t(p.lq) + qi] =  // local to this call: [H][B][lq]
                     ((m_run == -INFINITY) ? 0.f : m_run) + log2f(l_run);
         }
         const float inv_l = 1.0f / l_run;
@@ -486,8 +486,8 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     }
     for (int h = 0; h < p.H; ++h) {
         const int64_t off = (int64_t(h) * p.P_batch + p.P_b0) * p.lq;
-        hipLaunchKernelGGL(softmax_from_scores_kernel, dim3(unsigned(g)), dim3(256), 0, s, p.P + off * p.lk, p.lse + off,
-                           rows_per_head, p.lk);
+        hipLaunchKernelGGL(softmax_from_scores_kernel, dim3(unsigned(g)), dim3(256), 0, s, p.P + off * p.lk,
+                           p.lse + int64_t(h) * rows_per_head, rows_per_head, p.lk);
     }
     return int(hipGetLastError());
 }

@@ -38,7 +38,7 @@ struct AttnParams {
     float* O;
     float* P;  // nullable: (H*B, lq, lk) probabilities, index h*B + b.  With P given, V and O may
                // both be NULL: probabilities only (the reference's dead encoder self-attention).
-    float* lse;  // nullable; with P: single-pass write-out -- scores into P, row log2-sum-exp here [(H*P_batch), lq],
+    float* lse;  // nullable; with P: single-pass write-out -- scores into P, row log2-sum-exp here [H][B][lq] (this call's samples),
                  // then normalised in place by a second launch (training forward)
     float* scratch;  // (H*B, lq, lk) floats: score scratch of the general path (d_k or d_v > 128) when P is not given
     int B, H, lq, lk, dk, dv;
