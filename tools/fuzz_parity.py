@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Randomised differential campaign on the MI355X (not part of the pytest suite: minutes, not seconds).
+
+    python tools/fuzz_parity.py <n_eval_cases> <n_train_cases>
+
+Eval: random model shapes (1-8 heads, d_k 4..256 incl. widths beyond the fused attention kernel, 1-3 + 1-3 layers,
+every mask kind, L and T from 1 to 300 / 150, ragged lengths, with / without decoder self-attention): logits and
+enc_output against the fp64 oracle (bar: max(1e-4, 4 x the oracle's own fp32-vs-fp64 gap)), every attention map against
+the fp32 oracle (1e-5), and logits bit-identical with and without return_attns.
+Train: dropout 0, BCE loss, every parameter's gradient against torch.autograd on the fp64 oracle (relative 2e-3 of
+the gradient's max; a larger gap on one layer's FFN is what a ReLU pre-activation of ~1e-7 flipping sign between fp32
+and fp64 looks like -- check the sub-layer in isolation before calling it a bug).
+Round 1: 300 eval cases, 0 mismatches; 80 train cases, 1 flagged = such a ReLU kink (the sub-layer's backward, given
+its own input and output gradient, agreed with fp64 to 3e-7).
+"""
+import sys, random, torch, traceback
+import torch.nn.functional as F
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+from oracle import lamp_ref as R
+from lamp_amd.Models import LAMP
+dev = torch.device('cuda:0')
+
+def mad(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    if a.numel() == 0: return 0.0
+    na, nb = torch.isnan(a), torch.isnan(b)
+    if not torch.equal(na, nb): return float('inf')
+    return (torch.nan_to_num(a) - torch.nan_to_num(b)).abs().max().item()
+
+def case(i):
+    rng = random.Random(5000 + i)
+    h = rng.choice([1, 2, 3, 4, 8])
+    dk = rng.choice([4, 8, 12, 16, 20, 32, 36, 64, 128, 132, 160, 256])
+    if h >= 4 and dk > 64: dk = 64
+    d = h * dk
+    if h == 1: d = rng.choice([4, 8, 20, 64, 128, 200])
+    dff = rng.choice([4, 12, 64, 100, 200, 516])
+    L = rng.choice([1, 2, 17, 31, 32, 33, 64, 95, 129, 300])
+    T = rng.choice([1, 2, 5, 31, 32, 33, 97, 150])
+    B = rng.randint(1, 6)
+    mask = rng.choice(['prior', 'none', 'inveye'])
+    pos = rng.random() < 0.5
+    n_enc, n_dec = rng.randint(1, 3), rng.randint(1, 3)
+    no_slf = rng.random() < 0.2
+    lengths = [rng.randint(1, T) for _ in range(B)]
+    lengths[rng.randrange(B)] = T
+    return dict(h=h, d=d, dff=dff, L=L, T=T, B=B, mask=mask, pos=pos, n_enc=n_enc, n_dec=n_dec, no_slf=no_slf, lengths=lengths, V=rng.choice([5, 40, 1000]))
+
+def build(c, i):
+    h, d = c['h'], c['d']
+    sd = R.make_state_dict(c['V'], c['L'], c['T'], d, c['dff'], h, c['n_enc'], c['n_dec'], pos_emb=c['pos'], seed=i, no_dec_self_att=c['no_slf'])
+    adj = R.make_adjacency(c['L'], 0.2, i) if c['mask'] == 'prior' else None
+    seq, spos = R.make_batch(c['B'], c['V'], c['T'], lengths=c['lengths'], seed=i)
+    m = LAMP(c['V'], c['L'], c['T'], c['L'], n_layers_enc=c['n_enc'], n_layers_dec=c['n_dec'], n_head=h, n_head2=h, d_word_vec=d, d_model=d,
+             d_inner_hid=c['dff'], d_k=d // h, d_v=d // h, encoder='graph', decoder='graph', dropout=0.0, dec_dropout=0.0,
+             no_enc_pos_embedding=not c['pos'], no_dec_self_att=c['no_slf'], label_adj_matrix=adj.clone() if adj is not None else None,
+             label_mask=c['mask'], dec_dropout2=False)
+    m.load_state_dict(sd)
+    return m.to(dev), sd, R.label_block_mask(adj, c['mask'], c['L']), seq, spos
+
+n_eval, n_train, bad = int(sys.argv[1]), int(sys.argv[2]), 0
+for i in range(n_eval):
+    c = case(i)
+    try:
+        m, sd, blocked, seq, spos = build(c, i)
+        m.eval()
+        with torch.no_grad():
+            ref = R.forward(sd, seq, spos, c['h'], blocked, return_attns=True)
+            ref64, _, _ = R.forward(R.to_dtype(sd, torch.float64), seq, spos, c['h'], blocked)
+            lg, enc, _ = m((seq.to(dev), spos.to(dev)), None, None, None)
+            got = m((seq.to(dev), spos.to(dev)), None, None, None, return_attns=True)
+        gap = mad(ref[0], ref64)
+        tol = max(1e-4, 4 * gap)
+        errs = [mad(enc, ref[1]) < 5e-5, mad(lg, ref64) < tol, torch.equal(got[0], lg)]
+        for a, b in zip(got[3][1], ref[3][1]): errs.append(mad(a, b) < 1e-5)
+        for a, b in zip(got[3][0], ref[3][0]):
+            if a is not None: errs.append(mad(a, b) < 1e-5)
+        for a, b in zip(got[2][0], ref[2][0]): errs.append(mad(a, b) < 1e-5)
+        if not all(errs):
+            bad += 1; print('EVAL MISMATCH', i, c, errs, mad(lg, ref64), tol)
+    except Exception as e:
+        bad += 1; print('EVAL ERROR', i, c, repr(e)); traceback.print_exc()
+print('eval cases', n_eval, 'bad', bad)
+bad_t = 0
+for i in range(n_train):
+    c = case(10000 + i)
+    c['L'] = min(c['L'], 95); c['T'] = min(c['T'], 97)
+    c['lengths'] = [min(x, c['T']) for x in c['lengths']]; c['lengths'][0] = c['T']
+    try:
+        m, sd, blocked, seq, spos = build(c, i)
+        tgt = (torch.rand(c['B'], c['L'], generator=torch.Generator().manual_seed(i)) < 0.3).float()
+        sd64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        rl, _, _ = R.forward(sd64, seq, spos, c['h'], blocked)
+        F.binary_cross_entropy_with_logits(rl, tgt.double()).backward()
+        m.train()
+        lg, _, _ = m((seq.to(dev), spos.to(dev)), None, None, tgt.to(dev))
+        F.binary_cross_entropy_with_logits(lg, tgt.to(dev)).backward()
+        worst = 0.0
+        for n, p in m.named_parameters():
+            if p.grad is None: continue
+            ref = sd64[n].grad
+            if n == 'decoder.tgt_word_emb.weight' and 'tgt_word_proj.weight' in sd64 and sd64['tgt_word_proj.weight'].grad is not None:
+                ref = ref + sd64['tgt_word_proj.weight'].grad
+            scale = ref.abs().max().item()
+            rel = mad(p.grad, ref) / (scale + 1e-12) if scale > 0 else mad(p.grad, ref)
+            if scale > 1e-9: worst = max(worst, rel)
+        if not (worst < 2e-3):
+            bad_t += 1; print('TRAIN MISMATCH', i, c, worst)
+    except Exception as e:
+        bad_t += 1; print('TRAIN ERROR', i, c, repr(e)); traceback.print_exc()
+print('train cases', n_train, 'bad', bad_t)
