@@ -73,6 +73,7 @@ class LAMP(nn.Module):
         self.d_model, self.d_inner, self.d_k, self.d_v = d_model, d_inner_hid, d_k, d_v
         self.n_labels = n_tgt_vocab
         self._native_cache = None
+        self._param_list = None
 
     def get_trainable_parameters(self):
         """Everything but the frozen sinusoid table (reference: lamp/Models.py:97-107)."""
@@ -84,7 +85,11 @@ class LAMP(nn.Module):
     # ------------------------------------------------------------------ native model descriptor
     def _native_model(self):
         """Build (and cache, keyed on every parameter's data_ptr) the lamp_model struct."""
-        params = [p for p in self.parameters()]
+        # the Parameter objects are stable (load_state_dict / .to() replace their data, not them); a DataParallel
+        # replica is a shallow copy whose parameters ARE different tensors -- detected by the first one
+        params = self._param_list
+        if params is None or params[0] is not next(self.parameters()):
+            params = self._param_list = [p for p in self.parameters()]
         mask = self.decoder.label_mask_u8
         tiles = self.decoder.label_tiles
         bits = self.decoder.label_mask_bits

@@ -104,10 +104,17 @@ class EvalBatcher(object):
 
 def get_gold_binary(gold, n_labels):
     """(B, n_labels) float 0/1 matrix from padded target rows WITHOUT their leading BOS: drop PADs, drop the
-    trailing EOS, shift ids by the four specials (utils/utils.py:205-216)."""
-    out = torch.zeros((gold.size(0), n_labels + 4))
-    for i in range(gold.size(0)):
-        ids = gold[i][gold[i] > 0][:-1]
-        if len(ids) > 0:
-            out[i].index_fill_(0, ids, 1)
-    return out[:, 4:]
+    trailing EOS (the last remaining id of the row), shift ids by the four specials (utils/utils.py:205-216).
+    numpy, one fancy-index store instead of the reference's per-row index_fill_ (tiny torch CPU ops pay the
+    thread-pool wake-up of a 128-core host: 2 ms per call measured)."""
+    g = gold.numpy() if isinstance(gold, torch.Tensor) else np.asarray(gold)
+    B, W = g.shape
+    out = np.zeros((B, n_labels + 4), dtype=np.float32)
+    if W:
+        keep = g > 0
+        cols = np.arange(W)[None, :]
+        last = np.where(keep, cols, -1).max(axis=1, keepdims=True)
+        keep &= cols != last
+        rows = np.broadcast_to(np.arange(B)[:, None], g.shape)
+        out[rows[keep], g[keep]] = 1.0
+    return torch.from_numpy(out[:, 4:].copy())

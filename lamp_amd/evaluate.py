@@ -12,41 +12,76 @@ other batches' kernels (the batch-32 forward is a chain of ~35 short kernels: 38
 2 / 4 batches in flight on reuters).
 Each sample's numbers are identical in every mode.
 """
+import itertools
+
 import torch
 
 from . import _native as N
 from .data import get_gold_binary
 
 
-def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True, int_preds=False, streams=1):
+def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True, int_preds=False, streams=1,
+               prefetch=256):
     """-> (all_predictions (n, L) cpu, all_targets (n, L) cpu, bce_total float), as test.py:16-78 returns
-    them.  `batches` yields ((src_seq, src_pos), adj, tgt) like lamp_amd.data.EvalBatcher."""
+    them.  `batches` yields ((src_seq, src_pos), adj, tgt) like lamp_amd.data.EvalBatcher.
+
+    Up to `prefetch` batches are staged on the device before their forwards are issued: a host-to-device copy from
+    pageable memory blocks the host until the stream reaches it, so copies interleaved with forwards (as the
+    reference's loop does) serialise host and GPU -- measured 18k vs 30k+ samples/s on a reuters-sized test split."""
     model.eval()
     n = batches.n_insts
     all_targets = torch.zeros(n, n_labels)
-    lanes = [torch.cuda.Stream(device=device) for _ in range(streams)] if streams > 1 else [None]
-    done = []  # (row offset, real rows, probs (device), row_loss (device))
-    for bi, ((src_seq, src_pos), adj, tgt) in enumerate(batches):
-        real = src_seq.size(0)
-        gold_binary = get_gold_binary(tgt[:, 1:], n_labels)
-        lo = bi * batch_size
-        all_targets[lo:lo + real] = gold_binary
-        lane = lanes[bi % len(lanes)]
-        with torch.cuda.stream(lane) if lane is not None else _null():
-            src_seq, src_pos = src_seq.to(device), src_pos.to(device)
-            if pad_last_batch and real < batch_size:
-                pad = torch.zeros((batch_size - real, src_seq.size(1)), dtype=src_seq.dtype, device=device)
-                src_seq = torch.cat((src_seq, pad), 0)
-                src_pos = torch.cat((src_pos, pad), 0)
-            pred = model((src_seq, src_pos), adj, None, None, int_preds=int_preds)[0]
-            probs, row_loss = N.sigmoid_bce(pred[:real], gold_binary.to(device))
-        done.append((lo, real, probs, row_loss))
-    torch.cuda.synchronize(device)
     all_predictions = torch.zeros(n, n_labels)
     bce_total = 0.0
-    for lo, real, probs, row_loss in done:
-        all_predictions[lo:lo + real] = probs.cpu()
-        bce_total += float(row_loss.cpu().double().sum()) / (real * n_labels)  # reduction='mean' per batch
+    lanes = [torch.cuda.Stream(device=device) for _ in range(streams)] if streams > 1 else [None]
+    it = iter(enumerate(batches))
+    while True:
+        host = []
+        for bi, ((src_seq, src_pos), adj, tgt) in itertools.islice(it, prefetch):
+            real = src_seq.size(0)
+            gold_binary = get_gold_binary(tgt[:, 1:], n_labels)
+            lo = bi * batch_size
+            all_targets[lo:lo + real] = gold_binary
+            host.append((bi, lo, real, src_seq, src_pos, adj, gold_binary))
+        if not host:
+            break
+        # ONE host-to-device copy per stage for the token ids + positions and one for the targets (each small pageable
+        # copy costs ~0.25 ms of blocked host time); the batches are views into the device buffers
+        if all(h[3].is_cuda for h in host):
+            ids_d = None
+        else:
+            ids_d = torch.cat([torch.stack((h[3].reshape(-1), h[4].reshape(-1))).reshape(-1) for h in host]).to(device)
+        gold_d_all = torch.cat([h[6] for h in host]).to(device)
+        staged, off, row = [], 0, 0
+        for bi, lo, real, src_seq, src_pos, adj, gold_binary in host:
+            if ids_d is None:
+                seq_d, pos_d = src_seq, src_pos
+            else:
+                cnt = src_seq.numel()
+                seq_d = ids_d[off:off + cnt].view(src_seq.shape)
+                pos_d = ids_d[off + cnt:off + 2 * cnt].view(src_seq.shape)
+                off += 2 * cnt
+            staged.append((bi, lo, real, seq_d, pos_d, adj, gold_d_all[row:row + real]))
+            row += real
+        done = []  # (row offset, real rows, probs (device), mean BCE of the batch (device scalar))
+        for bi, lo, real, src_seq, src_pos, adj, gold_d in staged:
+            lane = lanes[bi % len(lanes)]
+            with torch.cuda.stream(lane) if lane is not None else _null():
+                if pad_last_batch and real < batch_size:
+                    pad = torch.zeros((batch_size - real, src_seq.size(1)), dtype=src_seq.dtype, device=device)
+                    src_seq = torch.cat((src_seq, pad), 0)
+                    src_pos = torch.cat((src_pos, pad), 0)
+                pred = model((src_seq, src_pos), adj, None, None, int_preds=int_preds)[0]
+                probs, row_loss = N.sigmoid_bce(pred[:real], gold_d)
+                done.append((lo, real, probs, row_loss.double().sum() / (real * n_labels)))  # reduction='mean' per batch
+        torch.cuda.synchronize(device)
+        probs_all = torch.cat([p for _, _, p, _ in done]).cpu()      # one device-to-host copy per stage
+        bce_total += float(torch.stack([l for _, _, _, l in done]).sum().cpu())
+        off = 0
+        for lo, real, _, _ in done:
+            all_predictions[lo:lo + real] = probs_all[off:off + real]
+            off += real
+        del staged, done, host
     return all_predictions, all_targets, bce_total
 
 
