@@ -170,6 +170,23 @@ int lamp_linear_fwd(const float* A, int64_t M, int32_t K, int64_t lda,
                     const float* residual, int64_t ldr, int32_t relu,
                     float* C, int64_t ldc, lamp_stream_t stream);
 
+/* Deferred LayerNorm: y = LayerNorm(z) is never stored when its only consumers are linear maps.
+ *   lamp_layernorm_fold  (weights only, once per weight version):
+ *        W_folded[n,k] = W[n,k] * gamma[k],  s[n] = sum_k W_folded[n,k],  bias_folded[n] = W[n,:] . beta + bias[n]
+ *   lamp_linear_ln_fwd:   C = act( LayerNorm(z) . W^T + bias ) + residual'
+ *        computed as  rstd_m * (z . W_folded^T - mean_m * s) + bias_folded  with each row's mean / rstd accumulated
+ *        while the kernel streams z (single pass: var = E[z^2] - E[z]^2); s == NULL: z is used as it is.
+ *        stats_out (nullable) receives (mean, rstd) per row [M][2].
+ *        residual' = residual, or -- with r_stats -- LayerNorm(residual) recomputed from the pre-norm rows, their
+ *        (mean, rstd) and (r_gamma, r_beta): the sub-layer residual of lamp/SubLayers.py:115,140 without y.
+ * K, lda, ldw multiples of 4. */
+int lamp_layernorm_fold(const float* W, int32_t N, int32_t K, const float* gamma, const float* beta, const float* bias,
+                        float* W_folded, float* s, float* bias_folded, lamp_stream_t stream);
+int lamp_linear_ln_fwd(const float* z, int64_t M, int32_t K, int64_t lda, const float* W_folded, int32_t N, int64_t ldw,
+                       const float* s, const float* bias_folded, float eps, const float* residual, int64_t ldr,
+                       const float* r_stats, const float* r_gamma, const float* r_beta, int32_t relu, float* C,
+                       int64_t ldc, float* stats_out, lamp_stream_t stream);
+
 /* nn.LayerNorm over the last dim, biased variance, eps inside the sqrt (lamp/SubLayers.py:68,130).
  * y may alias x.  d must be a multiple of 4. */
 int lamp_layernorm_fwd(const float* x, int64_t M, int32_t d, const float* gamma, const float* beta,

@@ -88,6 +88,9 @@ PROTOTYPES = {
     'lamp_version': (C.c_int, []),
     'lamp_strerror': (C.c_char_p, [C.c_int]),
     'lamp_linear_fwd': (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
+    'lamp_layernorm_fold': (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'lamp_linear_ln_fwd': (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _f, _vp, _i64, _vp, _vp, _vp, _i32,
+                                     _vp, _i64, _vp, _vp]),
     'lamp_layernorm_fwd': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _f, _vp, _vp]),
     'lamp_sdpa_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f,
                                 C.POINTER(Mask), C.POINTER(AttnLayout), _vp]),
@@ -273,6 +276,39 @@ def linear(x, weight, bias=None, residual=None, relu=False):
     check(lib().lamp_linear_fwd(ptr(x2), M, K, K, ptr(w), N, K, ptr(b), ptr(r), N, int(relu), ptr(out), N,
                                 stream()), 'lamp_linear_fwd')
     return out.view(*x.shape[:-1], N)
+
+
+def layernorm_fold(weight, gamma, beta, bias=None):
+    """-> (W_folded, s, bias_folded) for lamp_linear_ln_fwd (weights only; cache per weight version)."""
+    require_device(weight, gamma, beta, bias)
+    w = f32c(weight)
+    Nn, K = w.shape
+    wf = torch.empty_like(w)
+    s = torch.empty(Nn, dtype=torch.float32, device=w.device)
+    bf = torch.empty_like(s)
+    check(lib().lamp_layernorm_fold(ptr(w), Nn, K, ptr(f32c(gamma)), ptr(f32c(beta)), ptr(f32c(bias) if bias is not None else None),
+                                    ptr(wf), ptr(s), ptr(bf), stream()), 'lamp_layernorm_fold')
+    return wf, s, bf
+
+
+def linear_ln(z, folded, eps=1e-5, residual=None, r_stats=None, r_gamma=None, r_beta=None, relu=False, want_stats=False):
+    """act(LayerNorm(z) . W^T + bias) + residual' through the deferred-LayerNorm GEMM (folded = layernorm_fold(...)).
+    -> C or (C, stats) with stats (M, 2) = (mean, rstd) of z's rows."""
+    require_device(z, residual, r_stats)
+    wf, s, bf = folded
+    z2 = f32c(z).reshape(-1, z.size(-1))
+    M, K = z2.shape
+    Nn = wf.size(0)
+    out = torch.empty((M, Nn), dtype=torch.float32, device=z2.device)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=z2.device) if want_stats else None
+    r = f32c(residual).reshape(M, Nn) if residual is not None else None
+    check(lib().lamp_linear_ln_fwd(ptr(z2), M, K, K, ptr(wf), Nn, K, ptr(s), ptr(bf), eps, ptr(r), Nn,
+                                   ptr(f32c(r_stats) if r_stats is not None else None),
+                                   ptr(f32c(r_gamma) if r_gamma is not None else None),
+                                   ptr(f32c(r_beta) if r_beta is not None else None), int(bool(relu)), ptr(out), Nn,
+                                   ptr(stats), stream()), 'lamp_linear_ln_fwd')
+    out = out.view(tuple(z.shape[:-1]) + (Nn,))
+    return (out, stats) if want_stats else out
 
 
 def layernorm(x, gamma, beta, eps=1e-5):

@@ -316,6 +316,26 @@ int lamp_linear_fwd(const float* A, int64_t M, int32_t K, int64_t lda, const flo
     return linear(A, M, K, lda, Ws, 1, N, ldw, bs, residual, ldr, relu, Cs, ldc, hipStream_t(stream));
 }
 
+int lamp_layernorm_fold(const float* W, int32_t N, int32_t K, const float* gamma, const float* beta, const float* bias,
+                        float* W_folded, float* s, float* bias_folded, lamp_stream_t stream) {
+    return launch_fold_layernorm(W, N, K, gamma, beta, bias, W_folded, s, bias_folded, hipStream_t(stream));
+}
+
+int lamp_linear_ln_fwd(const float* z, int64_t M, int32_t K, int64_t lda, const float* W_folded, int32_t N, int64_t ldw,
+                       const float* s, const float* bias_folded, float eps, const float* residual, int64_t ldr,
+                       const float* r_stats, const float* r_gamma, const float* r_beta, int32_t relu, float* C,
+                       int64_t ldc, float* stats_out, lamp_stream_t stream) {
+    if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return LAMP_E_DIMS;
+    if (r_stats && (!residual || !r_gamma || !r_beta)) return LAMP_E_NULL;
+    GemmParams p{};
+    p.A = z; p.lda = lda; p.M = M; p.K = K; p.N = N; p.nseg = 1; p.ldw = ldw; p.ldc = ldc;
+    p.R = residual; p.ldr = ldr; p.relu = relu;
+    p.W[0] = W_folded; p.bias[0] = bias_folded; p.C[0] = C;
+    p.ln_s[0] = s; p.ln_eps = eps; p.stats_out = stats_out;
+    p.r_stats = r_stats; p.r_gamma = r_gamma; p.r_beta = r_beta;
+    return launch_gemm(p, hipStream_t(stream));
+}
+
 int lamp_layernorm_fwd(const float* x, int64_t M, int32_t d, const float* gamma, const float* beta, float eps,
                        float* y, lamp_stream_t stream) {
     return launch_layernorm(x, M, d, gamma, beta, eps, nullptr, 0, y, hipStream_t(stream));

@@ -47,7 +47,7 @@ struct GemmTile {
     static_assert(BK % 8 == 0, "BK must be a multiple of 8");
 };
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool LN = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
                                                                           int tiles_n) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
@@ -110,6 +110,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         vob[i] = unsigned(row * ldw + c4 * 4) * 4u;
     }
 
+    // LN: running sum / sum of squares of this thread's A rows (a thread's float4s stay in the same rows for every k-tile)
+    float ssum[LN ? T::A_LD : 1], ssq[LN ? T::A_LD : 1];
+    if constexpr (LN) {
+#pragma unroll
+        for (int i = 0; i < T::A_LD; ++i) ssum[i] = ssq[i] = 0.f;
+    }
     auto gload = [&](int k0, float4 (&ra)[T::A_LD], float4 (&rb)[T::B_LD]) {
         if constexpr (KTAIL) {
             // K is not a multiple of BK: columns past K must read as 0 (the row range check cannot see them)
@@ -139,6 +145,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
             const int idx = tid + i * T::NT;
             const int row = idx / C4, c4 = idx - row * C4;
             *reinterpret_cast<float4*>(a + row * S + c4 * 4) = ra[i];
+            if constexpr (LN) {
+                // Every A tile passes through here exactly once.  Row statistics in a summation order that does not
+                // depend on the tile configuration (samples must come out bit-identical for any batch size): the 16
+                // values of each 16-wide k-block are combined by a 4-lane butterfly, blocks are added in ascending k.
+                float f = (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
+                // explicit fma: the compiler must not contract these differently in different instantiations
+                float q = fmaf(ra[i].x, ra[i].x, ra[i].y * ra[i].y) + fmaf(ra[i].z, ra[i].z, ra[i].w * ra[i].w);
+                f += __shfl_xor(f, 1, 64); q += __shfl_xor(q, 1, 64);
+                f += __shfl_xor(f, 2, 64); q += __shfl_xor(q, 2, 64);
+                if constexpr (C4 == 8) {  // BK = 32: lanes 0-3 of the row hold the even 16-block, lanes 4-7 the odd one
+                    const float fo = __shfl_xor(f, 4, 64), qo = __shfl_xor(q, 4, 64);
+                    const bool low = (c4 & 4) == 0;
+                    ssum[i] = (ssum[i] + (low ? f : fo)) + (low ? fo : f);
+                    ssq[i] = (ssq[i] + (low ? q : qo)) + (low ? qo : q);
+                } else {
+                    static_assert(C4 == 4 || C4 == 8, "deferred LayerNorm supports BK = 16 or 32");
+                    ssum[i] += f;
+                    ssq[i] += q;
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < T::B_LD; ++i) {
@@ -197,6 +223,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         __syncthreads();
     }
 
+    // LN: finish the row statistics: (mean, rstd) go to LDS -- the tile buffers are free after the last barrier -- and, from the
+    // workgroups of the first column tile, to stats_out.
+    float* row_stats = smem;  // [BM][2]
+    if constexpr (LN) {
+#pragma unroll
+        for (int i = 0; i < T::A_LD; ++i) {
+            const float a = ssum[i], b = ssq[i];  // already complete (and equal) in every lane of the row
+            const int idx = tid + i * T::NT;
+            const int row = idx / C4;
+            if ((idx - row * C4) == 0) {
+                const float inv_k = 1.0f / float(p.K);
+                const float mean = a * inv_k;
+                const float var = fmaf(-mean, mean, b * inv_k);
+                const float rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + p.ln_eps);
+                row_stats[2 * row] = mean;
+                row_stats[2 * row + 1] = rstd;
+                if (p.stats_out && tn_all == 0 && row < rows_m) {
+                    p.stats_out[2 * (m0 + row)] = mean;
+                    p.stats_out[2 * (m0 + row) + 1] = rstd;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     // Stores to rows past M fall outside the descriptor and are dropped by the hardware; columns past
     // N are steered to an out-of-range offset.
@@ -208,6 +259,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         make_rsrc(has_r ? p.R + m0 * p.ldr + n0 : p.A, has_r ? (uint64_t(rows_m - 1) * ldr + rows_n) * 4u : 0);
     const float* bias = p.bias[seg];
     const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias ? bias + n0 : p.A, bias ? uint64_t(rows_n) * 4u : 0);
+    const float* lns = LN ? p.ln_s[seg] : nullptr;
+    const __amdgpu_buffer_rsrc_t rsS = make_rsrc(lns ? lns + n0 : p.A, lns ? uint64_t(rows_n) * 4u : 0);
+    const bool r_ln = LN && has_r && p.r_stats != nullptr;
+    const __amdgpu_buffer_rsrc_t rsRS =
+        make_rsrc(r_ln ? p.r_stats + 2 * m0 : p.A, r_ln ? uint64_t(rows_m) * 8u : 0);
+    const __amdgpu_buffer_rsrc_t rsRG = make_rsrc(r_ln ? p.r_gamma + n0 : p.A, r_ln ? uint64_t(rows_n) * 4u : 0);
+    const __amdgpu_buffer_rsrc_t rsRB = make_rsrc(r_ln ? p.r_beta + n0 : p.A, r_ln ? uint64_t(rows_n) * 4u : 0);
     // C/D layouts: 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16;
     //              16x16 block: col = lane&15, row = 4*(lane>>4) + r,            r < 4.
     auto blk_row = [&](int r) { return MF == 32 ? (r & 3) + 8 * (r >> 2) : r; };
@@ -218,6 +276,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         const int lcol = lcol0 + j * MF;
         const bool col_ok = lcol < rows_n;
         const float bv = bload1(rsBias, col_ok ? unsigned(lcol) * 4u : OOB);
+        float sv = 0.f, rg = 1.f, rb = 0.f;
+        if constexpr (LN) {
+            sv = bload1(rsS, col_ok ? unsigned(lcol) * 4u : OOB);
+            if (r_ln) {
+                rg = bload1(rsRG, col_ok ? unsigned(lcol) * 4u : OOB);
+                rb = bload1(rsRB, col_ok ? unsigned(lcol) * 4u : OOB);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < T::MI; ++i) {
             float res[NACC];
@@ -226,12 +292,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
                 for (int r = 0; r < NACC; ++r) {
                     const int lrow = lrow0 + i * MF + blk_row(r);
                     res[r] = bload1(rsR, col_ok ? unsigned(lrow * ldr + lcol) * 4u : OOB);
+                    if constexpr (LN) {
+                        if (r_ln) {  // the residual is LayerNorm(z_prev), recomputed from z_prev and its row statistics
+                            const f32x2 st = bload2(rsRS, unsigned(lrow) * 8u);
+                            res[r] = fmaf((res[r] - st.x) * st.y, rg, rb);
+                        }
+                    }
                 }
             }
 #pragma unroll
             for (int r = 0; r < NACC; ++r) {
                 const int lrow = lrow0 + i * MF + blk_row(r);
-                float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r];
+                if constexpr (LN) {
+                    if (lns)  // rstd * (acc - mean * s) + bias', as explicit fmas
+                        v = fmaf(row_stats[2 * lrow + 1], fmaf(-row_stats[2 * lrow], sv, v), bv);
+                    else
+                        v += bv;
+                } else {
+                    v += bv;
+                }
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (has_r) v += res[r];
                 bstore1(rsC, col_ok ? unsigned(lrow * ldc + lcol) * 4u : OOB, v);
@@ -240,10 +320,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     }
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool LN = false>
 static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
-    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF>;
+    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, LN>;
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -270,6 +350,12 @@ template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF = 32>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
     if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF>(p, s);
     return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF>(p, s);
+}
+// production tiles only: the deferred-LayerNorm variant (K a multiple of BK is required by the callers' d_model)
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+static int launch_cfg_ln(const GemmParams& p, hipStream_t s) {
+    if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, 16, true>(p, s);
+    return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, 16, true>(p, s);
 }
 
 // Debug/tuning hook (not part of the ABI header): force a tile configuration.  0 = heuristic.
@@ -322,6 +408,15 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     // also ahead of the best 32x32x2 tile (128x128x32: 128-139).  The 32x32x2 tiles remain as forced configs 1-8.
     auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nseg; };
     const int64_t t64 = tiles(64, 64);
+    bool ln = p.r_stats != nullptr || p.stats_out != nullptr;
+    for (int i = 0; i < p.nseg; ++i) ln = ln || p.ln_s[i] != nullptr;
+    if (ln) {  // same menu, deferred-LayerNorm instantiations
+        if (p.r_stats && (!p.R || !p.r_gamma || !p.r_beta)) return LAMP_E_NULL;
+        if (tiles(128, 64) >= 2048 && p.K >= 512) return launch_cfg_ln<128, 64, 16, 2, 2>(p, s);
+        if (t64 >= 2048) return launch_cfg_ln<64, 64, 32, 2, 2>(p, s);
+        if (t64 >= 1200) return launch_cfg_ln<64, 64, 16, 2, 2>(p, s);
+        return launch_cfg_ln<32, 64, 32, 1, 4>(p, s);
+    }
     if (tiles(128, 64) >= 2048 && p.K >= 512) return launch_cfg<128, 64, 16, 2, 2, 16>(p, s);  // short K: fewer, deeper steps
     if (t64 >= 2048) return launch_cfg<64, 64, 32, 2, 2, 16>(p, s);
     if (t64 >= 1200) return launch_cfg<64, 64, 16, 2, 2, 16>(p, s);

@@ -29,6 +29,18 @@ struct GemmParams {
     const float* R;  // residual, same for every segment (only meaningful with nseg == 1)
     int64_t ldr;
     int relu;
+    // ---- deferred LayerNorm (LN = true instantiations; see gemm.hip) ----
+    // A holds PRE-LayerNorm rows z; the weights passed in W are folded, W'[n,k] = W[n,k] * gamma[k], and
+    // bias' = W.beta + bias, ln_s[n] = sum_k W'[n,k].  The kernel accumulates each row's mean / rstd while it streams
+    // A and applies   C = rstd * (A.W'^T - mean * ln_s) + bias'   in the epilogue -- LayerNorm(z).W^T + bias without a
+    // LayerNorm launch and without ever storing LayerNorm(z).
+    const float* ln_s[GEMM_MAX_SEG];  // all null = plain GEMM
+    float ln_eps;
+    float* stats_out;                 // nullable [M][2] (mean, rstd) of A's rows, for the consumer of the residual below
+    // R holds PRE-LayerNorm rows too: residual = (R - mean) * rstd * r_gamma + r_beta with r_stats [M][2]
+    const float* r_stats;             // null = R is used as it is
+    const float* r_gamma;
+    const float* r_beta;
 };
 
 struct AttnParams {
@@ -104,6 +116,8 @@ int launch_embed(const int64_t* seq, const int64_t* pos, int64_t n_tok, const fl
 int launch_diag(const float* y, const float* w, int B, int L, int d, float* logits, hipStream_t s);
 int launch_prior_graph(const int64_t* ids, const int64_t* offsets, int64_t n_samples, int L, float* adj,
                        uint8_t* blocked, hipStream_t s);
+int launch_fold_layernorm(const float* W, int N, int K, const float* gamma, const float* beta, const float* bias, float* Wf,
+                          float* s, float* bf, hipStream_t st);
 int launch_sigmoid_bce(const float* logits, const float* targets, int64_t n_rows, int L, float* probs,
                        float* row_loss, hipStream_t s);
 

@@ -670,3 +670,37 @@ def test_model_with_wide_heads_vs_oracle(dev):
         with torch.no_grad():
             lg2, _, _ = m((seq.to(dev), spos.to(dev)), None, None, None)
         assert torch.equal(lg2, logits)
+
+
+# ------------------------------------------------------------------ deferred LayerNorm (LN folded into the consuming GEMM)
+@pytest.mark.parametrize('M,K,N_', [(2880, 512, 512), (9664, 512, 512), (2880, 512, 1536), (31456, 1024, 2048), (77, 64, 96), (5, 36, 7)])
+def test_linear_with_deferred_layernorm_vs_torch(dev, M, K, N_):
+    """act(LayerNorm(z) W^T + b) + LayerNorm_r(z_prev) without either LayerNorm being materialised, on every production
+    tile (the shapes pick all four), ragged edges, and row statistics written for the next consumer."""
+    from lamp_amd import _native as N
+    g = torch.Generator().manual_seed(M + K)
+    z = torch.randn(M, K, generator=g) * 1.7 + 0.3
+    w = torch.randn(N_, K, generator=g) / K ** 0.5
+    b = torch.randn(N_, generator=g)
+    gam, bet = 1 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    zprev = torch.randn(M, N_, generator=g) * 0.8 - 0.2
+    rg, rb = 1 + 0.2 * torch.randn(N_, generator=g), 0.1 * torch.randn(N_, generator=g)
+    y = torch.nn.functional.layer_norm(z.double(), (K,), gam.double(), bet.double(), 1e-5)
+    res = torch.nn.functional.layer_norm(zprev.double(), (N_,), rg.double(), rb.double(), 1e-5)
+    ref = (y @ w.double().t() + b.double()).clamp_min(0) + res
+    folded = N.layernorm_fold(w.to(dev), gam.to(dev), bet.to(dev), b.to(dev))
+    mean_p = zprev.double().mean(1)
+    rstd_p = 1.0 / torch.sqrt(zprev.double().var(1, unbiased=False) + 1e-5)
+    r_stats = torch.stack((mean_p, rstd_p), 1).float().to(dev)
+    out, stats = N.linear_ln(z.to(dev), folded, residual=zprev.to(dev), r_stats=r_stats, r_gamma=rg.to(dev), r_beta=rb.to(dev),
+                             relu=True, want_stats=True)
+    assert max_abs_diff(out, ref) < 5e-5
+    assert max_abs_diff(stats[:, 0], z.double().mean(1)) < 1e-5
+    assert max_abs_diff(stats[:, 1], 1.0 / torch.sqrt(z.double().var(1, unbiased=False) + 1e-5)) < 2e-5
+    # plain residual, no activation
+    out2 = N.linear_ln(z.to(dev), folded, residual=zprev.to(dev))
+    assert max_abs_diff(out2, y @ w.double().t() + b.double() + zprev.double()) < 5e-5
+    # deterministic and independent of the rows around it (batch invariance)
+    out3 = N.linear_ln(z[: max(1, M // 3)].to(dev), folded)
+    full = N.linear_ln(z.to(dev), folded)
+    assert torch.equal(out3, full[: max(1, M // 3)])
