@@ -129,6 +129,8 @@ def main():
     ap.add_argument('--no-pipelined', action='store_true',
                     help='skip the extra two-batches-in-flight measurement (use under rocprofv3: overlapping '
                          'kernels inflate per-kernel durations)')
+    ap.add_argument('--fuse-ln', type=int, default=None, choices=[0, 1],
+                    help='override LAMP.fuse_layernorm (deferred LayerNorm: fewer launches, logits equal to rounding)')
     ap.add_argument('--ragged', action='store_true',
                     help='sequence lengths U{lo..hi} padded to the batch maximum (SURVEY.md 8d variant ii) instead of fixed T')
     ap.add_argument('--mask', default=None, choices=['prior', 'none', 'inveye'], help='override the workload label mask')
@@ -171,6 +173,8 @@ def main():
         lengths = torch.randint(lo, hi + 1, (args.batch,), generator=g).tolist()
         w['T'] = max(lengths)  # padded length of this batch: what the kernels process and what F_live counts
     model, sd, adj, seq, pos = build(w, args.batch, device, seed=rank, lengths=lengths)
+    if args.fuse_ln is not None:
+        model.fuse_layernorm = bool(args.fuse_ln)
     src = (seq.to(device), pos.to(device))
 
     def step():
@@ -292,7 +296,7 @@ def main():
                                 else 'fixed', w['L'], w['d'], w['dff'], w['h'], w['mask']),
                    'batch_per_gpu': args.batch, 'parallelism': 'batch-sharded x%d, no collectives' % n_gpus,
                    'launch': 'hip-graph replay' if args.graph else 'eager (one lamp_forward call per step)',
-                   'streams_per_forward': args.streams},
+                   'streams_per_forward': args.streams, 'deferred_layernorm': bool(model.fuse_layernorm)},
         'roofline': {
             'bound': 'mfma', 'kernel': 'gemm_nt_kernel (fp32 MFMA 16x16x4), all launches of a forward',
             'achieved': gemm_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',

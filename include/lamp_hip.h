@@ -119,6 +119,31 @@ typedef struct lamp_dec_layer {  /* lamp/Layers.py:22-48 */
     lamp_ffn_weights pos_ffn2;
 } lamp_dec_layer;
 
+/* Deferred LayerNorm (optional, lamp_model.fused_ln): a sub-layer's closing LayerNorm is not launched when every
+ * consumer of its output is a linear map of the next sub-layer; the producing GEMM's epilogue then also writes the
+ * rows' partial sums, the consuming map runs on the pre-norm rows with FOLDED weights (lamp_layernorm_fold: w = W *
+ * gamma, s = row sums of w, b = W . beta + bias) and the residual add recomputes LayerNorm from the pre-norm rows
+ * and their statistics (lamp_linear_ln_fwd).  All pointers depend on
+ * weights only: a caller computes them once per weight version.  Entries that do not apply stay all-NULL. */
+typedef struct lamp_folded_linear {
+    const float* w; /* [out, in] */
+    const float* s; /* [out] */
+    const float* b; /* [out] */
+} lamp_folded_linear;
+typedef struct lamp_fused_ln_enc_layer {
+    lamp_folded_linear w1; /* pos_ffn.w_1 folded with the PREVIOUS encoder layer's pos_ffn LayerNorm (layers >= 1) */
+} lamp_fused_ln_enc_layer;
+typedef struct lamp_fused_ln_dec_layer {
+    lamp_folded_linear enc_q;   /* enc_attn.w_qs with the previous layer's pos_ffn2 LayerNorm (layers >= 1) */
+    lamp_folded_linear ffn1_w1; /* pos_ffn1.w_1 with this layer's enc_attn LayerNorm (layers >= 1) */
+    lamp_folded_linear slf_q, slf_k, slf_v; /* slf_attn projections with this layer's pos_ffn1 LayerNorm */
+    lamp_folded_linear ffn2_w1; /* pos_ffn2.w_1 with this layer's slf_attn LayerNorm (pos_ffn1's without self-attention) */
+} lamp_fused_ln_dec_layer;
+typedef struct lamp_fused_ln {
+    const lamp_fused_ln_enc_layer* enc; /* n_layers_enc entries */
+    const lamp_fused_ln_dec_layer* dec; /* n_layers_dec entries */
+} lamp_fused_ln;
+
 /* The whole graph-encoder / graph-decoder model (lamp/Models.py:18-94).  Host-side struct of
  * device pointers; enc_layers / dec_layers are host arrays. */
 typedef struct lamp_model {
@@ -142,6 +167,11 @@ typedef struct lamp_model {
      * 132-134), so a caller may compute it once per weight version (lamp_linear_fwd) and
      * pass it here; NULL = lamp_forward projects it on every call. */
     const float* dec0_query;
+    /* Optional deferred-LayerNorm data (see lamp_fused_ln): with it, and when no intermediate outputs are requested,
+     * lamp_forward skips the LayerNorm launches whose output only feeds the next sub-layer (7 of 10 at 2+2 layers).
+     * Results agree with the plain path to fp32 rounding (single-pass row statistics), not bitwise; a sample's bits
+     * still do not depend on the batch it is in.  Needs n_head > 1 everywhere. */
+    const lamp_fused_ln* fused_ln;
 } lamp_model;
 
 /* Optional extra outputs of lamp_forward (return_attns / int_preds, lamp/Models.py:127-135).
@@ -173,19 +203,22 @@ int lamp_linear_fwd(const float* A, int64_t M, int32_t K, int64_t lda,
 /* Deferred LayerNorm: y = LayerNorm(z) is never stored when its only consumers are linear maps.
  *   lamp_layernorm_fold  (weights only, once per weight version):
  *        W_folded[n,k] = W[n,k] * gamma[k],  s[n] = sum_k W_folded[n,k],  bias_folded[n] = W[n,:] . beta + bias[n]
- *   lamp_linear_ln_fwd:   C = act( LayerNorm(z) . W^T + bias ) + residual'
- *        computed as  rstd_m * (z . W_folded^T - mean_m * s) + bias_folded  with each row's mean / rstd accumulated
- *        while the kernel streams z (single pass: var = E[z^2] - E[z]^2); s == NULL: z is used as it is.
- *        stats_out (nullable) receives (mean, rstd) per row [M][2].
- *        residual' = residual, or -- with r_stats -- LayerNorm(residual) recomputed from the pre-norm rows, their
- *        (mean, rstd) and (r_gamma, r_beta): the sub-layer residual of lamp/SubLayers.py:115,140 without y.
- * K, lda, ldw multiples of 4. */
+ *   lamp_linear_ln_fwd:   C = act( A' . W^T + bias ) + residual'   (+ row partials of C)
+ *        part_out (nullable): per row and 16-column group of C the partial (sum, sum of squares),
+ *          [M][4*ceil(N/64)][2] -- the statistics a LayerNorm of C's rows needs, produced in this GEMM's epilogue.
+ *        s != NULL: `a` holds PRE-norm rows with partials a_part [M][4*ceil(K/64)][2] (written by the GEMM that produced
+ *          them), W is W_folded and bias is bias_folded; the result is rstd_m * (a . W^T - mean_m * s) + bias =
+ *          LayerNorm(a) . W_orig^T + bias_orig (single-pass statistics: var = E[a^2] - E[a]^2).
+ *        r_part != NULL: `residual` holds PRE-norm rows with partials r_part [M][4*ceil(N/64)][2]; residual' =
+ *          LayerNorm(residual; r_gamma, r_beta) recomputed on the fly (lamp/SubLayers.py:115,140 without storing y).
+ *        Nothing is added to the GEMM's main loop; summation orders are fixed, independent of the tile configuration.
+ * K, lda, ldw multiples of 4; a pre-norm operand needs K a multiple of the tile depth (32). */
 int lamp_layernorm_fold(const float* W, int32_t N, int32_t K, const float* gamma, const float* beta, const float* bias,
                         float* W_folded, float* s, float* bias_folded, lamp_stream_t stream);
-int lamp_linear_ln_fwd(const float* z, int64_t M, int32_t K, int64_t lda, const float* W_folded, int32_t N, int64_t ldw,
-                       const float* s, const float* bias_folded, float eps, const float* residual, int64_t ldr,
-                       const float* r_stats, const float* r_gamma, const float* r_beta, int32_t relu, float* C,
-                       int64_t ldc, float* stats_out, lamp_stream_t stream);
+int lamp_linear_ln_fwd(const float* a, int64_t M, int32_t K, int64_t lda, const float* a_part, const float* W, int32_t N,
+                       int64_t ldw, const float* s, const float* bias, float eps, const float* residual, int64_t ldr,
+                       const float* r_part, const float* r_gamma, const float* r_beta, int32_t relu, float* C, int64_t ldc,
+                       float* part_out, lamp_stream_t stream);
 
 /* nn.LayerNorm over the last dim, biased variance, eps inside the sqrt (lamp/SubLayers.py:68,130).
  * y may alias x.  d must be a multiple of 4. */

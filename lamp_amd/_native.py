@@ -58,13 +58,30 @@ class DecLayer(C.Structure):
                 ('pos_ffn2', FfnWeights)]
 
 
+class FoldedLinear(C.Structure):  # include/lamp_hip.h: lamp_folded_linear
+    _fields_ = [('w', _vp), ('s', _vp), ('b', _vp)]
+
+
+class FusedLnEncLayer(C.Structure):
+    _fields_ = [('w1', FoldedLinear)]
+
+
+class FusedLnDecLayer(C.Structure):
+    _fields_ = [('enc_q', FoldedLinear), ('ffn1_w1', FoldedLinear), ('slf_q', FoldedLinear), ('slf_k', FoldedLinear),
+                ('slf_v', FoldedLinear), ('ffn2_w1', FoldedLinear)]
+
+
+class FusedLn(C.Structure):
+    _fields_ = [('enc', C.POINTER(FusedLnEncLayer)), ('dec', C.POINTER(FusedLnDecLayer))]
+
+
 class Model(C.Structure):
     _fields_ = [('n_src_vocab', C.c_int32), ('n_position', C.c_int32), ('n_labels', C.c_int32),
                 ('d_model', C.c_int32), ('d_inner', C.c_int32), ('d_k', C.c_int32), ('d_v', C.c_int32),
                 ('n_layers_enc', C.c_int32), ('n_layers_dec', C.c_int32), ('reserved', C.c_int32),
                 ('src_word_emb', _vp), ('position_enc', _vp), ('tgt_word_emb', _vp), ('w_out', _vp),
                 ('label_mask', _vp), ('label_mask_bits', _vp), ('label_tiles', _vp), ('enc_layers', C.POINTER(EncLayer)), ('dec_layers', C.POINTER(DecLayer)),
-                ('dec0_query', _vp)]
+                ('dec0_query', _vp), ('fused_ln', C.POINTER(FusedLn))]
 
 
 class GemmDesc(C.Structure):  # include/lamp_hip.h: lamp_gemm_desc
@@ -89,7 +106,7 @@ PROTOTYPES = {
     'lamp_strerror': (C.c_char_p, [C.c_int]),
     'lamp_linear_fwd': (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     'lamp_layernorm_fold': (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'lamp_linear_ln_fwd': (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _f, _vp, _i64, _vp, _vp, _vp, _i32,
+    'lamp_linear_ln_fwd': (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _i64, _vp, _vp, _f, _vp, _i64, _vp, _vp, _vp, _i32,
                                      _vp, _i64, _vp, _vp]),
     'lamp_layernorm_fwd': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _f, _vp, _vp]),
     'lamp_sdpa_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f,
@@ -291,24 +308,26 @@ def layernorm_fold(weight, gamma, beta, bias=None):
     return wf, s, bf
 
 
-def linear_ln(z, folded, eps=1e-5, residual=None, r_stats=None, r_gamma=None, r_beta=None, relu=False, want_stats=False):
-    """act(LayerNorm(z) . W^T + bias) + residual' through the deferred-LayerNorm GEMM (folded = layernorm_fold(...)).
-    -> C or (C, stats) with stats (M, 2) = (mean, rstd) of z's rows."""
-    require_device(z, residual, r_stats)
-    wf, s, bf = folded
-    z2 = f32c(z).reshape(-1, z.size(-1))
-    M, K = z2.shape
-    Nn = wf.size(0)
-    out = torch.empty((M, Nn), dtype=torch.float32, device=z2.device)
-    stats = torch.empty((M, 2), dtype=torch.float32, device=z2.device) if want_stats else None
+def linear_ln(a, weight, s=None, bias=None, a_part=None, eps=1e-5, residual=None, r_part=None, r_gamma=None, r_beta=None,
+              relu=False, want_part=False):
+    """act(A' . W^T + bias) + residual' through lamp_linear_ln_fwd (see include/lamp_hip.h):
+    s given: `a` is pre-LayerNorm with row partials a_part and (weight, s, bias) = layernorm_fold(...);
+    r_part given: `residual` is pre-LayerNorm (r_gamma, r_beta); want_part: also return the row partials of the output.
+    -> C or (C, part)."""
+    require_device(a, residual, a_part, r_part)
+    a2 = f32c(a).reshape(-1, a.size(-1))
+    M, K = a2.shape
+    w = f32c(weight)
+    Nn = w.size(0)
+    out = torch.empty((M, Nn), dtype=torch.float32, device=a2.device)
+    part = torch.empty((M, 4 * ((Nn + 63) // 64), 2), dtype=torch.float32, device=a2.device) if want_part else None
     r = f32c(residual).reshape(M, Nn) if residual is not None else None
-    check(lib().lamp_linear_ln_fwd(ptr(z2), M, K, K, ptr(wf), Nn, K, ptr(s), ptr(bf), eps, ptr(r), Nn,
-                                   ptr(f32c(r_stats) if r_stats is not None else None),
-                                   ptr(f32c(r_gamma) if r_gamma is not None else None),
-                                   ptr(f32c(r_beta) if r_beta is not None else None), int(bool(relu)), ptr(out), Nn,
-                                   ptr(stats), stream()), 'lamp_linear_ln_fwd')
-    out = out.view(tuple(z.shape[:-1]) + (Nn,))
-    return (out, stats) if want_stats else out
+    opt = lambda t: ptr(f32c(t)) if t is not None else None  # noqa: E731
+    check(lib().lamp_linear_ln_fwd(ptr(a2), M, K, K, opt(a_part), ptr(w), Nn, K, opt(s), opt(bias), eps, ptr(r), Nn,
+                                   opt(r_part), opt(r_gamma), opt(r_beta), int(bool(relu)), ptr(out), Nn, ptr(part),
+                                   stream()), 'lamp_linear_ln_fwd')
+    out = out.view(tuple(a.shape[:-1]) + (Nn,))
+    return (out, part) if want_part else out
 
 
 def layernorm(x, gamma, beta, eps=1e-5):

@@ -77,9 +77,20 @@ struct Carver {
     }
 };
 
+// Deferred-LayerNorm context of one GEMM (gemm.hip).
+struct LnGemm {
+    const float* s[GEMM_MAX_SEG] = {};  // per segment: row sums of the folded weights (A is pre-norm), or null
+    const float* a_part = nullptr;      // partial (sum, sum of squares) of A's rows per 16-column group, [M][ln_parts][2]
+    const float* r_part = nullptr;      // R is pre-norm: its rows' partials ...
+    const float* r_g = nullptr;         // ... and the pending LayerNorm's gamma / beta
+    const float* r_b = nullptr;
+    float* part_out = nullptr;          // partials of this GEMM's output rows (the next sub-layer's input)
+};
+static inline int ln_parts(int d) { return 4 * ((d + 63) / 64); }  // 16-column groups, padded to whole 64-column tiles
+
 static int linear(const float* A, int64_t M, int K, int64_t lda, const float* const* W, int nseg, int N,
                   int64_t ldw, const float* const* bias, const float* R, int64_t ldr, int relu,
-                  float* const* C, int64_t ldc, hipStream_t s) {
+                  float* const* C, int64_t ldc, hipStream_t s, const LnGemm* ln = nullptr) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.M = M; p.K = K; p.N = N; p.nseg = nseg; p.ldw = ldw; p.ldc = ldc;
     p.R = R; p.ldr = ldr; p.relu = relu;
@@ -87,9 +98,27 @@ static int linear(const float* A, int64_t M, int K, int64_t lda, const float* co
         p.W[i] = W[i];
         p.bias[i] = bias ? bias[i] : nullptr;
         p.C[i] = C[i];
+        if (ln) p.ln_s[i] = ln->s[i];
+    }
+    if (ln) {
+        p.ln_eps = 1e-5f;
+        p.a_part = ln->a_part; p.a_nparts = ln_parts(K);
+        p.r_part = ln->r_part; p.r_nparts = ln_parts(N); p.r_gamma = ln->r_g; p.r_beta = ln->r_b;
+        p.part_out = ln->part_out;
     }
     return launch_gemm(p, s);
 }
+
+// A sub-layer whose INPUT is pre-LayerNorm (the previous sub-layer deferred its LayerNorm): the pending norm's affine
+// parameters, the row partials its producer wrote, and the folded weights of this sub-layer's first linear map(s).
+struct LnIn {
+    const float* g;
+    const float* b;
+    const float* part;                                 // [rows][ln_parts(d)][2]
+    const lamp_folded_linear *q = nullptr, *k = nullptr, *v = nullptr;  // attention projections
+    const lamp_folded_linear* w1 = nullptr;            // first FFN map
+};
+static inline bool folded_ok(const lamp_folded_linear* f) { return f && f->w && f->s && f->b; }
 
 static int check_mask(const lamp_mask* m) {
     if (!m) return 0;
@@ -115,8 +144,11 @@ static inline bool wide_heads(int dk, int dv) { return dk > 128 || dv > 128; }
 static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, int lq, int lk, int d, int dk,
                     int dv, const lamp_mha_weights& w, const lamp_mask* mask, float* out, float* attn,
                     const MhaScratch& sc, hipStream_t s, bool kv_ready = false,
-                    const float* q_ready = nullptr, int P_batch = 0, int P_b0 = 0) {
+                    const float* q_ready = nullptr, int P_batch = 0, int P_b0 = 0, const LnIn* in = nullptr,
+                    float* defer_part = nullptr) {
+    const bool defer_out = defer_part != nullptr;  // leave pre-norm rows in `out`, their row partials in defer_part
     const int h = w.n_head;
+    if ((in || defer_out) && (h == 1 || xq_shared || !out)) return LAMP_E_UNSUPPORTED;  // needs fc and per-row residual
     if (h < 1 || dk < 1 || dv < 1) return LAMP_E_DIMS;
     if (!w.w_qs || !w.w_ks || !w.w_vs || (out && (!w.ln_g || !w.ln_b))) return LAMP_E_NULL;
     if (h == 1 && out && dv != d) return LAMP_E_DIMS;  // no fc: O is added to the residual directly
@@ -128,11 +160,31 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     const bool need_v = out != nullptr;
 
     if (self && hdk == hdv && need_v) {
-        const float* W[3] = {w.w_qs, w.w_ks, w.w_vs};
         float* C[3] = {sc.Q, sc.K, sc.V};
-        LAMP_CK(linear(xq, Mq, d, d, W, 3, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
+        if (in) {  // the label state is pre-norm: folded Q/K/V weights, statistics kept for the residual below
+            if (!folded_ok(in->q) || !folded_ok(in->k) || !folded_ok(in->v)) return LAMP_E_NULL;
+            const float* W[3] = {in->q->w, in->k->w, in->v->w};
+            const float* bf[3] = {in->q->b, in->k->b, in->v->b};
+            LnGemm ln;
+            ln.s[0] = in->q->s; ln.s[1] = in->k->s; ln.s[2] = in->v->s;
+            ln.a_part = in->part;
+            LAMP_CK(linear(xq, Mq, d, d, W, 3, hdk, d, bf, nullptr, 0, 0, C, hdk, s, &ln));
+        } else {
+            const float* W[3] = {w.w_qs, w.w_ks, w.w_vs};
+            LAMP_CK(linear(xq, Mq, d, d, W, 3, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
+        }
     } else {
-        if (!q_ready) {
+        if (in && (self || q_ready)) return LAMP_E_UNSUPPORTED;
+        if (in) {
+            if (!folded_ok(in->q)) return LAMP_E_NULL;
+            const float* W[1] = {in->q->w};
+            const float* bf[1] = {in->q->b};
+            float* C[1] = {sc.Q};
+            LnGemm ln;
+            ln.s[0] = in->q->s;
+            ln.a_part = in->part;
+            LAMP_CK(linear(xq, Mq, d, d, W, 1, hdk, d, bf, nullptr, 0, 0, C, hdk, s, &ln));
+        } else if (!q_ready) {
             const float* W[1] = {w.w_qs};
             float* C[1] = {sc.Q};
             LAMP_CK(linear(xq, Mq, d, d, W, 1, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
@@ -186,7 +238,17 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
             LAMP_CK(linear(sc.A, M, hdv, hdv, W, 1, d, hdv, nullptr, nullptr, 0, 0, C, d, s));
             return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, xq, r_mod, out, s);
         }
-        LAMP_CK(linear(sc.A, M, hdv, hdv, W, 1, d, hdv, nullptr, xq, d, 0, C, d, s));
+        if (in || defer_out) {
+            LnGemm ln;
+            if (in) {  // residual = LayerNorm(xq) recomputed from the pre-norm rows and their statistics
+                ln.r_part = in->part; ln.r_g = in->g; ln.r_b = in->b;
+            }
+            ln.part_out = defer_part;
+            LAMP_CK(linear(sc.A, M, hdv, hdv, W, 1, d, hdv, nullptr, xq, d, 0, C, d, s, &ln));
+        } else {
+            LAMP_CK(linear(sc.A, M, hdv, hdv, W, 1, d, hdv, nullptr, xq, d, 0, C, d, s));
+        }
+        if (defer_out) return 0;  // `out` holds the pre-norm rows; the next sub-layer's GEMMs apply this LayerNorm
         return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, out, s);
     }
     return launch_layernorm(sc.A, M, d, w.ln_g, w.ln_b, 1e-5f, xq, r_mod, out, s);
@@ -235,20 +297,42 @@ static int project_kv_layers(const float* x, int64_t Me, int d, int dk, int dv, 
 // PositionwiseFeedForward.forward (lamp/SubLayers.py:133-142); out may alias x.
 static int ffn_core(const float* x, int64_t M, int d, int dff, const lamp_ffn_weights& w, float* out,
                     float* hidden, hipStream_t s, const float* w_out = nullptr, int n_labels = 0,
-                    float* logits = nullptr) {
+                    float* logits = nullptr, const LnIn* in = nullptr, float* defer_part = nullptr) {
     if (!w.w1 || !w.b1 || !w.w2 || !w.b2 || !w.ln_g || !w.ln_b) return LAMP_E_NULL;
-    {
-        const float* W[1] = {w.w1};
-        const float* b[1] = {w.b1};
+    const bool defer_out = defer_part != nullptr;  // leave pre-norm rows in `out`, their row partials in defer_part
+    if (in) {  // x is pre-norm: folded W1, LayerNorm'd residual recomputed in the second epilogue
+        if (!folded_ok(in->w1)) return LAMP_E_NULL;
+        const float* W[1] = {in->w1->w};
+        const float* b[1] = {in->w1->b};
         float* C[1] = {hidden};
-        LAMP_CK(linear(x, M, d, d, W, 1, dff, d, b, nullptr, 0, 1, C, dff, s));
+        LnGemm ln;
+        ln.s[0] = in->w1->s;
+        ln.a_part = in->part;
+        LAMP_CK(linear(x, M, d, d, W, 1, dff, d, b, nullptr, 0, 1, C, dff, s, &ln));
+        const float* W2[1] = {w.w2};
+        const float* b2[1] = {w.b2};
+        float* C2[1] = {out};
+        LnGemm lr;
+        lr.r_part = in->part; lr.r_g = in->g; lr.r_b = in->b;
+        lr.part_out = defer_part;
+        LAMP_CK(linear(hidden, M, dff, dff, W2, 1, d, dff, b2, x, d, 0, C2, d, s, &lr));
+    } else {
+        {
+            const float* W[1] = {w.w1};
+            const float* b[1] = {w.b1};
+            float* C[1] = {hidden};
+            LAMP_CK(linear(x, M, d, d, W, 1, dff, d, b, nullptr, 0, 1, C, dff, s));
+        }
+        {
+            const float* W[1] = {w.w2};
+            const float* b[1] = {w.b2};
+            float* C[1] = {out};
+            LnGemm lp;
+            lp.part_out = defer_part;
+            LAMP_CK(linear(hidden, M, dff, dff, W, 1, d, dff, b, x, d, 0, C, d, s, defer_out ? &lp : nullptr));
+        }
     }
-    {
-        const float* W[1] = {w.w2};
-        const float* b[1] = {w.b2};
-        float* C[1] = {out};
-        LAMP_CK(linear(hidden, M, dff, dff, W, 1, d, dff, b, x, d, 0, C, d, s));
-    }
+    if (defer_out) return 0;  // `out` holds the pre-norm rows
     // with w_out: the final decoder LayerNorm also produces the logits and its output row is not stored
     return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, w_out ? nullptr : out, s, w_out, n_labels,
                             logits);
@@ -321,18 +405,20 @@ int lamp_layernorm_fold(const float* W, int32_t N, int32_t K, const float* gamma
     return launch_fold_layernorm(W, N, K, gamma, beta, bias, W_folded, s, bias_folded, hipStream_t(stream));
 }
 
-int lamp_linear_ln_fwd(const float* z, int64_t M, int32_t K, int64_t lda, const float* W_folded, int32_t N, int64_t ldw,
-                       const float* s, const float* bias_folded, float eps, const float* residual, int64_t ldr,
-                       const float* r_stats, const float* r_gamma, const float* r_beta, int32_t relu, float* C,
-                       int64_t ldc, float* stats_out, lamp_stream_t stream) {
+int lamp_linear_ln_fwd(const float* a, int64_t M, int32_t K, int64_t lda, const float* a_part, const float* W, int32_t N,
+                       int64_t ldw, const float* s, const float* bias, float eps, const float* residual, int64_t ldr,
+                       const float* r_part, const float* r_gamma, const float* r_beta, int32_t relu, float* C, int64_t ldc,
+                       float* part_out, lamp_stream_t stream) {
     if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return LAMP_E_DIMS;
-    if (r_stats && (!residual || !r_gamma || !r_beta)) return LAMP_E_NULL;
+    if ((s && !a_part) || (r_part && (!residual || !r_gamma || !r_beta))) return LAMP_E_NULL;
     GemmParams p{};
-    p.A = z; p.lda = lda; p.M = M; p.K = K; p.N = N; p.nseg = 1; p.ldw = ldw; p.ldc = ldc;
+    p.A = a; p.lda = lda; p.M = M; p.K = K; p.N = N; p.nseg = 1; p.ldw = ldw; p.ldc = ldc;
     p.R = residual; p.ldr = ldr; p.relu = relu;
-    p.W[0] = W_folded; p.bias[0] = bias_folded; p.C[0] = C;
-    p.ln_s[0] = s; p.ln_eps = eps; p.stats_out = stats_out;
-    p.r_stats = r_stats; p.r_gamma = r_gamma; p.r_beta = r_beta;
+    p.W[0] = W; p.bias[0] = bias; p.C[0] = C;
+    p.ln_s[0] = s; p.ln_eps = eps;
+    p.a_part = a_part; p.a_nparts = ln_parts(K);
+    p.r_part = r_part; p.r_nparts = ln_parts(N); p.r_gamma = r_gamma; p.r_beta = r_beta;
+    p.part_out = part_out;
     return launch_gemm(p, hipStream_t(stream));
 }
 
@@ -501,6 +587,7 @@ struct FwdPlan {
     size_t side_kv_floats;     // per sample; only carved in two-stream mode
     size_t score_floats;       // per sample; (h, Rq, R) score scratch of wide heads, else 0
     size_t lse_floats;         // per sample; (h, Rq)
+    size_t stats_floats;       // per sample; 2 x (R, d_model / 64, 2)
 };
 
 static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
@@ -518,7 +605,7 @@ static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
     pl->hdv = h * m->d_v;
     const int Rq = want_attn ? R : L;  // the Q / A buffers only see encoder rows when maps are wanted
     // + 64 floats of slack per region for the carver's 256-byte rounding
-    pl->fixed_floats = 64 * 10;
+    pl->fixed_floats = 64 * 11;
     pl->per_sample_floats = size_t(R) * m->d_inner + size_t(Rq) * pl->hdk + size_t(R) * pl->hdk +
                             size_t(R) * pl->hdv + size_t(Rq) * pl->hdv + size_t(L) * m->d_model;
     // wide heads (d_k or d_v > 128): the scores of the largest attention of the forward go through this scratch
@@ -526,6 +613,9 @@ static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
     pl->per_sample_floats += pl->score_floats;
     pl->lse_floats = size_t(h) * Rq;  // row log-sum-exp of an attention whose maps are requested
     pl->per_sample_floats += pl->lse_floats;
+    // two ping-pong buffers of row partials (sum, sum of squares per 64-column tile) for deferred LayerNorm
+    pl->stats_floats = size_t(2) * R * 2 * ln_parts(m->d_model);
+    pl->per_sample_floats += pl->stats_floats;
     // K/V of decoder layers >= 1, projected ahead on the side stream (lamp_set_forward_streams(2))
     pl->side_kv_floats = size_t(m->n_layers_dec) * T * (pl->hdk + pl->hdv);
     return 0;
@@ -589,7 +679,14 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
     if (mb > B) mb = B;
 
     const int Rq = want_enc_attn ? pl.R : L;
-    float *H = nullptr, *Y = nullptr;
+    float *H = nullptr, *Y = nullptr, *ln_stats = nullptr;
+    // Deferred LayerNorm (lamp_fused_ln): only without auxiliary outputs (intermediate predictions need the
+    // normalised states) and with an output projection in every attention block.
+    bool fused = m->fused_ln && !aux && m->fused_ln->dec && (m->n_layers_enc <= 1 || m->fused_ln->enc);
+    for (int i = 0; i < m->n_layers_dec && fused; ++i) {
+        const lamp_dec_layer& l = m->dec_layers[i];
+        if (l.enc_attn.n_head < 2 || (l.slf_attn.present && l.slf_attn.n_head < 2)) fused = false;
+    }
     float* Kahead[MAX_SIDE_EVENTS] = {};
     float* Vahead[MAX_SIDE_EVENTS] = {};
     MhaScratch sc{};
@@ -602,6 +699,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         sc.A = c.take(size_t(mb) * Rq * pl.hdv);
         sc.S = pl.score_floats ? c.take(size_t(mb) * pl.score_floats) : nullptr;
         sc.lse = c.take(size_t(mb) * pl.lse_floats);
+        ln_stats = c.take(size_t(mb) * pl.stats_floats);
         Y = c.take(size_t(mb) * L * d);
         for (int i = 0; i < n_ahead; ++i) {
             Kahead[i] = c.take(size_t(mb) * T * pl.hdk);
@@ -623,6 +721,10 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         LAMP_CK(launch_embed(seq, pos, Me, m->src_word_emb, m->n_src_vocab, m->position_enc, m->n_position, d, x, s));
         {
             lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq, T, 0, nullptr, 0};
+            bool enc_pend = false;
+            const float *enc_pg = nullptr, *enc_pb = nullptr;
+            float* enc_part[2] = {ln_stats, ln_stats + size_t(mb) * pl.stats_floats / 2};  // ping-pong row partials
+            int enc_cur = 0;
             for (int i = 0; i < m->n_layers_enc; ++i) {
                 const lamp_enc_layer& l = m->enc_layers[i];
                 if (want_enc_attn && aux->enc_self_attn[i]) {
@@ -631,7 +733,18 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
                     LAMP_CK(mha_core(x, false, x, nb, T, T, d, dk, dv, l.slf_attn, &pad_mask, nullptr,
                                      aux->enc_self_attn[i], sc, s, false, nullptr, B, int(b0)));
                 }
-                LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s));  // lamp/Layers.py:18
+                // lamp/Layers.py:18.  With deferred LayerNorm a layer leaves its pre-norm rows in x when the next layer
+                // has folded weights for them; the last layer always normalises (enc_output is an output).
+                const bool last = i + 1 == m->n_layers_enc;
+                const bool defer = fused && !last && folded_ok(&m->fused_ln->enc[i + 1].w1);
+                LnIn in{enc_pg, enc_pb, enc_part[enc_cur]};
+                if (enc_pend) in.w1 = &m->fused_ln->enc[i].w1;
+                LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s, nullptr, 0, nullptr, enc_pend ? &in : nullptr,
+                                 defer ? enc_part[enc_cur ^ 1] : nullptr));
+                if (defer) enc_cur ^= 1;
+                enc_pend = defer;
+                enc_pg = l.pos_ffn.ln_g;
+                enc_pb = l.pos_ffn.ln_b;
             }
         }
 
@@ -665,8 +778,17 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
                 ++n_int;
                 return 0;
             };
+            // deferred LayerNorm: `pend` = Yr holds PRE-norm rows of the sub-layer whose LayerNorm is (pg, pb)
+            bool pend = false;
+            const float *pg = nullptr, *pb = nullptr;
+            // ping-pong row partials of this range's label rows: a sub-layer reads its input's, writes its output's
+            const size_t half = size_t(mb) * pl.stats_floats / 2;
+            float* part[2] = {ln_stats + int64_t(r_lo) * (pl.stats_floats / 2), ln_stats + half + int64_t(r_lo) * (pl.stats_floats / 2)};
+            int cur = 0;
             for (int i = 0; i < m->n_layers_dec; ++i) {
                 const lamp_dec_layer& l = m->dec_layers[i];
+                const lamp_fused_ln_dec_layer* fd = fused ? &m->fused_ln->dec[i] : nullptr;
+                const bool has_slf = l.slf_attn.present != 0;
                 float* Penc = (aux && aux->dec_enc_attn) ? aux->dec_enc_attn[i] : nullptr;
                 float* Pslf = (aux && aux->dec_self_attn) ? aux->dec_self_attn[i] : nullptr;
                 MhaScratch sci = scr;
@@ -675,26 +797,67 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
                     sci.K = Kahead[i] + int64_t(r_lo) * T * pl.hdk;
                     sci.V = Vahead[i] + int64_t(r_lo) * T * pl.hdv;
                 }
-                // input->label messages (lamp/Layers.py:35); layer 0's query is the label table itself
-                if (i == 0)
+                // input->label messages (lamp/Layers.py:35); layer 0's query is the label table itself (its LayerNorm
+                // kernel adds the shared residual, so it is never deferred)
+                if (i == 0) {
                     LAMP_CK(mha_core(m->tgt_word_emb, true, xr, nr, L, T, d, dk, dv, l.enc_attn, &pad_mask, Yr, Penc,
                                      sci, st, ahead, m->dec0_query, B, int(b0) + r_lo));
-                else
+                    pend = false;
+                } else {
+                    LnIn in{pg, pb, part[cur]};
+                    if (pend) in.q = &fd->enc_q;
+                    const bool defer = fused && folded_ok(&fd->ffn1_w1);
                     LAMP_CK(mha_core(Yr, false, xr, nr, L, T, d, dk, dv, l.enc_attn, &pad_mask, Yr, Penc, sci, st, ahead, nullptr, B,
-                                     int(b0) + r_lo));
-                LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn1, Yr, Hr, st));  // lamp/Layers.py:36
-                if (l.slf_attn.present) {
+                                     int(b0) + r_lo, pend ? &in : nullptr, defer ? part[cur ^ 1] : nullptr));
+                    if (defer) cur ^= 1;
+                    pend = defer;
+                    pg = l.enc_attn.ln_g;
+                    pb = l.enc_attn.ln_b;
+                }
+                {  // lamp/Layers.py:36
+                    LnIn in{pg, pb, part[cur]};
+                    if (pend) in.w1 = &fd->ffn1_w1;
+                    const bool next_ok = fused && (has_slf ? (folded_ok(&fd->slf_q) && folded_ok(&fd->slf_k) && folded_ok(&fd->slf_v))
+                                                           : folded_ok(&fd->ffn2_w1));
+                    LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn1, Yr, Hr, st, nullptr, 0, nullptr, pend ? &in : nullptr,
+                                     next_ok ? part[cur ^ 1] : nullptr));
+                    if (next_ok) cur ^= 1;
+                    pend = next_ok;
+                    pg = l.pos_ffn1.ln_g;
+                    pb = l.pos_ffn1.ln_b;
+                }
+                if (has_slf) {
                     LAMP_CK(int_pred());  // dec_output_int, lamp/Decoders.py:149-151
                     // label->label messages over the label graph (lamp/Layers.py:40)
+                    LnIn in{pg, pb, part[cur]};
+                    if (pend) {
+                        in.q = &fd->slf_q;
+                        in.k = &fd->slf_k;
+                        in.v = &fd->slf_v;
+                    }
+                    const bool defer = fused && folded_ok(&fd->ffn2_w1);
                     LAMP_CK(mha_core(Yr, false, Yr, nr, L, L, d, dk, dv, l.slf_attn, &label_mask, Yr, Pslf, scr, st, false, nullptr,
-                                     B, int(b0) + r_lo));
+                                     B, int(b0) + r_lo, pend ? &in : nullptr, defer ? part[cur ^ 1] : nullptr));
+                    if (defer) cur ^= 1;
+                    pend = defer;
+                    pg = l.slf_attn.ln_g;
+                    pb = l.slf_attn.ln_b;
                 }
+                LnIn in2{pg, pb, part[cur]};
+                if (pend) in2.w1 = &fd->ffn2_w1;
                 if (i + 1 < m->n_layers_dec) {
-                    LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn2, Yr, Hr, st));  // lamp/Layers.py:45
-                    LAMP_CK(int_pred());                                         // all but the last (lamp/Models.py:130)
+                    const bool defer = fused && folded_ok(&m->fused_ln->dec[i + 1].enc_q);
+                    LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn2, Yr, Hr, st, nullptr, 0, nullptr, pend ? &in2 : nullptr,
+                                     defer ? part[cur ^ 1] : nullptr));  // lamp/Layers.py:45
+                    LAMP_CK(int_pred());  // all but the last (lamp/Models.py:130)
+                    if (defer) cur ^= 1;
+                    pend = defer;
+                    pg = l.pos_ffn2.ln_g;
+                    pb = l.pos_ffn2.ln_b;
                 } else {
                     // last layer: the read-out (lamp/Models.py:124-126) is fused into this LayerNorm
-                    LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn2, Yr, Hr, st, m->w_out, L, logits + (b0 + r_lo) * L));
+                    LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn2, Yr, Hr, st, m->w_out, L, logits + (b0 + r_lo) * L,
+                                     pend ? &in2 : nullptr, nullptr));
                 }
             }
             return 0;

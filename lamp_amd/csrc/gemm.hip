@@ -47,9 +47,18 @@ struct GemmTile {
     static_assert(BK % 8 == 0, "BK must be a multiple of 8");
 };
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool LN = false>
+// LNM (deferred LayerNorm, production tiles only; 0 = plain GEMM, identical code to before):
+//   bit 0  A holds pre-LayerNorm rows: (mean, rstd) from their partial sums, applied in the epilogue with folded weights
+//   bit 1  R holds pre-LayerNorm rows: the residual is LayerNorm(R), recomputed from R and its rows' statistics
+//   bit 2  the epilogue also writes per row and 16-column group the partial (sum, sum of squares) of the output
+// Nothing is added to the main loop.  Summation orders are fixed and independent of the tile configuration (16-column
+// butterflies, then groups in ascending column order), so a sample's bits still do not
+// depend on the batch it is in.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, int LNM = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
                                                                           int tiles_n) {
+    constexpr bool LN = (LNM & 1) != 0, LNR = (LNM & 2) != 0, PS = (LNM & 4) != 0;
+    static_assert(LNM == 0 || (MF == 16 && BN == 64), "deferred LayerNorm: 16x16x4 tiles with 64 columns");
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
     // lane -> (row within an MFMA block, which group of 4 consecutive k this lane's b128 read covers)
     constexpr int KQ = 64 / MF;             // 2 for 32x32x2, 4 for 16x16x4
@@ -61,6 +70,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;               // [2][BM][S]
     float* Bs = smem + 2 * BM * S;  // [2][BN][S]
+    float* ln_lds = smem + 2 * (BM + BN) * S;  // deferred LayerNorm: [BM][4] = (A mean, A rstd, R mean, R rstd)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -110,12 +120,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         vob[i] = unsigned(row * ldw + c4 * 4) * 4u;
     }
 
-    // LN: running sum / sum of squares of this thread's A rows (a thread's float4s stay in the same rows for every k-tile)
-    float ssum[LN ? T::A_LD : 1], ssq[LN ? T::A_LD : 1];
-    if constexpr (LN) {
-#pragma unroll
-        for (int i = 0; i < T::A_LD; ++i) ssum[i] = ssq[i] = 0.f;
-    }
     auto gload = [&](int k0, float4 (&ra)[T::A_LD], float4 (&rb)[T::B_LD]) {
         if constexpr (KTAIL) {
             // K is not a multiple of BK: columns past K must read as 0 (the row range check cannot see them)
@@ -145,26 +149,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
             const int idx = tid + i * T::NT;
             const int row = idx / C4, c4 = idx - row * C4;
             *reinterpret_cast<float4*>(a + row * S + c4 * 4) = ra[i];
-            if constexpr (LN) {
-                // Every A tile passes through here exactly once.  Row statistics in a summation order that does not
-                // depend on the tile configuration (samples must come out bit-identical for any batch size): the 16
-                // values of each 16-wide k-block are combined by a 4-lane butterfly, blocks are added in ascending k.
-                float f = (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
-                // explicit fma: the compiler must not contract these differently in different instantiations
-                float q = fmaf(ra[i].x, ra[i].x, ra[i].y * ra[i].y) + fmaf(ra[i].z, ra[i].z, ra[i].w * ra[i].w);
-                f += __shfl_xor(f, 1, 64); q += __shfl_xor(q, 1, 64);
-                f += __shfl_xor(f, 2, 64); q += __shfl_xor(q, 2, 64);
-                if constexpr (C4 == 8) {  // BK = 32: lanes 0-3 of the row hold the even 16-block, lanes 4-7 the odd one
-                    const float fo = __shfl_xor(f, 4, 64), qo = __shfl_xor(q, 4, 64);
-                    const bool low = (c4 & 4) == 0;
-                    ssum[i] = (ssum[i] + (low ? f : fo)) + (low ? fo : f);
-                    ssq[i] = (ssq[i] + (low ? q : qo)) + (low ? qo : q);
-                } else {
-                    static_assert(C4 == 4 || C4 == 8, "deferred LayerNorm supports BK = 16 or 32");
-                    ssum[i] += f;
-                    ssq[i] += q;
-                }
-            }
         }
 #pragma unroll
         for (int i = 0; i < T::B_LD; ++i) {
@@ -207,6 +191,36 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     lstore(0, ra0, rb0);
     if (nk > 1) gload(BK, ra0, rb0);      // tile 1 -> set 0
     if (nk > 2) gload(2 * BK, ra1, rb1);  // tile 2 -> set 1
+    if constexpr (LN || LNR) {
+        // Row statistics from the producer's partial sums (issued after the first tile loads so that their latency
+        // overlaps): 16 lanes per row; lane l adds partials l, l + 16, ... in ascending order, then a DPP row sum --
+        // an order that depends on neither this kernel's nor the producer's tile configuration.  Visible to the epilogue
+        // through the main loop's barriers.
+        const int sub = tid & 15;
+        for (int row = tid >> 4; row < (LN && LNR ? 2 : 1) * BM; row += T::NT / 16) {
+            const bool for_r = LNR && (!LN || row >= BM);
+            const int lr = row >= BM ? row - BM : row;
+            const float* part = for_r ? p.r_part : p.a_part;
+            const int np = for_r ? p.r_nparts : p.a_nparts;
+            const float inv_n = 1.0f / float(for_r ? p.N : p.K);
+            float a = 0.f, b = 0.f;
+            if (lr < rows_m) {
+                const float* q = part + (m0 + lr) * int64_t(np) * 2;
+                for (int t2 = sub; t2 < np; t2 += 16) {
+                    a += q[2 * t2];
+                    b += q[2 * t2 + 1];
+                }
+            }
+            a = row16_sum(a);
+            b = row16_sum(b);
+            if (sub == 0) {
+                const float mean = a * inv_n;
+                const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, b * inv_n), 0.f) + p.ln_eps);
+                ln_lds[4 * lr + (for_r ? 2 : 0)] = mean;
+                ln_lds[4 * lr + (for_r ? 3 : 1)] = rstd;
+            }
+        }
+    }
     __syncthreads();
 
     for (int kt = 0; kt < nk; kt += 2) {
@@ -223,31 +237,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         __syncthreads();
     }
 
-    // LN: finish the row statistics: (mean, rstd) go to LDS -- the tile buffers are free after the last barrier -- and, from the
-    // workgroups of the first column tile, to stats_out.
-    float* row_stats = smem;  // [BM][2]
-    if constexpr (LN) {
-#pragma unroll
-        for (int i = 0; i < T::A_LD; ++i) {
-            const float a = ssum[i], b = ssq[i];  // already complete (and equal) in every lane of the row
-            const int idx = tid + i * T::NT;
-            const int row = idx / C4;
-            if ((idx - row * C4) == 0) {
-                const float inv_k = 1.0f / float(p.K);
-                const float mean = a * inv_k;
-                const float var = fmaf(-mean, mean, b * inv_k);
-                const float rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + p.ln_eps);
-                row_stats[2 * row] = mean;
-                row_stats[2 * row + 1] = rstd;
-                if (p.stats_out && tn_all == 0 && row < rows_m) {
-                    p.stats_out[2 * (m0 + row)] = mean;
-                    p.stats_out[2 * (m0 + row) + 1] = rstd;
-                }
-            }
-        }
-        __syncthreads();
-    }
-
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     // Stores to rows past M fall outside the descriptor and are dropped by the hardware; columns past
     // N are steered to an out-of-range offset.
@@ -261,9 +250,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias ? bias + n0 : p.A, bias ? uint64_t(rows_n) * 4u : 0);
     const float* lns = LN ? p.ln_s[seg] : nullptr;
     const __amdgpu_buffer_rsrc_t rsS = make_rsrc(lns ? lns + n0 : p.A, lns ? uint64_t(rows_n) * 4u : 0);
-    const bool r_ln = LN && has_r && p.r_stats != nullptr;
-    const __amdgpu_buffer_rsrc_t rsRS =
-        make_rsrc(r_ln ? p.r_stats + 2 * m0 : p.A, r_ln ? uint64_t(rows_m) * 8u : 0);
+    const bool r_ln = LNR && has_r;
     const __amdgpu_buffer_rsrc_t rsRG = make_rsrc(r_ln ? p.r_gamma + n0 : p.A, r_ln ? uint64_t(rows_n) * 4u : 0);
     const __amdgpu_buffer_rsrc_t rsRB = make_rsrc(r_ln ? p.r_beta + n0 : p.A, r_ln ? uint64_t(rows_n) * 4u : 0);
     // C/D layouts: 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16;
@@ -277,12 +264,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         const bool col_ok = lcol < rows_n;
         const float bv = bload1(rsBias, col_ok ? unsigned(lcol) * 4u : OOB);
         float sv = 0.f, rg = 1.f, rb = 0.f;
-        if constexpr (LN) {
-            sv = bload1(rsS, col_ok ? unsigned(lcol) * 4u : OOB);
-            if (r_ln) {
-                rg = bload1(rsRG, col_ok ? unsigned(lcol) * 4u : OOB);
-                rb = bload1(rsRB, col_ok ? unsigned(lcol) * 4u : OOB);
-            }
+        if constexpr (LN) sv = bload1(rsS, col_ok ? unsigned(lcol) * 4u : OOB);
+        if constexpr (LNR) {
+            rg = bload1(rsRG, (r_ln && col_ok) ? unsigned(lcol) * 4u : OOB);
+            rb = bload1(rsRB, (r_ln && col_ok) ? unsigned(lcol) * 4u : OOB);
         }
 #pragma unroll
         for (int i = 0; i < T::MI; ++i) {
@@ -292,12 +277,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
                 for (int r = 0; r < NACC; ++r) {
                     const int lrow = lrow0 + i * MF + blk_row(r);
                     res[r] = bload1(rsR, col_ok ? unsigned(lrow * ldr + lcol) * 4u : OOB);
-                    if constexpr (LN) {
-                        if (r_ln) {  // the residual is LayerNorm(z_prev), recomputed from z_prev and its row statistics
-                            const f32x2 st = bload2(rsRS, unsigned(lrow) * 8u);
-                            res[r] = fmaf((res[r] - st.x) * st.y, rg, rb);
-                        }
-                    }
+                    if constexpr (LNR)  // LayerNorm(z_prev) recomputed from z_prev and its row statistics (explicit fma)
+                        res[r] = fmaf((res[r] - ln_lds[4 * lrow + 2]) * ln_lds[4 * lrow + 3], rg, rb);
                 }
             }
 #pragma unroll
@@ -305,8 +286,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
                 const int lrow = lrow0 + i * MF + blk_row(r);
                 float v = acc[i][j][r];
                 if constexpr (LN) {
-                    if (lns)  // rstd * (acc - mean * s) + bias', as explicit fmas
-                        v = fmaf(row_stats[2 * lrow + 1], fmaf(-row_stats[2 * lrow], sv, v), bv);
+                    if (lns)  // rstd * (acc - mean * s) + bias'
+                        v = fmaf(ln_lds[4 * lrow + 1], fmaf(-ln_lds[4 * lrow], sv, v), bv);
                     else
                         v += bv;
                 } else {
@@ -315,21 +296,35 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (has_r) v += res[r];
                 bstore1(rsC, col_ok ? unsigned(lrow * ldc + lcol) * 4u : OOB, v);
+                if constexpr (PS) {
+                    // 16-lane butterfly = the 16 columns of one group of this row; lane 0 of the group stores the
+                    // partial (sum, sum of squares) [row][group][2].  Columns past N contribute exact zeros.
+                    float a = col_ok ? v : 0.f, q = a * a;
+                    a = row16_sum(a);
+                    q = row16_sum(q);
+                    if (l31 == 0 && lrow < rows_m) {
+                        const int g = tn * 4 + ((wn * T::WTN + j * MF) >> 4);
+                        float* out = p.part_out + ((m0 + lrow) * int64_t(tiles_n_seg) * 4 + g) * 2;
+                        out[0] = a;
+                        out[1] = q;
+                    }
+                }
             }
         }
     }
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool LN = false>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, int LNM = 0>
 static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
-    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, LN>;
+    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, LNM>;
+    constexpr size_t LDS = T::LDS_BYTES + (LNM ? size_t(BM) * 4 * sizeof(float) : 0);
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(T::LDS_BYTES));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS));
         if (e != hipSuccess) return int(e);
         attr_done[dev] = true;
     }
@@ -342,7 +337,7 @@ static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     const int tiles_n = tiles_n_seg * p.nseg;
     const int64_t nwg = tiles_m * tiles_n;
     if (nwg > 0x7fffffffLL) return LAMP_E_DIMS;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(T::NT), T::LDS_BYTES, s, p, tiles_n_seg, tiles_n);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(T::NT), LDS, s, p, tiles_n_seg, tiles_n);
     return int(hipGetLastError());
 }
 
@@ -351,11 +346,17 @@ static int launch_cfg(const GemmParams& p, hipStream_t s) {
     if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF>(p, s);
     return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF>(p, s);
 }
-// production tiles only: the deferred-LayerNorm variant (K a multiple of BK is required by the callers' d_model)
+// production tiles only: the deferred-LayerNorm variants (the callers' d_model is a multiple of BK: no K tail)
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
-static int launch_cfg_ln(const GemmParams& p, hipStream_t s) {
-    if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, 16, true>(p, s);
-    return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, 16, true>(p, s);
+static int launch_cfg_ln(const GemmParams& p, int lnm, hipStream_t s) {
+    if (p.K % BK) return LAMP_E_UNSUPPORTED;
+    switch (lnm) {
+        case 1: return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, 16, 1>(p, s);
+        case 2: return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, 16, 2>(p, s);
+        case 4: return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, 16, 4>(p, s);
+        case 6: return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, 16, 6>(p, s);
+        default: return LAMP_E_UNSUPPORTED;  // A pre-norm never coincides with a residual or partials on this path
+    }
 }
 
 // Debug/tuning hook (not part of the ABI header): force a tile configuration.  0 = heuristic.
@@ -408,14 +409,16 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     // also ahead of the best 32x32x2 tile (128x128x32: 128-139).  The 32x32x2 tiles remain as forced configs 1-8.
     auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nseg; };
     const int64_t t64 = tiles(64, 64);
-    bool ln = p.r_stats != nullptr || p.stats_out != nullptr;
-    for (int i = 0; i < p.nseg; ++i) ln = ln || p.ln_s[i] != nullptr;
-    if (ln) {  // same menu, deferred-LayerNorm instantiations
-        if (p.r_stats && (!p.R || !p.r_gamma || !p.r_beta)) return LAMP_E_NULL;
-        if (tiles(128, 64) >= 2048 && p.K >= 512) return launch_cfg_ln<128, 64, 16, 2, 2>(p, s);
-        if (t64 >= 2048) return launch_cfg_ln<64, 64, 32, 2, 2>(p, s);
-        if (t64 >= 1200) return launch_cfg_ln<64, 64, 16, 2, 2>(p, s);
-        return launch_cfg_ln<32, 64, 32, 1, 4>(p, s);
+    int lnm = (p.r_part ? 2 : 0) | (p.part_out ? 4 : 0);
+    for (int i = 0; i < p.nseg; ++i) lnm |= p.ln_s[i] ? 1 : 0;
+    if (lnm) {  // same menu, deferred-LayerNorm instantiations
+        if ((lnm & 1) && (!p.a_part || p.a_nparts < 1)) return LAMP_E_NULL;
+        if ((lnm & 2) && (!p.R || !p.r_gamma || !p.r_beta || p.r_nparts < 1)) return LAMP_E_NULL;
+        if ((lnm & 4) && p.nseg != 1) return LAMP_E_UNSUPPORTED;
+        if (tiles(128, 64) >= 2048 && p.K >= 512) return launch_cfg_ln<128, 64, 16, 2, 2>(p, lnm, s);
+        if (t64 >= 2048) return launch_cfg_ln<64, 64, 32, 2, 2>(p, lnm, s);
+        if (t64 >= 1200) return launch_cfg_ln<64, 64, 16, 2, 2>(p, lnm, s);
+        return launch_cfg_ln<32, 64, 32, 1, 4>(p, lnm, s);
     }
     if (tiles(128, 64) >= 2048 && p.K >= 512) return launch_cfg<128, 64, 16, 2, 2, 16>(p, s);  // short K: fewer, deeper steps
     if (t64 >= 2048) return launch_cfg<64, 64, 32, 2, 2, 16>(p, s);

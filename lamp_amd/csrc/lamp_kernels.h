@@ -29,18 +29,22 @@ struct GemmParams {
     const float* R;  // residual, same for every segment (only meaningful with nseg == 1)
     int64_t ldr;
     int relu;
-    // ---- deferred LayerNorm (LN = true instantiations; see gemm.hip) ----
-    // A holds PRE-LayerNorm rows z; the weights passed in W are folded, W'[n,k] = W[n,k] * gamma[k], and
-    // bias' = W.beta + bias, ln_s[n] = sum_k W'[n,k].  The kernel accumulates each row's mean / rstd while it streams
-    // A and applies   C = rstd * (A.W'^T - mean * ln_s) + bias'   in the epilogue -- LayerNorm(z).W^T + bias without a
-    // LayerNorm launch and without ever storing LayerNorm(z).
-    const float* ln_s[GEMM_MAX_SEG];  // all null = plain GEMM
+    // ---- deferred LayerNorm (see gemm.hip) ----
+    // Producer (part_out): beside C, the epilogue writes per row and 16-column group the partial (sum, sum of squares)
+    // of the output values, [M][4 * ceil(N / 64)][2] -- the row statistics a later LayerNorm of C needs.
+    // Consumer, A pre-norm (ln_s): A holds PRE-LayerNorm rows z with partials a_part; the weights in W are folded,
+    // W'[n,k] = W[n,k] * gamma[k], bias' = W.beta + bias, ln_s[n] = sum_k W'[n,k]; the epilogue applies
+    //   C = rstd * (A.W'^T - mean * ln_s) + bias'  =  LayerNorm(z).W^T + bias   without LayerNorm(z) ever being stored.
+    // Consumer, R pre-norm (r_part): residual = (R - mean) * rstd * r_gamma + r_beta.
+    const float* ln_s[GEMM_MAX_SEG];  // all null = A is used as it is
     float ln_eps;
-    float* stats_out;                 // nullable [M][2] (mean, rstd) of A's rows, for the consumer of the residual below
-    // R holds PRE-LayerNorm rows too: residual = (R - mean) * rstd * r_gamma + r_beta with r_stats [M][2]
-    const float* r_stats;             // null = R is used as it is
+    const float* a_part;  // [M][a_nparts][2]
+    int a_nparts;
+    const float* r_part;  // [M][r_nparts][2]; null = R is used as it is
+    int r_nparts;
     const float* r_gamma;
     const float* r_beta;
+    float* part_out;      // nullable; nseg must be 1
 };
 
 struct AttnParams {
@@ -160,6 +164,21 @@ __device__ __forceinline__ unsigned bload_u8(__amdgpu_buffer_rsrc_t r, unsigned 
 }
 __device__ __forceinline__ unsigned long long bload_u64(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     return __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+}
+
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), result in every lane, as four pure-DPP steps (quad
+// swaps, then half-row and row mirrors between groups that already hold equal values).  __shfl_xor compiles to
+// ds_bpermute (LDS crossbar, ~100 cycles each); these are VALU-speed.  Same pairing as an xor butterfly.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);  // row_half_mirror
+    v += dpp_move<0x140>(v);  // row_mirror
+    return v;
 }
 
 // Workgroup id -> work-item id such that each XCD (workgroup b runs on XCD b % 8) gets a CONTIGUOUS range

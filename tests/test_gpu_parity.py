@@ -673,34 +673,79 @@ def test_model_with_wide_heads_vs_oracle(dev):
 
 
 # ------------------------------------------------------------------ deferred LayerNorm (LN folded into the consuming GEMM)
-@pytest.mark.parametrize('M,K,N_', [(2880, 512, 512), (9664, 512, 512), (2880, 512, 1536), (31456, 1024, 2048), (77, 64, 96), (5, 36, 7)])
+@pytest.mark.parametrize('M,K,N_', [(2880, 512, 512), (9664, 512, 512), (2880, 512, 1536), (31456, 1024, 2048), (77, 64, 96), (5, 96, 7)])
 def test_linear_with_deferred_layernorm_vs_torch(dev, M, K, N_):
-    """act(LayerNorm(z) W^T + b) + LayerNorm_r(z_prev) without either LayerNorm being materialised, on every production
-    tile (the shapes pick all four), ragged edges, and row statistics written for the next consumer."""
+    """act(LayerNorm(z) W^T + b) + LayerNorm_r(z_prev) without either LayerNorm being materialised: z and z_prev come out
+    of producer GEMMs whose epilogues also write the rows' partial sums; the consumer derives (mean, rstd) from them.
+    Every production tile (the shapes pick all four), ragged edges, partial tiles of 64 columns."""
     from lamp_amd import _native as N
     g = torch.Generator().manual_seed(M + K)
-    z = torch.randn(M, K, generator=g) * 1.7 + 0.3
+    x0 = torch.randn(M, 64, generator=g)
+    w0, b0 = torch.randn(K, 64, generator=g) * 0.2, torch.randn(K, generator=g) * 0.5 + 0.3
+    w1, b1 = torch.randn(N_, 64, generator=g) * 0.2, torch.randn(N_, generator=g) * 0.5 - 0.2
+    z, zpart = N.linear_ln(x0.to(dev), w0.to(dev), bias=b0.to(dev), want_part=True)          # producer of z   (M, K)
+    zprev, zprev_part = N.linear_ln(x0.to(dev), w1.to(dev), bias=b1.to(dev), want_part=True)  # producer of z_prev (M, N)
+    zd, zpd = z.double().cpu(), zprev.double().cpu()
+    assert max_abs_diff(z, x0.double() @ w0.double().t() + b0.double()) < 2e-5
+    assert max_abs_diff(zpart.sum(1)[:, 0], zd.sum(1)) < 1e-3 and max_abs_diff(zpart.sum(1)[:, 1], (zd * zd).sum(1)) < 2e-3
     w = torch.randn(N_, K, generator=g) / K ** 0.5
     b = torch.randn(N_, generator=g)
     gam, bet = 1 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
-    zprev = torch.randn(M, N_, generator=g) * 0.8 - 0.2
     rg, rb = 1 + 0.2 * torch.randn(N_, generator=g), 0.1 * torch.randn(N_, generator=g)
-    y = torch.nn.functional.layer_norm(z.double(), (K,), gam.double(), bet.double(), 1e-5)
-    res = torch.nn.functional.layer_norm(zprev.double(), (N_,), rg.double(), rb.double(), 1e-5)
+    y = torch.nn.functional.layer_norm(zd, (K,), gam.double(), bet.double(), 1e-5)
+    res = torch.nn.functional.layer_norm(zpd, (N_,), rg.double(), rb.double(), 1e-5)
     ref = (y @ w.double().t() + b.double()).clamp_min(0) + res
-    folded = N.layernorm_fold(w.to(dev), gam.to(dev), bet.to(dev), b.to(dev))
-    mean_p = zprev.double().mean(1)
-    rstd_p = 1.0 / torch.sqrt(zprev.double().var(1, unbiased=False) + 1e-5)
-    r_stats = torch.stack((mean_p, rstd_p), 1).float().to(dev)
-    out, stats = N.linear_ln(z.to(dev), folded, residual=zprev.to(dev), r_stats=r_stats, r_gamma=rg.to(dev), r_beta=rb.to(dev),
-                             relu=True, want_stats=True)
-    assert max_abs_diff(out, ref) < 5e-5
-    assert max_abs_diff(stats[:, 0], z.double().mean(1)) < 1e-5
-    assert max_abs_diff(stats[:, 1], 1.0 / torch.sqrt(z.double().var(1, unbiased=False) + 1e-5)) < 2e-5
-    # plain residual, no activation
-    out2 = N.linear_ln(z.to(dev), folded, residual=zprev.to(dev))
-    assert max_abs_diff(out2, y @ w.double().t() + b.double() + zprev.double()) < 5e-5
-    # deterministic and independent of the rows around it (batch invariance)
-    out3 = N.linear_ln(z[: max(1, M // 3)].to(dev), folded)
-    full = N.linear_ln(z.to(dev), folded)
-    assert torch.equal(out3, full[: max(1, M // 3)])
+    wf, s, bf = N.layernorm_fold(w.to(dev), gam.to(dev), bet.to(dev), b.to(dev))
+    out = N.linear_ln(z, wf, s=s, bias=bf, a_part=zpart, relu=True)                 # consumer with A pre-norm
+    assert max_abs_diff(out, (y @ w.double().t() + b.double()).clamp_min(0)) < 5e-5
+    out2, part2 = N.linear_ln(y.float().to(dev), w.to(dev), bias=b.to(dev), residual=zprev, r_part=zprev_part,
+                              r_gamma=rg.to(dev), r_beta=rb.to(dev), want_part=True)  # consumer with R pre-norm + producer
+    ref2 = y.float().double() @ w.double().t() + b.double() + res
+    assert max_abs_diff(out2, ref2) < 5e-5
+    assert max_abs_diff(part2.sum(1)[:, 0], out2.double().sum(1)) < 2e-3
+    # deterministic and independent of the rows around it (batch invariance across tile configurations)
+    m3 = max(1, M // 3)
+    z3, zp3 = N.linear_ln(x0[:m3].to(dev), w0.to(dev), bias=b0.to(dev), want_part=True)
+    assert torch.equal(z3, z[:m3]) and torch.equal(zp3, zpart[:m3])
+    out3 = N.linear_ln(z3, wf, s=s, bias=bf, a_part=zp3, relu=True)
+    assert torch.equal(out3, out[:m3])
+
+
+@pytest.mark.parametrize('name', sorted(CONFIGS))
+def test_deferred_layernorm_forward_vs_oracle(dev, name):
+    """LAMP.fuse_layernorm: 7 of 10 LayerNorm launches elided (folded into the consuming GEMMs); logits and enc_output
+    against the oracle at BASELINE sizes, agreement with the plain path to rounding, sample independence."""
+    m, sd, blocked, seq, spos, h = make_case(CONFIGS[name], dev)
+    src = (seq.to(dev), spos.to(dev))
+    with torch.no_grad():
+        ref_logits, ref_enc, _ = R.forward(sd, seq, spos, h, blocked)
+        plain, enc_plain, _ = m(src, None, None, None)
+        m.fuse_layernorm = True
+        logits, enc, _ = m(src, None, None, None)
+        assert max_abs_diff(enc, ref_enc) < TOL_ACT
+        assert max_abs_diff(logits, ref_logits) < TOL_LOGIT
+        assert max_abs_diff(logits, plain) < 2e-5
+        # a sample's bits do not depend on the batch it is in, nor on the micro-batch split
+        one, _, _ = m((src[0][:1], src[1][:1]), None, None, None)
+        assert torch.equal(one, logits[:1])
+        m.workspace_limit_bytes = 1
+        split, _, _ = m(src, None, None, None)
+        assert torch.equal(split, logits)
+        # auxiliary outputs fall back to the plain path
+        ip = m(src, None, None, None, int_preds=True)
+        assert torch.equal(ip[0], plain)
+
+
+def test_deferred_layernorm_tracks_weight_updates(dev):
+    m, sd, blocked, seq, spos, h = make_case(CONFIGS['inveye_8h'], dev)
+    m.fuse_layernorm = True
+    src = (seq.to(dev), spos.to(dev))
+    with torch.no_grad():
+        a, _, _ = m(src, None, None, None)
+        m.decoder.layer_stack[0].pos_ffn1.layer_norm.weight.mul_(1.5)     # folded into slf_attn's projections
+        m.decoder.layer_stack[1].pos_ffn1.w_1.weight.add_(0.01)
+        b, _, _ = m(src, None, None, None)
+        m.fuse_layernorm = False
+        c, _, _ = m(src, None, None, None)
+    assert not torch.equal(a, b)
+    assert max_abs_diff(b, c) < 2e-5

@@ -41,7 +41,8 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(N.FfnWeights) == 48
     assert ctypes.sizeof(N.EncLayer) == 104
     assert ctypes.sizeof(N.DecLayer) == 208
-    assert ctypes.sizeof(N.Model) == 120
+    assert ctypes.sizeof(N.Model) == 128
+    assert ctypes.sizeof(N.FusedLnDecLayer) == 144 and ctypes.sizeof(N.FusedLnEncLayer) == 24
     assert ctypes.sizeof(N.Aux) == 40
     assert ctypes.sizeof(N.GemmDesc) == 160
 
