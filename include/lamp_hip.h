@@ -212,7 +212,8 @@ int lamp_linear_fwd(const float* A, int64_t M, int32_t K, int64_t lda,
  *        r_part != NULL: `residual` holds PRE-norm rows with partials r_part [M][4*ceil(N/64)][2]; residual' =
  *          LayerNorm(residual; r_gamma, r_beta) recomputed on the fly (lamp/SubLayers.py:115,140 without storing y).
  *        Nothing is added to the GEMM's main loop; summation orders are fixed, independent of the tile configuration.
- * K, lda, ldw multiples of 4; a pre-norm operand needs K a multiple of the tile depth (32). */
+ * K, lda, ldw multiples of 4; a pre-norm operand needs K a multiple of the tile depth (32) and a LayerNorm width of
+ * at most 1024. */
 int lamp_layernorm_fold(const float* W, int32_t N, int32_t K, const float* gamma, const float* beta, const float* bias,
                         float* W_folded, float* s, float* bias_folded, lamp_stream_t stream);
 int lamp_linear_ln_fwd(const float* a, int64_t M, int32_t K, int64_t lda, const float* a_part, const float* W, int32_t N,

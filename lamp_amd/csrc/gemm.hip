@@ -191,33 +191,30 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     lstore(0, ra0, rb0);
     if (nk > 1) gload(BK, ra0, rb0);      // tile 1 -> set 0
     if (nk > 2) gload(2 * BK, ra1, rb1);  // tile 2 -> set 1
+    // Deferred LayerNorm, consumer side: the rows' 16-column partial sums are LOADED here, together with the first tiles
+    // (16 lanes per row; lane l takes partials l, l + 16, ...), and reduced only after the main loop, so their latency
+    // hides under the MFMAs.
+    constexpr int LN_ROWS = (LN && LNR ? 2 : 1) * BM;   // A rows, then R rows
+    constexpr int LN_IT = (LN || LNR) ? (LN_ROWS * 16 + T::NT - 1) / T::NT : 1;
+    constexpr int LN_NP = 4;                             // partials per lane: up to 64 groups = d <= 1024
+    float lpa[LN_IT][LN_NP], lpb[LN_IT][LN_NP];
     if constexpr (LN || LNR) {
-        // Row statistics from the producer's partial sums (issued after the first tile loads so that their latency
-        // overlaps): 16 lanes per row; lane l adds partials l, l + 16, ... in ascending order, then a DPP row sum --
-        // an order that depends on neither this kernel's nor the producer's tile configuration.  Visible to the epilogue
-        // through the main loop's barriers.
         const int sub = tid & 15;
-        for (int row = tid >> 4; row < (LN && LNR ? 2 : 1) * BM; row += T::NT / 16) {
+#pragma unroll
+        for (int it = 0; it < LN_IT; ++it) {
+            const int row = (tid >> 4) + it * (T::NT / 16);
             const bool for_r = LNR && (!LN || row >= BM);
             const int lr = row >= BM ? row - BM : row;
             const float* part = for_r ? p.r_part : p.a_part;
             const int np = for_r ? p.r_nparts : p.a_nparts;
-            const float inv_n = 1.0f / float(for_r ? p.N : p.K);
-            float a = 0.f, b = 0.f;
-            if (lr < rows_m) {
-                const float* q = part + (m0 + lr) * int64_t(np) * 2;
-                for (int t2 = sub; t2 < np; t2 += 16) {
-                    a += q[2 * t2];
-                    b += q[2 * t2 + 1];
-                }
-            }
-            a = row16_sum(a);
-            b = row16_sum(b);
-            if (sub == 0) {
-                const float mean = a * inv_n;
-                const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, b * inv_n), 0.f) + p.ln_eps);
-                ln_lds[4 * lr + (for_r ? 2 : 0)] = mean;
-                ln_lds[4 * lr + (for_r ? 3 : 1)] = rstd;
+            const bool row_ok = row < LN_ROWS && lr < rows_m;
+            const float* q = part + (m0 + (row_ok ? lr : 0)) * int64_t(np) * 2;
+#pragma unroll
+            for (int u = 0; u < LN_NP; ++u) {
+                const int t2 = sub + 16 * u;
+                const bool ok = row_ok && t2 < np;
+                lpa[it][u] = ok ? q[2 * t2] : 0.f;
+                lpb[it][u] = ok ? q[2 * t2 + 1] : 0.f;
             }
         }
     }
@@ -234,6 +231,30 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         compute(1);
         if (kt + 2 < nk) lstore(0, ra1, rb1);
         if (kt + 4 < nk) gload((kt + 4) * BK, ra1, rb1);
+        __syncthreads();
+    }
+
+    if constexpr (LN || LNR) {
+        // reduce the partials loaded before the main loop: ascending within a lane, then a DPP row sum (an order that
+        // depends on neither this kernel's nor the producer's tile configuration); (mean, rstd) -> LDS for the epilogue
+        const int sub = tid & 15;
+#pragma unroll
+        for (int it = 0; it < LN_IT; ++it) {
+            const int row = (tid >> 4) + it * (T::NT / 16);
+            const bool for_r = LNR && (!LN || row >= BM);
+            const int lr = row >= BM ? row - BM : row;
+            float a = ((lpa[it][0] + lpa[it][1]) + lpa[it][2]) + lpa[it][3];
+            float b = ((lpb[it][0] + lpb[it][1]) + lpb[it][2]) + lpb[it][3];
+            a = row16_sum(a);
+            b = row16_sum(b);
+            if (sub == 0 && row < LN_ROWS) {
+                const float inv_n = 1.0f / float(for_r ? p.N : p.K);
+                const float mean = a * inv_n;
+                const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, b * inv_n), 0.f) + p.ln_eps);
+                ln_lds[4 * lr + (for_r ? 2 : 0)] = mean;
+                ln_lds[4 * lr + (for_r ? 3 : 1)] = rstd;
+            }
+        }
         __syncthreads();
     }
 
@@ -414,6 +435,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     if (lnm) {  // same menu, deferred-LayerNorm instantiations
         if ((lnm & 1) && (!p.a_part || p.a_nparts < 1)) return LAMP_E_NULL;
         if ((lnm & 2) && (!p.R || !p.r_gamma || !p.r_beta || p.r_nparts < 1)) return LAMP_E_NULL;
+        if (((lnm & 1) && p.a_nparts > 64) || ((lnm & 2) && p.r_nparts > 64)) return LAMP_E_UNSUPPORTED;  // d <= 1024
         if ((lnm & 4) && p.nseg != 1) return LAMP_E_UNSUPPORTED;
         if (tiles(128, 64) >= 2048 && p.K >= 512) return launch_cfg_ln<128, 64, 16, 2, 2>(p, lnm, s);
         if (t64 >= 2048) return launch_cfg_ln<64, 64, 32, 2, 2>(p, lnm, s);

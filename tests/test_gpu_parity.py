@@ -698,11 +698,12 @@ def test_linear_with_deferred_layernorm_vs_torch(dev, M, K, N_):
     wf, s, bf = N.layernorm_fold(w.to(dev), gam.to(dev), bet.to(dev), b.to(dev))
     out = N.linear_ln(z, wf, s=s, bias=bf, a_part=zpart, relu=True)                 # consumer with A pre-norm
     assert max_abs_diff(out, (y @ w.double().t() + b.double()).clamp_min(0)) < 5e-5
-    out2, part2 = N.linear_ln(y.float().to(dev), w.to(dev), bias=b.to(dev), residual=zprev, r_part=zprev_part,
-                              r_gamma=rg.to(dev), r_beta=rb.to(dev), want_part=True)  # consumer with R pre-norm + producer
-    ref2 = y.float().double() @ w.double().t() + b.double() + res
-    assert max_abs_diff(out2, ref2) < 5e-5
-    assert max_abs_diff(part2.sum(1)[:, 0], out2.double().sum(1)) < 2e-3
+    if N_ <= 1024:   # a pre-norm operand's LayerNorm width is limited to 1024 (64 partials per row)
+        out2, part2 = N.linear_ln(y.float().to(dev), w.to(dev), bias=b.to(dev), residual=zprev, r_part=zprev_part,
+                                  r_gamma=rg.to(dev), r_beta=rb.to(dev), want_part=True)  # R pre-norm + producer
+        ref2 = y.float().double() @ w.double().t() + b.double() + res
+        assert max_abs_diff(out2, ref2) < 5e-5
+        assert max_abs_diff(part2.sum(1)[:, 0], out2.double().sum(1)) < 2e-3
     # deterministic and independent of the rows around it (batch invariance across tile configurations)
     m3 = max(1, M // 3)
     z3, zp3 = N.linear_ln(x0[:m3].to(dev), w0.to(dev), bias=b0.to(dev), want_part=True)
