@@ -457,13 +457,13 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
         return LAMP_E_UNSUPPORTED;  // 32-bit offsets inside one (sample, head) slice
     // Key split: must NOT depend on the batch size (a split sums in a different order than the
     // sequential online softmax, and samples must come out bit-identical for every batch / shard), so it
-    // is chosen from the per-sample shape only.  At most 128 queries and >= 4 key tiles -> 2-way split
-    // (36-40 us vs 56-61 us unsplit at reuters batch 32); otherwise none.
+    // is chosen from the per-sample shape only.  At most 128 queries and >= 3 key tiles -> 2-way split
+    // (enc-dec attention of reuters: 34 vs 53 us unsplit; its 90 x 90 label self-attention: 18 vs 21 us); otherwise none.
     const int nt = (p.lk + 31) / 32;
     if (p.tiles && (p.m_sb != 0 || (p.mask_kind != LAMP_MASK_U8 && p.mask_kind != LAMP_MASK_BITS_U32)))
         return LAMP_E_UNSUPPORTED;  // the sparsity hint belongs to shared masks
     int ksplit = g_force_attn;
-    if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = (p.lq <= 128 && nt >= 4) ? 2 : 1;
+    if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = (p.lq <= 128 && nt >= 3) ? 2 : 1;
     if (ksplit == 4 && p.lse) ksplit = 2;
     int rc;
     if (dmax <= 32)
