@@ -15,11 +15,7 @@ __device__ __forceinline__ float wmax(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
-__device__ __forceinline__ float wsum2(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float wsum2(float v) { return wave64_sum(v); }
 
 struct SoftmaxParams {
     float* P;        // [(H * P_batch), lq, lk]; rows of sample (P_b0 + b), head h at (h * P_batch + P_b0 + b) * lq

@@ -9,11 +9,7 @@ namespace lamp {
 
 namespace {
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float wsum(float v) { return wave64_sum(v); }
 
 constexpr int LNB_MAX_WG = 256;
 

@@ -181,6 +181,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Sum over the 64 lanes of a wave, result in every lane: DPP row sums, then the four row totals through readlane
+// (v_readlane -> SGPR).  Replaces the __shfl_xor butterfly (six ds_bpermute round trips through the LDS crossbar).
+__device__ __forceinline__ float wave64_sum(float v) {
+    v = row16_sum(v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // Workgroup id -> work-item id such that each XCD (workgroup b runs on XCD b % 8) gets a CONTIGUOUS range
 // of work items: GEMM tiles sharing an A row-panel, or attention query blocks sharing one (sample, head)'s
 // K/V, then hit the same 4 MiB L2.  Bijective for any count; placement affects speed only.

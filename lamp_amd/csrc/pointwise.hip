@@ -4,11 +4,7 @@
 
 namespace lamp {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave64_sum(v); }
 
 // out[t, :] = emb[seq[t], :] (+ pos_table[pos[t], :])          lamp/Encoders.py:66,75
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ seq,
