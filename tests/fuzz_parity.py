@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential campaign on the MI355X (not part of the pytest suite: minutes, not seconds).
 
-    python tools/fuzz_parity.py <n_eval_cases> <n_train_cases>
+    python tests/fuzz_parity.py <n_eval_cases> <n_train_cases>
+
+(Lives under tests/ because it uses the oracle, which only test code may import.)
 
 Eval: random model shapes (1-8 heads, d_k 4..256 incl. widths beyond the fused attention kernel, 1-3 + 1-3 layers,
 every mask kind, L and T from 1 to 300 / 150, ragged lengths, with / without decoder self-attention): logits and

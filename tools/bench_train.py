@@ -2,11 +2,11 @@
 """Training-step throughput of the HIP path: the reference's train loop body (train.py:34-48) --
 forward in train() mode with dropout, BCE-with-logits, loss.backward(), Adam step -- on one synthetic batch.
 
-    python tools/bench_train.py [--workload reuters] [--batch 32] [--steps 30] [--dropout 0.1] [--cpu]
+    python tools/bench_train.py [--workload reuters] [--batch 32] [--steps 30] [--dropout 0.1]
 
 Prints one JSON line: samples/s of the whole step, the split into forward / backward / optimizer wall time, the
-summed HIP-event kernel time per class (so host overhead = wall - kernels is visible), and with --cpu the same step
-on the oracle's autograd on the host cores (bounded sample).
+summed HIP-event kernel time per class (so host overhead = wall - kernels is visible).  The same step on the CPU
+oracle's autograd is timed by tests/time_oracle_train_step.py (the oracle is test infrastructure).
 """
 import argparse
 import json
@@ -28,7 +28,6 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dropout', type=float, default=0.1)
-    ap.add_argument('--cpu', action='store_true', help='also time the oracle autograd step on the host')
     a = ap.parse_args()
     from lamp_amd import _native as N
     dev = torch.device('cuda:0')
@@ -84,22 +83,6 @@ def main():
                                     for k, v in prof.items()},
            'note': 'only launches bracketed by the library profiler are listed (pointwise backward kernels and torch '
                    'optimizer kernels are not); wall - kernels = host-side autograd / launch overhead'}
-    if a.cpu:
-        from oracle import lamp_ref as R
-        blocked = R.label_block_mask(adj, w['mask'], w['L'])
-        sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
-        seq_c, pos_c, tgt_c = seq.cpu(), pos.cpu(), tgt.cpu()
-        torch.set_num_threads(16)
-
-        def cpu_step():
-            lg, _, _ = R.forward(sdg, seq_c, pos_c, w['h'], blocked)
-            F.binary_cross_entropy_with_logits(lg, tgt_c).backward()
-        cpu_step()
-        ts = []
-        while len(ts) < 5:
-            t0 = time.perf_counter(); cpu_step(); ts.append(time.perf_counter() - t0)
-        out['cpu_oracle_autograd'] = {'value': a.batch / sorted(ts)[2], 'unit': 'samples/s', 'threads': 16,
-                                      'sample': '5 forward+backward steps (median), dropout off, no optimizer'}
     print(json.dumps(out))
 
 

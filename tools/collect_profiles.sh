@@ -28,7 +28,8 @@ BENCH="python $PWD/bench.py --no-cpu-baseline --no-pipelined"
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o p -f csv -- $BENCH --steps 5 --warmup 3 > /dev/null 2>&1 )
 done
-python tools/bench_train.py --cpu > "$OUT/train_reuters.json" 2>/dev/null
+python tools/bench_train.py > "$OUT/train_reuters.json" 2>/dev/null
+python tests/time_oracle_train_step.py > "$OUT/train_reuters_cpu_oracle.json" 2>/dev/null
 python tools/bench_train.py --workload delicious --steps 5 --warmup 2 > "$OUT/train_delicious.json" 2>/dev/null
 python tools/bench_kernels.py gemm_gen 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_gen.txt"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/train_stats" -o p -f csv -- python $REPO/tools/bench_train.py --steps 20 > /dev/null 2>&1 )

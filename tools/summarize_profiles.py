@@ -47,7 +47,7 @@ def main():
     cp('attn_variants.txt', 'attn_variants.txt')
     cp('sparse_label_attention.txt', 'sparse_label_attention.txt')
     cp('stats/p_kernel_stats.csv', 'bench_kernel_stats.csv')
-    for f in ('train_reuters.json', 'train_delicious.json', 'gemm_gen.txt'):
+    for f in ('train_reuters.json', 'train_reuters_cpu_oracle.json', 'train_delicious.json', 'gemm_gen.txt'):
         if os.path.exists(os.path.join(src, f)):
             cp(f, f)
     if os.path.exists(os.path.join(src, 'train_stats/p_kernel_stats.csv')):
