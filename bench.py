@@ -8,13 +8,27 @@ the configuration the metric is quoted on: reuters-shaped, batch 32 per GPU, T =
 L = 90 labels, d_model 512, 2 + 2 graph layers, 4 heads, label_mask = prior.
 Inputs and weights are resident in HBM before the timed region.  Samples shard over GPUs with no
 collective on the data path (weak scaling: every rank runs its own batch of 32); torch.distributed
-is used only for the barrier and the max-over-ranks of the elapsed time.
+is used only for the barrier, the max-over-ranks of the elapsed time and the per-rank report.
+
+Launching N > 1 ranks: either under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or plainly as `python bench.py --gpus N`:
+without WORLD_SIZE in the environment the script starts the N ranks itself (one process per visible
+device, rendezvous on 127.0.0.1) and exits non-zero unless exactly N ranks report.  Replaces the
+reference's single-process nn.DataParallel scatter (main.py:106-108).
+
+BASELINE.json configs[4] (4096 labels x 512 tokens, d_model 1024, batch 8192 over 8 GPUs) is
+    python bench.py --gpus 8 --workload synthetic4096 --batch 1024 --steps 2 --warmup 1
 
 Rank 0 prints ONE JSON line with, besides the contract fields,
+  ranks_seen / per_rank   which ranks reported and each one's own samples/s,
   roofline      the dominant kernel class (fp32-MFMA GEMM): algorithmic FLOPs of its launches divided
                 by their HIP-event durations (events recorded by liblamp_hip.so on the launch stream,
-                in an instrumented replay of the same K steps right after the timed region),
+                in an instrumented replay of the same K steps right after the timed region); `traffic`
+                = HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes
+                (profiles/hbm_traffic.json, written by tools/summarize_profiles.py),
   forward       whole-forward achieved fraction of the fp32 MFMA roof with F_live of SURVEY.md 8d,
+  workloads     (N = 1) the other GPU configurations of BASELINE.json -- bibtex, delicious, synthetic4096 --
+                each for a bounded number of steps: value, ms_per_step, GEMM roofline, attention TFLOP/s,
   cpu_baseline  the oracle (a port of the reference's op sequence, `as_written`, autograd graph
                 built as the reference's test loop does) timed on this host's cores on a bounded
                 sample (N = 1 only).
@@ -22,6 +36,8 @@ Rank 0 prints ONE JSON line with, besides the contract fields,
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +48,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
+DEVICE_WARMUP_S = 0.5           # fixed device warm-up before every timed region (clock ramp), stated in `config`
 
 RAGGED = {'reuters': (20, 302), 'bibtex': (10, 150), 'delicious': (5, 60)}  # SURVEY.md 8d length variant (ii)
 WORKLOADS = {
@@ -41,6 +58,8 @@ WORKLOADS = {
     'delicious': dict(V=504, L=983, T=40, d=1024, dff=2048, h=8, mask='none', pos=False, p=0.0),
     'synthetic4096': dict(V=32004, L=4096, T=512, d=1024, dff=2048, h=8, mask='prior', pos=True, p=0.05),
 }
+# bounded (steps, warmup) of the secondary workloads reported beside the headline at N = 1
+EXTRA_WORKLOADS = (('bibtex', 100, 10), ('delicious', 20, 3), ('synthetic4096', 4, 1))
 
 
 def f_live(w, n_enc=2, n_dec=2):
@@ -116,6 +135,144 @@ def cpu_baseline(w, sd, adj, seq, pos, budget_s=20.0):
     }
 
 
+def warm_device(step, seconds=DEVICE_WARMUP_S):
+    """Keep the device busy for a fixed wall time so the timed region does not measure the clock ramp."""
+    t_end = time.perf_counter() + seconds
+    n = 0
+    while time.perf_counter() < t_end:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        n += 8
+    return n
+
+
+def load_traffic(workload):
+    """HBM-side bytes per GEMM launch measured by the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs, FETCH_SIZE doubled per the MI355X guide's gfx950 calibration) -- or None when no profile of this
+    workload is committed.  Written by tools/summarize_profiles.py."""
+    path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
+def profile_steps(N, step, n_steps):
+    """Instrumented replay: per-kernel-class HIP-event durations on the launch stream."""
+    N.prof_reset()
+    N.prof_enable(True)
+    for _ in range(n_steps):
+        step()
+    torch.cuda.synchronize()
+    N.prof_enable(False)
+    prof = N.prof_read()
+    N.prof_reset()
+    kernels = {}
+    for name, r in prof.items():
+        if r['launches']:
+            kernels[name] = {
+                'launches_per_step': r['launches'] / n_steps,
+                'us_per_step': r['ms'] * 1e3 / n_steps,
+                'avg_us_per_launch': r['ms'] * 1e3 / r['launches'],
+                'tflops': r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else None,
+                'algorithmic_gbs': r['bytes'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else None,
+            }
+    return prof, kernels
+
+
+def roofline_of(prof, n_steps, workload):
+    gemm = prof['gemm']
+    tf = gemm['flops'] / (gemm['ms'] * 1e-3) / 1e12 if gemm['ms'] > 0 else 0.0
+    tr = load_traffic(workload)
+    launches = gemm['launches'] / n_steps if n_steps else 0
+    out = {
+        'bound': 'mfma', 'kernel': 'gemm_nt_kernel (fp32 MFMA 16x16x4), all launches of a forward',
+        'achieved': tf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_FP32_MFMA_TFLOPS,
+        'traffic': None,
+        'launches_per_step': launches,
+        'avg_launch_us': gemm['ms'] * 1e3 / gemm['launches'] if gemm['launches'] else None,
+        'algorithmic_gflop_per_step': gemm['flops'] / n_steps / 1e9 if n_steps else None,
+        'algorithmic_bytes_per_launch': gemm['bytes'] / gemm['launches'] if gemm['launches'] else None,
+    }
+    if tr and tr.get('gemm_launches'):
+        out['traffic'] = (tr['gemm_fetch_bytes'] + tr['gemm_write_bytes']) / tr['gemm_launches']
+        out['traffic_detail'] = {
+            'unit': 'bytes per GEMM launch (HBM-side: L2 fabric requests incl. Infinity-Cache hits)',
+            'fetch': tr['gemm_fetch_bytes'] / tr['gemm_launches'], 'write': tr['gemm_write_bytes'] / tr['gemm_launches'],
+            'source': tr.get('source'), 'batch': tr.get('batch'),
+        }
+    else:
+        out['traffic_detail'] = 'no committed PMC profile of this workload (profiles/hbm_traffic.json)'
+    return out
+
+
+def measure(N, name, w, batch, steps, warmup, device, rank, sync, lengths=None, graph=False):
+    """Build one workload on `device`, warm up, time exactly `steps` steps between barriers.  -> dict."""
+    model, sd, adj, seq, pos = build(w, batch, device, seed=rank, lengths=lengths)
+    src = (seq.to(device), pos.to(device))
+
+    def step():
+        return model(src, None, None, None)
+
+    for _ in range(max(warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    run = step
+    g = None
+    if graph:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = step()
+        run = g.replay
+    warm_n = warm_device(run)
+    run()
+    torch.cuda.synchronize()
+
+    sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sync()
+    logits = out[0]
+    assert torch.isfinite(logits).all(), 'non-finite logits'
+    return dict(model=model, sd=sd, adj=adj, seq=seq, pos=pos, step=step, run=run, elapsed=elapsed,
+                device_warmup_steps=warm_n, graph=g)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per visible device."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0',
+                   LAMP_BENCH_SPAWNED='1')
+        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in alive:      # a dead rank leaves the others in a barrier: stop exactly the ones we started
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -129,14 +286,15 @@ def main():
     ap.add_argument('--no-pipelined', action='store_true',
                     help='skip the extra two-batches-in-flight measurement (use under rocprofv3: overlapping '
                          'kernels inflate per-kernel durations)')
-    ap.add_argument('--fuse-ln', type=int, default=None, choices=[0, 1],
-                    help='override LAMP.fuse_layernorm (deferred LayerNorm: fewer launches, logits equal to rounding)')
+    ap.add_argument('--no-extra-workloads', action='store_true',
+                    help='skip the bounded bibtex / delicious / synthetic4096 runs reported beside the headline (N = 1)')
     ap.add_argument('--ragged', action='store_true',
                     help='sequence lengths U{lo..hi} padded to the batch maximum (SURVEY.md 8d variant ii) instead of fixed T')
     ap.add_argument('--mask', default=None, choices=['prior', 'none', 'inveye'], help='override the workload label mask')
-    ap.add_argument('--streams', type=int, default=1, choices=[1, 2],
-                    help='HIP streams one forward spreads its batch over (lamp_set_forward_streams)')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -156,13 +314,16 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    n_gpus = world if world > 1 else 1
-    if world > 1 and args.gpus != world and rank == 0:
-        print('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print('error: --gpus %d but %d rank(s) were launched' % (args.gpus, world), file=sys.stderr)
+    comm_dev = device if backend == 'nccl' else torch.device('cpu')
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
 
     from lamp_amd import _native as N
     N.lib()
-    N.set_forward_streams(args.streams)
     w = dict(WORKLOADS[args.workload])
     if args.mask:
         w['mask'] = args.mask
@@ -172,45 +333,21 @@ def main():
         g = torch.Generator().manual_seed(1000 + rank)
         lengths = torch.randint(lo, hi + 1, (args.batch,), generator=g).tolist()
         w['T'] = max(lengths)  # padded length of this batch: what the kernels process and what F_live counts
-    model, sd, adj, seq, pos = build(w, args.batch, device, seed=rank, lengths=lengths)
-    if args.fuse_ln is not None:
-        model.fuse_layernorm = bool(args.fuse_ln)
-    src = (seq.to(device), pos.to(device))
 
-    def step():
-        return model(src, None, None, None)
+    m = measure(N, args.workload, w, args.batch, args.steps, args.warmup, device, rank, sync, lengths=lengths,
+                graph=args.graph)
+    model, step, run, my_elapsed = m['model'], m['step'], m['run'], m['elapsed']
 
-    for _ in range(max(args.warmup, 1)):
-        out = step()
-    torch.cuda.synchronize()
-
-    graph = None
-    if args.graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = step()
-        run = graph.replay
-    else:
-        run = step
-    run()
-    torch.cuda.synchronize()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
+    # every rank reports (rank, device, elapsed, samples); rank 0 aggregates: total samples / max elapsed
+    mine = torch.tensor([float(rank), float(dev_index), my_elapsed, float(args.batch * args.steps)],
+                        dtype=torch.float64, device=comm_dev)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        rows = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        rows = [r.cpu().tolist() for r in rows]
+    else:
+        rows = [mine.cpu().tolist()]
+    elapsed = max(r[2] for r in rows)
 
     # per-step latency with a device sync after every step (median and min), outside the timed region
     lat = []
@@ -221,10 +358,6 @@ def main():
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - ts) * 1e3)
     lat.sort()
-
-    # sanity: the timed work produced finite logits
-    logits = out[0]
-    assert torch.isfinite(logits).all(), 'non-finite logits'
 
     # ---- throughput mode (reported beside `value`, never as `value`): successive batches issued round-robin
     # on two HIP streams, so that one forward's launch gaps / ramp / tail are filled by the other's kernels ----
@@ -250,38 +383,21 @@ def main():
         pipelined['value'] = pipelined['depth_2']['value']
         pipelined['streams'] = 2
 
-    # ---- instrumented replay: per-kernel HIP-event durations on the launch stream ----
     prof_steps = min(args.steps, 20)
-    N.prof_reset()
-    N.prof_enable(True)
-    for _ in range(prof_steps):
-        step()
-    torch.cuda.synchronize()
-    N.prof_enable(False)
-    prof = N.prof_read()
-    N.prof_reset()
+    prof, kernels = profile_steps(N, step, prof_steps)
 
     if rank != 0:
         if dist is not None:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
-    samples = args.batch * n_gpus * args.steps
+    ranks_seen = sorted(int(r[0]) for r in rows)
+    n_gpus = len(ranks_seen)
+    samples = sum(r[3] for r in rows)
     value = samples / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     fl = f_live(w)
-    gemm = prof['gemm']
-    gemm_tflops = gemm['flops'] / (gemm['ms'] * 1e-3) / 1e12 if gemm['ms'] > 0 else 0.0
-    kernels = {}
-    for name, r in prof.items():
-        if r['launches']:
-            kernels[name] = {
-                'launches_per_step': r['launches'] / prof_steps,
-                'us_per_step': r['ms'] * 1e3 / prof_steps,
-                'avg_us_per_launch': r['ms'] * 1e3 / r['launches'],
-                'tflops': r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else None,
-                'algorithmic_gbs': r['bytes'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else None,
-            }
     result = {
         'metric': 'forward samples/sec, reuters d512 2+2L 4h' if args.workload == 'reuters' else
                   'forward samples/sec, %s d%d 2+2L %dh' % (args.workload, w['d'], w['h']),
@@ -289,6 +405,10 @@ def main():
         'ms_per_step': ms_per_step, 'step_ms_synced': {'median': lat[len(lat) // 2], 'min': lat[0], 'n': len(lat)},
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
+        'ranks_seen': ranks_seen,
+        'per_rank': [{'rank': int(r[0]), 'device': int(r[1]), 'value': r[3] / r[2], 'ms_per_step': r[2] / args.steps * 1e3}
+                     for r in sorted(rows)],
+        'physical_devices': len({int(r[1]) for r in rows}),
         'config': {'workload': '%s: batch %d/GPU, T=%d %s, L=%d, d_model=%d, d_ff=%d, 2 enc + 2 dec graph layers, '
                                '%d heads, label_mask=%s, fp32' %
                                (args.workload, args.batch, w['T'],
@@ -296,15 +416,12 @@ def main():
                                 else 'fixed', w['L'], w['d'], w['dff'], w['h'], w['mask']),
                    'batch_per_gpu': args.batch, 'parallelism': 'batch-sharded x%d, no collectives' % n_gpus,
                    'launch': 'hip-graph replay' if args.graph else 'eager (one lamp_forward call per step)',
-                   'streams_per_forward': args.streams, 'deferred_layernorm': bool(model.fuse_layernorm)},
-        'roofline': {
-            'bound': 'mfma', 'kernel': 'gemm_nt_kernel (fp32 MFMA 16x16x4), all launches of a forward',
-            'achieved': gemm_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': gemm_tflops / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
-            'launches_per_step': gemm['launches'] / prof_steps if prof_steps else None,
-            'avg_launch_us': gemm['ms'] * 1e3 / gemm['launches'] if gemm['launches'] else None,
-            'algorithmic_gflop_per_step': gemm['flops'] / prof_steps / 1e9 if prof_steps else None,
-        },
+                   'launcher': 'self-spawned ranks' if os.environ.get('LAMP_BENCH_SPAWNED') else
+                               ('torch.distributed.run' if world > 1 else 'single process'),
+                   'backend': backend if world > 1 else None,
+                   'device_warmup_s': DEVICE_WARMUP_S, 'device_warmup_steps': m['device_warmup_steps'],
+                   },
+        'roofline': roofline_of(prof, prof_steps, args.workload if not (args.ragged or args.mask) else None),
         'forward': {
             'f_live_gflop_per_sample': fl / 1e9,
             'achieved_tflops_per_gpu': value / n_gpus * fl / 1e12,
@@ -314,13 +431,46 @@ def main():
         'kernels': kernels,
         'pipelined_batches_in_flight': pipelined,
     }
+
+    if n_gpus == 1 and not args.no_extra_workloads and args.workload == 'reuters' and not (args.ragged or args.mask):
+        # the other GPU configurations of BASELINE.json, bounded; the headline model is dropped first
+        sd_h, adj_h, seq_h, pos_h = m['sd'], m['adj'], m['seq'], m['pos']
+        del model, step, run
+        m.clear()
+        torch.cuda.empty_cache()
+        extra = {}
+        for name, steps, warm in EXTRA_WORKLOADS:
+            we = dict(WORKLOADS[name])
+            me = measure(N, name, we, 32, steps, warm, device, 0, lambda: None)
+            pe, ke = profile_steps(N, me['step'], min(steps, 10))
+            v = 32 * steps / me['elapsed']
+            fe = f_live(we)
+            rf = roofline_of(pe, min(steps, 10), name)
+            extra[name] = {
+                'value': v, 'unit': 'samples/s', 'batch': 32, 'steps': steps, 'warmup': warm,
+                'ms_per_step': me['elapsed'] / steps * 1e3,
+                'config': 'T=%d fixed, L=%d, d_model=%d, d_ff=%d, %d heads, label_mask=%s' %
+                          (we['T'], we['L'], we['d'], we['dff'], we['h'], we['mask']),
+                'roofline': {'achieved': rf['achieved'], 'frac': rf['frac'], 'unit': 'TFLOP/s', 'traffic': rf['traffic']},
+                'attention_tflops': ke.get('attention', {}).get('tflops'),
+                'forward_frac_of_fp32_mfma_peak': v * fe / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            }
+            me.clear()
+            torch.cuda.empty_cache()
+        result['workloads'] = extra
+        m.update(sd=sd_h, adj=adj_h, seq=seq_h, pos=pos_h)
+
     if n_gpus == 1 and not args.no_cpu_baseline:
-        cb = cpu_baseline(w, sd, adj, seq, pos, args.cpu_budget)
+        cb = cpu_baseline(w, m['sd'], m['adj'], m['seq'], m['pos'], args.cpu_budget)
         result['cpu_baseline'] = cb
         result['speedup_vs_cpu_as_written'] = value / cb['value']
-    print(json.dumps(result))
+    print(json.dumps(result), flush=True)
+    ok = n_gpus == args.gpus
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -15,8 +15,11 @@
  *   - mask convention everywhere (as in the reference): NONZERO = BLOCKED.
  *   - the caller owns every byte: inputs, outputs, weights, workspace.  The library never
  *     allocates or frees device memory and keeps no pointer after return.
- *   - every call only enqueues work on `stream` (asynchronous w.r.t. the host) and is re-entrant;
- *     the device is the one current for the calling thread.
+ *   - every call only enqueues work on `stream` (asynchronous w.r.t. the host) and is re-entrant and
+ *     thread-safe for distinct streams / devices (one host thread per device, as nn.DataParallel runs
+ *     its replicas, works); the device is the one current for the calling thread.
+ *   - no mutable library state: the only process-wide data are lazily initialised, immutable per-device
+ *     kernel attributes and -- for diagnostics, mutex-protected -- the lamp_prof_* event records.
  *   - return value: 0 = ok, > 0 = a hipError_t from a launch, < 0 = lamp_status below.  Nothing
  *     throws or aborts across the boundary.  NaN produced by fully masked attention rows is data,
  *     not an error (reference behaviour).
@@ -31,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LAMP_HIP_ABI_VERSION 1
+#define LAMP_HIP_ABI_VERSION 2
 
 typedef void* lamp_stream_t; /* hipStream_t */
 
@@ -119,31 +122,6 @@ typedef struct lamp_dec_layer {  /* lamp/Layers.py:22-48 */
     lamp_ffn_weights pos_ffn2;
 } lamp_dec_layer;
 
-/* Deferred LayerNorm (optional, lamp_model.fused_ln): a sub-layer's closing LayerNorm is not launched when every
- * consumer of its output is a linear map of the next sub-layer; the producing GEMM's epilogue then also writes the
- * rows' partial sums, the consuming map runs on the pre-norm rows with FOLDED weights (lamp_layernorm_fold: w = W *
- * gamma, s = row sums of w, b = W . beta + bias) and the residual add recomputes LayerNorm from the pre-norm rows
- * and their statistics (lamp_linear_ln_fwd).  All pointers depend on
- * weights only: a caller computes them once per weight version.  Entries that do not apply stay all-NULL. */
-typedef struct lamp_folded_linear {
-    const float* w; /* [out, in] */
-    const float* s; /* [out] */
-    const float* b; /* [out] */
-} lamp_folded_linear;
-typedef struct lamp_fused_ln_enc_layer {
-    lamp_folded_linear w1; /* pos_ffn.w_1 folded with the PREVIOUS encoder layer's pos_ffn LayerNorm (layers >= 1) */
-} lamp_fused_ln_enc_layer;
-typedef struct lamp_fused_ln_dec_layer {
-    lamp_folded_linear enc_q;   /* enc_attn.w_qs with the previous layer's pos_ffn2 LayerNorm (layers >= 1) */
-    lamp_folded_linear ffn1_w1; /* pos_ffn1.w_1 with this layer's enc_attn LayerNorm (layers >= 1) */
-    lamp_folded_linear slf_q, slf_k, slf_v; /* slf_attn projections with this layer's pos_ffn1 LayerNorm */
-    lamp_folded_linear ffn2_w1; /* pos_ffn2.w_1 with this layer's slf_attn LayerNorm (pos_ffn1's without self-attention) */
-} lamp_fused_ln_dec_layer;
-typedef struct lamp_fused_ln {
-    const lamp_fused_ln_enc_layer* enc; /* n_layers_enc entries */
-    const lamp_fused_ln_dec_layer* dec; /* n_layers_dec entries */
-} lamp_fused_ln;
-
 /* The whole graph-encoder / graph-decoder model (lamp/Models.py:18-94).  Host-side struct of
  * device pointers; enc_layers / dec_layers are host arrays. */
 typedef struct lamp_model {
@@ -167,11 +145,6 @@ typedef struct lamp_model {
      * 132-134), so a caller may compute it once per weight version (lamp_linear_fwd) and
      * pass it here; NULL = lamp_forward projects it on every call. */
     const float* dec0_query;
-    /* Optional deferred-LayerNorm data (see lamp_fused_ln): with it, and when no intermediate outputs are requested,
-     * lamp_forward skips the LayerNorm launches whose output only feeds the next sub-layer (7 of 10 at 2+2 layers).
-     * Results agree with the plain path to fp32 rounding (single-pass row statistics), not bitwise; a sample's bits
-     * still do not depend on the batch it is in.  Needs n_head > 1 everywhere. */
-    const lamp_fused_ln* fused_ln;
 } lamp_model;
 
 /* Optional extra outputs of lamp_forward (return_attns / int_preds, lamp/Models.py:127-135).
@@ -199,27 +172,6 @@ int lamp_linear_fwd(const float* A, int64_t M, int32_t K, int64_t lda,
                     const float* W, int32_t N, int64_t ldw, const float* bias,
                     const float* residual, int64_t ldr, int32_t relu,
                     float* C, int64_t ldc, lamp_stream_t stream);
-
-/* Deferred LayerNorm: y = LayerNorm(z) is never stored when its only consumers are linear maps.
- *   lamp_layernorm_fold  (weights only, once per weight version):
- *        W_folded[n,k] = W[n,k] * gamma[k],  s[n] = sum_k W_folded[n,k],  bias_folded[n] = W[n,:] . beta + bias[n]
- *   lamp_linear_ln_fwd:   C = act( A' . W^T + bias ) + residual'   (+ row partials of C)
- *        part_out (nullable): per row and 16-column group of C the partial (sum, sum of squares),
- *          [M][4*ceil(N/64)][2] -- the statistics a LayerNorm of C's rows needs, produced in this GEMM's epilogue.
- *        s != NULL: `a` holds PRE-norm rows with partials a_part [M][4*ceil(K/64)][2] (written by the GEMM that produced
- *          them), W is W_folded and bias is bias_folded; the result is rstd_m * (a . W^T - mean_m * s) + bias =
- *          LayerNorm(a) . W_orig^T + bias_orig (single-pass statistics: var = E[a^2] - E[a]^2).
- *        r_part != NULL: `residual` holds PRE-norm rows with partials r_part [M][4*ceil(N/64)][2]; residual' =
- *          LayerNorm(residual; r_gamma, r_beta) recomputed on the fly (lamp/SubLayers.py:115,140 without storing y).
- *        Nothing is added to the GEMM's main loop; summation orders are fixed, independent of the tile configuration.
- * K, lda, ldw multiples of 4; a pre-norm operand needs K a multiple of the tile depth (32) and a LayerNorm width of
- * at most 1024. */
-int lamp_layernorm_fold(const float* W, int32_t N, int32_t K, const float* gamma, const float* beta, const float* bias,
-                        float* W_folded, float* s, float* bias_folded, lamp_stream_t stream);
-int lamp_linear_ln_fwd(const float* a, int64_t M, int32_t K, int64_t lda, const float* a_part, const float* W, int32_t N,
-                       int64_t ldw, const float* s, const float* bias, float eps, const float* residual, int64_t ldr,
-                       const float* r_part, const float* r_gamma, const float* r_beta, int32_t relu, float* C, int64_t ldc,
-                       float* part_out, lamp_stream_t stream);
 
 /* nn.LayerNorm over the last dim, biased variance, eps inside the sqrt (lamp/SubLayers.py:68,130).
  * y may alias x.  d must be a multiple of 4. */
@@ -382,12 +334,6 @@ size_t lamp_forward_workspace_bytes(const lamp_model* m, int32_t micro_batch, in
 int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src_pos,
                  int32_t B, int32_t T, float* logits, float* enc_output, const lamp_aux* aux,
                  void* workspace, size_t workspace_bytes, lamp_stream_t stream);
-
-/* Number of HIP streams one lamp_forward call uses: 1 (default) or 2.  With 2, the encoder and the K/V
- * projections of every decoder layer run on `stream`; then the two halves of the batch go through the decoder
- * stack concurrently, one on `stream`, one on a library-owned side stream (forked from and joined to `stream`
- * with events).  Samples are independent: results are bit-identical either way.  Process-wide setting. */
-int lamp_set_forward_streams(int32_t n);
 
 /* ---- per-kernel timing (HIP events on the launch stream; used by bench.py's roofline) ------ */
 enum lamp_kernel_class {

@@ -83,28 +83,78 @@ class LAMP(nn.Module):
         return (p for p in self.parameters() if id(p) not in frozen)
 
     # ------------------------------------------------------------------ native model descriptor
+    def invalidate_native_cache(self):
+        """Drop the cached lamp_model descriptor and the hoisted layer-0 query projection.  Called by load_state_dict,
+        train() / eval() and _apply (.to / .cuda); call it yourself after modifying weights through ``.data`` (in-place
+        updates via ``p.data`` do not bump ``p._version``, which is what the cache otherwise watches)."""
+        self._native_cache = None
+        self._param_list = None
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """nn.Module.load_state_dict; additionally accepts checkpoints saved from an nn.DataParallel wrapper
+        (main.py:106-108 wraps the model BEFORE utils.save_model, so multi-GPU hosts write ``module.``-prefixed keys)."""
+        if state_dict and all(k.startswith('module.') for k in state_dict):
+            state_dict = type(state_dict)((k[len('module.'):], v) for k, v in state_dict.items())
+        self.invalidate_native_cache()
+        return super().load_state_dict(state_dict, *args, **kwargs)
+
+    def train(self, mode=True):
+        self.invalidate_native_cache()   # an optimiser may have stepped through .data; eval recomputes the hoisted query
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_native_cache()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _weight_tensors(self):
+        """Every weight tensor the descriptor points to, in a fixed order, fetched by ATTRIBUTE: a DataParallel
+        replica (torch/nn/parallel/replicate.py) has an empty ``_parameters`` -- ``self.parameters()`` yields nothing
+        there -- but carries its device's copies as plain attributes."""
+        enc, dec = self.encoder, self.decoder
+        out = [enc.src_word_emb.weight, dec.tgt_word_emb.weight, self.tgt_word_proj.linear.weight]
+        if hasattr(enc, 'position_enc'):
+            out.append(enc.position_enc.weight)
+
+        def mha(m):
+            out.extend((m.w_qs.weight, m.w_ks.weight, m.w_vs.weight, m.layer_norm.weight, m.layer_norm.bias))
+            if getattr(m, 'fc', None) is not None:
+                out.append(m.fc.weight)
+
+        def ffn(m):
+            out.extend((m.w_1.weight, m.w_1.bias, m.w_2.weight, m.w_2.bias, m.layer_norm.weight, m.layer_norm.bias))
+        for l in enc.layer_stack:
+            mha(l.slf_attn)
+            ffn(l.pos_ffn)
+        for l in dec.layer_stack:
+            mha(l.enc_attn)
+            ffn(l.pos_ffn1)
+            if hasattr(l, 'slf_attn'):
+                mha(l.slf_attn)
+            ffn(l.pos_ffn2)
+        return out
+
     def _native_model(self):
-        """Build (and cache, keyed on every parameter's data_ptr) the lamp_model struct."""
-        # the Parameter objects are stable (load_state_dict / .to() replace their data, not them); a DataParallel
-        # replica is a shallow copy whose parameters ARE different tensors -- detected by the first one
-        params = self._param_list
-        if params is None or params[0] is not next(self.parameters()):
-            params = self._param_list = [p for p in self.parameters()]
+        """Build (and cache, keyed on every weight's data_ptr) the lamp_model struct."""
+        replica = getattr(self, '_is_replica', False)
+        # the Parameter objects of the original module are stable (load_state_dict / .to() replace their data, not
+        # them): keep the list.  A DataParallel replica is rebuilt on every forward with fresh tensors: no caching.
+        params = None if replica else self._param_list
+        if params is None:
+            params = self._weight_tensors()
+            if not replica:
+                self._param_list = params
         mask = self.decoder.label_mask_u8
         tiles = self.decoder.label_tiles
         bits = self.decoder.label_mask_bits
+        hoist = self.cache_layer0_query and not replica   # the hoisted projection needs a one-off stream sync
         key = tuple(p.data_ptr() for p in params) + (N.ptr(mask), N.ptr(bits), N.ptr(tiles), self.use_label_tiles,
-                                                      self.cache_layer0_query, self.use_mask_bits)
-        if self.cache_layer0_query:  # the hoisted projection below is stale once either operand changes
+                                                      hoist, self.use_mask_bits)
+        if hoist:  # the hoisted projection below is stale once either operand changes
             l0 = self.decoder.layer_stack[0].enc_attn
             key += (self.decoder.tgt_word_emb.weight._version, l0.w_qs.weight._version)
-        fuse = bool(self.fuse_layernorm) and all(
-            l.enc_attn.n_head > 1 and (not hasattr(l, 'slf_attn') or l.slf_attn.n_head > 1) for l in self.decoder.layer_stack)
-        key += (fuse,)
-        if fuse:  # folded weights depend on (almost) every parameter: any in-place update invalidates them
-            key += tuple(p._version for p in params)
-        if self._native_cache is not None and self._native_cache[0] == key:
-            return self._native_cache[1]
+        cache = None if replica else self._native_cache
+        if cache is not None and cache[0] == key:
+            return cache[1]
         for p in params:
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise RuntimeError('lamp_amd expects contiguous fp32 parameters')
@@ -127,12 +177,8 @@ class LAMP(nn.Module):
                     0, N.ptr(enc.src_word_emb.weight), N.ptr(pos), N.ptr(dec.tgt_word_emb.weight),
                     N.ptr(w_out), N.ptr(mask), N.ptr(bits) if self.use_mask_bits else 0,
                     N.ptr(tiles) if self.use_label_tiles else 0, enc_arr, dec_arr, 0)
-        folded = None
-        if fuse:
-            folded = self._fold_layernorms(enc, dec)
-            m.fused_ln = C.pointer(folded[0])
         q0 = None
-        if self.cache_layer0_query and len(dec.layer_stack) > 0:
+        if hoist and len(dec.layer_stack) > 0:
             # decoder layer 0's query = label table x W_q: weights only, so it is projected here once per
             # weight version (lamp_linear_fwd) instead of on every forward
             q0 = N.linear(dec.tgt_word_emb.weight.detach(), dec.layer_stack[0].enc_attn.w_qs.weight.detach())
@@ -140,42 +186,10 @@ class LAMP(nn.Module):
             # forwards may be issued from several streams (evaluate.test_epoch(streams=2)); the cached
             # projection must be complete before any of them reads it -- a one-off sync per weight version
             torch.cuda.current_stream().synchronize()
-        self._native_cache = (key, (m, enc_arr, dec_arr, (q0, folded)))
-        return self._native_cache[1]
-
-    def _fold_layernorms(self, enc, dec):
-        """Deferred LayerNorm (include/lamp_hip.h: lamp_fused_ln): fold each elidable LayerNorm's gamma / beta into the
-        linear maps that consume its output (lamp_layernorm_fold, weights only).  -> (FusedLn struct, keepalive)."""
-        keep = []
-
-        def fold(lin_w, ln, bias=None):
-            w = lin_w.detach()
-            w = w.view(w.size(0), w.size(1))
-            wf, s, bf = N.layernorm_fold(w, ln.weight.detach(), ln.bias.detach(), bias.detach() if bias is not None else None)
-            keep.extend((wf, s, bf))
-            return N.FoldedLinear(wf.data_ptr(), s.data_ptr(), bf.data_ptr())
-        enc_arr = (N.FusedLnEncLayer * max(1, len(enc.layer_stack)))()
-        for i, l in enumerate(enc.layer_stack):
-            if i > 0:
-                prev = enc.layer_stack[i - 1].pos_ffn
-                enc_arr[i] = N.FusedLnEncLayer(fold(l.pos_ffn.w_1.weight, prev.layer_norm, l.pos_ffn.w_1.bias))
-        dec_arr = (N.FusedLnDecLayer * max(1, len(dec.layer_stack)))()
-        for i, l in enumerate(dec.layer_stack):
-            e = N.FusedLnDecLayer()
-            if i > 0:
-                e.enc_q = fold(l.enc_attn.w_qs.weight, dec.layer_stack[i - 1].pos_ffn2.layer_norm)
-                e.ffn1_w1 = fold(l.pos_ffn1.w_1.weight, l.enc_attn.layer_norm, l.pos_ffn1.w_1.bias)
-            if hasattr(l, 'slf_attn'):
-                e.slf_q = fold(l.slf_attn.w_qs.weight, l.pos_ffn1.layer_norm)
-                e.slf_k = fold(l.slf_attn.w_ks.weight, l.pos_ffn1.layer_norm)
-                e.slf_v = fold(l.slf_attn.w_vs.weight, l.pos_ffn1.layer_norm)
-                e.ffn2_w1 = fold(l.pos_ffn2.w_1.weight, l.slf_attn.layer_norm, l.pos_ffn2.w_1.bias)
-            else:
-                e.ffn2_w1 = fold(l.pos_ffn2.w_1.weight, l.pos_ffn1.layer_norm, l.pos_ffn2.w_1.bias)
-            dec_arr[i] = e
-        fused = N.FusedLn(enc_arr, dec_arr)
-        keep.extend((enc_arr, dec_arr))
-        return fused, keep
+        built = (m, enc_arr, dec_arr, q0)
+        if not replica:
+            self._native_cache = (key, built)
+        return built
 
     def forward(self, src, adj, tgt_seq, binary_tgt, return_attns=False, int_preds=False):
         if self.decoder_type != 'graph':
@@ -184,6 +198,10 @@ class LAMP(nn.Module):
             raise NotImplementedError('per-sample adjacency for the encoder is outside the hot path')
         src_seq, src_pos = src
         N.require_device(src_seq, src_pos)
+        if src_seq.device.index != torch.cuda.current_device():
+            # every launch goes to the CURRENT device's stream: make the tensors' device current for the call
+            with torch.cuda.device(src_seq.device):
+                return self.forward(src, adj, tgt_seq, binary_tgt, return_attns=return_attns, int_preds=int_preds)
         if self.training:
             # train.py:36: the autograd-recording path (HIP kernels forward and backward, lamp_amd/training.py)
             from . import training
@@ -248,6 +266,3 @@ class LAMP(nn.Module):
     use_label_tiles = True
     # Read the label mask bit-packed (one 32-bit word per 32-key tile and row) instead of as bytes.
     use_mask_bits = True
-    # Deferred LayerNorm: skip the LayerNorm launches whose output only feeds the next sub-layer's linear maps
-    # (include/lamp_hip.h: lamp_fused_ln).  Logits agree with the plain path to fp32 rounding, not bitwise.
-    fuse_layernorm = False

@@ -11,8 +11,11 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liblamp_hip.so')
+# LAMP_HIP_LIBRARY: load another build of the same library (tools/bench_kernels.py runs on the -DLAMP_TUNING build)
+LIB_PATH = os.environ.get('LAMP_HIP_LIBRARY') or os.path.join(_HERE, 'liblamp_hip.so')
+TUNING_LIB_PATH = os.path.join(_HERE, 'liblamp_hip_tuning.so')
 
+ABI_VERSION = 2
 LAMP_MASK_NONE, LAMP_MASK_U8, LAMP_MASK_KEY_TOKENS_I64, LAMP_MASK_BITS_U32 = 0, 1, 2, 3
 K_EMBED, K_GEMM, K_ATTN, K_LAYERNORM, K_DIAG, K_COUNT = 0, 1, 2, 3, 4, 5
 KERNEL_CLASS_NAMES = ('embed', 'gemm', 'attention', 'layernorm', 'diag_readout')
@@ -58,30 +61,13 @@ class DecLayer(C.Structure):
                 ('pos_ffn2', FfnWeights)]
 
 
-class FoldedLinear(C.Structure):  # include/lamp_hip.h: lamp_folded_linear
-    _fields_ = [('w', _vp), ('s', _vp), ('b', _vp)]
-
-
-class FusedLnEncLayer(C.Structure):
-    _fields_ = [('w1', FoldedLinear)]
-
-
-class FusedLnDecLayer(C.Structure):
-    _fields_ = [('enc_q', FoldedLinear), ('ffn1_w1', FoldedLinear), ('slf_q', FoldedLinear), ('slf_k', FoldedLinear),
-                ('slf_v', FoldedLinear), ('ffn2_w1', FoldedLinear)]
-
-
-class FusedLn(C.Structure):
-    _fields_ = [('enc', C.POINTER(FusedLnEncLayer)), ('dec', C.POINTER(FusedLnDecLayer))]
-
-
 class Model(C.Structure):
     _fields_ = [('n_src_vocab', C.c_int32), ('n_position', C.c_int32), ('n_labels', C.c_int32),
                 ('d_model', C.c_int32), ('d_inner', C.c_int32), ('d_k', C.c_int32), ('d_v', C.c_int32),
                 ('n_layers_enc', C.c_int32), ('n_layers_dec', C.c_int32), ('reserved', C.c_int32),
                 ('src_word_emb', _vp), ('position_enc', _vp), ('tgt_word_emb', _vp), ('w_out', _vp),
                 ('label_mask', _vp), ('label_mask_bits', _vp), ('label_tiles', _vp), ('enc_layers', C.POINTER(EncLayer)), ('dec_layers', C.POINTER(DecLayer)),
-                ('dec0_query', _vp), ('fused_ln', C.POINTER(FusedLn))]
+                ('dec0_query', _vp)]
 
 
 class GemmDesc(C.Structure):  # include/lamp_hip.h: lamp_gemm_desc
@@ -105,9 +91,6 @@ PROTOTYPES = {
     'lamp_version': (C.c_int, []),
     'lamp_strerror': (C.c_char_p, [C.c_int]),
     'lamp_linear_fwd': (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
-    'lamp_layernorm_fold': (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'lamp_linear_ln_fwd': (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _i64, _vp, _vp, _f, _vp, _i64, _vp, _vp, _vp, _i32,
-                                     _vp, _i64, _vp, _vp]),
     'lamp_layernorm_fwd': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _f, _vp, _vp]),
     'lamp_sdpa_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f,
                                 C.POINTER(Mask), C.POINTER(AttnLayout), _vp]),
@@ -136,7 +119,6 @@ PROTOTYPES = {
     'lamp_sigmoid_bce_fwd': (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     'lamp_forward_workspace_bytes': (_sz, [C.POINTER(Model), _i32, _i32, _i32]),
     'lamp_forward': (C.c_int, [C.POINTER(Model), _vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(Aux), _vp, _sz, _vp]),
-    'lamp_set_forward_streams': (C.c_int, [_i32]),
     'lamp_prof_enable': (C.c_int, [_i32]),
     'lamp_prof_reset': (C.c_int, []),
     'lamp_prof_read': (C.c_int, [_i32, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -147,24 +129,29 @@ _lib = None
 _lock = threading.Lock()
 
 
+def load_library(path):
+    """dlopen one build of the library and attach the header's prototypes.  Raises when it is absent."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            'lamp_amd: %s is missing -- build it with `python -m lamp_amd.build` '
+            '(hipcc, gfx950).  There is no CPU or PyTorch fallback.' % path)
+    handle = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    if handle.lamp_version() != ABI_VERSION:
+        raise RuntimeError('lamp_amd: ABI version mismatch in ' + path)
+    return handle
+
+
 def lib():
     """Load liblamp_hip.so once.  Raises (never falls back) when it is absent."""
     global _lib
     if _lib is None:
         with _lock:
             if _lib is None:
-                if not os.path.exists(LIB_PATH):
-                    raise RuntimeError(
-                        'lamp_amd: %s is missing -- build it with `python -m lamp_amd.build` '
-                        '(hipcc, gfx950).  There is no CPU or PyTorch fallback.' % LIB_PATH)
-                handle = C.CDLL(LIB_PATH)
-                for name, (res, args) in PROTOTYPES.items():
-                    fn = getattr(handle, name)
-                    fn.restype = res
-                    fn.argtypes = args
-                if handle.lamp_version() != 1:
-                    raise RuntimeError('lamp_amd: ABI version mismatch in ' + LIB_PATH)
-                _lib = handle
+                _lib = load_library(LIB_PATH)
     return _lib
 
 
@@ -281,7 +268,7 @@ def key_token_mask(src_seq, T):
 
 
 # ------------------------------------------------------------------ thin wrappers
-def linear(x, weight, bias=None, residual=None, relu=False):
+def linear(x, weight, bias=None, residual=None, relu=False, _lib=None):
     require_device(x, weight, bias, residual)
     x2 = f32c(x).reshape(-1, x.size(-1))
     w = f32c(weight).reshape(weight.size(0), -1)
@@ -290,44 +277,9 @@ def linear(x, weight, bias=None, residual=None, relu=False):
     out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     r = f32c(residual).reshape(M, N) if residual is not None else None
     b = f32c(bias) if bias is not None else None
-    check(lib().lamp_linear_fwd(ptr(x2), M, K, K, ptr(w), N, K, ptr(b), ptr(r), N, int(relu), ptr(out), N,
+    check((_lib or lib()).lamp_linear_fwd(ptr(x2), M, K, K, ptr(w), N, K, ptr(b), ptr(r), N, int(relu), ptr(out), N,
                                 stream()), 'lamp_linear_fwd')
     return out.view(*x.shape[:-1], N)
-
-
-def layernorm_fold(weight, gamma, beta, bias=None):
-    """-> (W_folded, s, bias_folded) for lamp_linear_ln_fwd (weights only; cache per weight version)."""
-    require_device(weight, gamma, beta, bias)
-    w = f32c(weight)
-    Nn, K = w.shape
-    wf = torch.empty_like(w)
-    s = torch.empty(Nn, dtype=torch.float32, device=w.device)
-    bf = torch.empty_like(s)
-    check(lib().lamp_layernorm_fold(ptr(w), Nn, K, ptr(f32c(gamma)), ptr(f32c(beta)), ptr(f32c(bias) if bias is not None else None),
-                                    ptr(wf), ptr(s), ptr(bf), stream()), 'lamp_layernorm_fold')
-    return wf, s, bf
-
-
-def linear_ln(a, weight, s=None, bias=None, a_part=None, eps=1e-5, residual=None, r_part=None, r_gamma=None, r_beta=None,
-              relu=False, want_part=False):
-    """act(A' . W^T + bias) + residual' through lamp_linear_ln_fwd (see include/lamp_hip.h):
-    s given: `a` is pre-LayerNorm with row partials a_part and (weight, s, bias) = layernorm_fold(...);
-    r_part given: `residual` is pre-LayerNorm (r_gamma, r_beta); want_part: also return the row partials of the output.
-    -> C or (C, part)."""
-    require_device(a, residual, a_part, r_part)
-    a2 = f32c(a).reshape(-1, a.size(-1))
-    M, K = a2.shape
-    w = f32c(weight)
-    Nn = w.size(0)
-    out = torch.empty((M, Nn), dtype=torch.float32, device=a2.device)
-    part = torch.empty((M, 4 * ((Nn + 63) // 64), 2), dtype=torch.float32, device=a2.device) if want_part else None
-    r = f32c(residual).reshape(M, Nn) if residual is not None else None
-    opt = lambda t: ptr(f32c(t)) if t is not None else None  # noqa: E731
-    check(lib().lamp_linear_ln_fwd(ptr(a2), M, K, K, opt(a_part), ptr(w), Nn, K, opt(s), opt(bias), eps, ptr(r), Nn,
-                                   opt(r_part), opt(r_gamma), opt(r_beta), int(bool(relu)), ptr(out), Nn, ptr(part),
-                                   stream()), 'lamp_linear_ln_fwd')
-    out = out.view(tuple(a.shape[:-1]) + (Nn,))
-    return (out, part) if want_part else out
 
 
 def layernorm(x, gamma, beta, eps=1e-5):
@@ -339,7 +291,7 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return out.view(x.shape)
 
 
-def sdpa(q, k, v, mask, inv_temperature, need_attn=True):
+def sdpa(q, k, v, mask, inv_temperature, need_attn=True, _lib=None):
     """q (N, lq, dk), k (N, lk, dk), v (N, lk, dv) head-major batches as in the reference."""
     require_device(q, k, v)
     q, k, v = f32c(q), f32c(k), f32c(v)
@@ -350,7 +302,7 @@ def sdpa(q, k, v, mask, inv_temperature, need_attn=True):
     attn = torch.empty((N, lq, lk), dtype=torch.float32, device=q.device) if (need_attn or wide) else None
     mstruct, keep = make_mask(mask, N, lq, lk)
     lay = AttnLayout(lq * dk, 0, dk, lk * dk, 0, dk, lk * dv, 0, dv, lq * dv, 0, dv)
-    check(lib().lamp_sdpa_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(attn), N, 1, lq, lk, dk, dv,
+    check((_lib or lib()).lamp_sdpa_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(attn), N, 1, lq, lk, dk, dv,
                               float(inv_temperature), C.byref(mstruct) if mstruct is not None else None,
                               C.byref(lay), stream()), 'lamp_sdpa_fwd')
     del keep
@@ -663,11 +615,6 @@ def sigmoid_bce(logits, targets=None):
     check(lib().lamp_sigmoid_bce_fwd(ptr(x), ptr(z), B, L, ptr(probs), ptr(row_loss), stream()),
           'lamp_sigmoid_bce_fwd')
     return probs, row_loss
-
-
-def set_forward_streams(n):
-    """1 or 2 HIP streams per lamp_forward call (see include/lamp_hip.h)."""
-    check(lib().lamp_set_forward_streams(int(n)), 'lamp_set_forward_streams')
 
 
 # ------------------------------------------------------------------ profiling

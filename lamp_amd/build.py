@@ -1,17 +1,30 @@
 """Build liblamp_hip.so (the C-ABI HIP library) for gfx950 with hipcc, in-tree.
 
-    python -m lamp_amd.build            # rebuild if sources are newer than the .so
+    python -m lamp_amd.build            # rebuild what is older than its sources
     python -m lamp_amd.build --force
+
+Two libraries come out of the same sources:
+  liblamp_hip.so         the product: exactly the entry points include/lamp_hip.h declares.
+  liblamp_hip_tuning.so  the same code compiled with -DLAMP_TUNING: additionally exports the lamp_debug_* hooks
+                         (force a GEMM tile / attention variant, per-workgroup timelines) that tools/bench_kernels.py
+                         and the every-variant tests use.  Nothing in lamp_amd/ loads it.
+Translation units are compiled in parallel (one hipcc process each) and linked afterwards.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'liblamp_hip.so')
-SOURCES = ['gemm.hip', 'gemm_gen.hip', 'attention.hip', 'attention_general.hip', 'pointwise.hip', 'backward.hip', 'api.hip']
+LIB_TUNING = os.path.join(HERE, 'liblamp_hip_tuning.so')
+SOURCES = ['gemm.hip', 'gemm_gen.hip', 'attention.hip', 'attention_small.hip', 'attention_general.hip', 'pointwise.hip',
+           'backward.hip', 'api.hip']
+TUNING_SOURCES = {'gemm.hip', 'attention.hip', 'attention_small.hip'}   # the units that contain LAMP_TUNING code
 HEADERS = [os.path.join(CSRC, 'lamp_kernels.h'), os.path.join(HERE, '..', 'include', 'lamp_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
 
 
 def _hipcc():
@@ -21,25 +34,49 @@ def _hipcc():
     return 'hipcc'
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP translation unit for gfx950 and link the shared library."""
-    if not force and not needs_build():
-        return LIB
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-Wno-unused-result', '-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+def needs_build():
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return _newer(LIB, deps) or _newer(LIB_TUNING, deps)
+
+
+def _run(cmd, verbose):
     if verbose:
-        print(' '.join(cmd))
+        print(' '.join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError('hipcc failed:\n' + r.stdout + r.stderr)
+        raise RuntimeError('hipcc failed:\n' + ' '.join(cmd) + '\n' + r.stdout + r.stderr)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP translation unit for gfx950 and link both shared libraries."""
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    cc = _hipcc()
+    jobs = []   # (object, command)
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        deps = [src] + HEADERS
+        obj = os.path.join(OBJ, s.replace('.hip', '.o'))
+        if force or _newer(obj, deps):
+            jobs.append([cc] + FLAGS + ['-c', src, '-o', obj])
+        if s in TUNING_SOURCES:
+            tobj = os.path.join(OBJ, s.replace('.hip', '.tuning.o'))
+            if force or _newer(tobj, deps):
+                jobs.append([cc] + FLAGS + ['-DLAMP_TUNING', '-c', src, '-o', tobj])
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4) or 1) as ex:
+        list(ex.map(lambda c: _run(c, verbose), jobs))
+    objs = [os.path.join(OBJ, s.replace('.hip', '.o')) for s in SOURCES]
+    tobjs = [os.path.join(OBJ, s.replace('.hip', '.tuning.o' if s in TUNING_SOURCES else '.o')) for s in SOURCES]
+    _run([cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs, verbose)
+    _run([cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_TUNING] + tobjs, verbose)
     return LIB
 
 

@@ -77,20 +77,9 @@ struct Carver {
     }
 };
 
-// Deferred-LayerNorm context of one GEMM (gemm.hip).
-struct LnGemm {
-    const float* s[GEMM_MAX_SEG] = {};  // per segment: row sums of the folded weights (A is pre-norm), or null
-    const float* a_part = nullptr;      // partial (sum, sum of squares) of A's rows per 16-column group, [M][ln_parts][2]
-    const float* r_part = nullptr;      // R is pre-norm: its rows' partials ...
-    const float* r_g = nullptr;         // ... and the pending LayerNorm's gamma / beta
-    const float* r_b = nullptr;
-    float* part_out = nullptr;          // partials of this GEMM's output rows (the next sub-layer's input)
-};
-static inline int ln_parts(int d) { return 4 * ((d + 63) / 64); }  // 16-column groups, padded to whole 64-column tiles
-
 static int linear(const float* A, int64_t M, int K, int64_t lda, const float* const* W, int nseg, int N,
                   int64_t ldw, const float* const* bias, const float* R, int64_t ldr, int relu,
-                  float* const* C, int64_t ldc, hipStream_t s, const LnGemm* ln = nullptr) {
+                  float* const* C, int64_t ldc, hipStream_t s) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.M = M; p.K = K; p.N = N; p.nseg = nseg; p.ldw = ldw; p.ldc = ldc;
     p.R = R; p.ldr = ldr; p.relu = relu;
@@ -98,27 +87,9 @@ static int linear(const float* A, int64_t M, int K, int64_t lda, const float* co
         p.W[i] = W[i];
         p.bias[i] = bias ? bias[i] : nullptr;
         p.C[i] = C[i];
-        if (ln) p.ln_s[i] = ln->s[i];
-    }
-    if (ln) {
-        p.ln_eps = 1e-5f;
-        p.a_part = ln->a_part; p.a_nparts = ln_parts(K);
-        p.r_part = ln->r_part; p.r_nparts = ln_parts(N); p.r_gamma = ln->r_g; p.r_beta = ln->r_b;
-        p.part_out = ln->part_out;
     }
     return launch_gemm(p, s);
 }
-
-// A sub-layer whose INPUT is pre-LayerNorm (the previous sub-layer deferred its LayerNorm): the pending norm's affine
-// parameters, the row partials its producer wrote, and the folded weights of this sub-layer's first linear map(s).
-struct LnIn {
-    const float* g;
-    const float* b;
-    const float* part;                                 // [rows][ln_parts(d)][2]
-    const lamp_folded_linear *q = nullptr, *k = nullptr, *v = nullptr;  // attention projections
-    const lamp_folded_linear* w1 = nullptr;            // first FFN map
-};
-static inline bool folded_ok(const lamp_folded_linear* f) { return f && f->w && f->s && f->b; }
 
 static int check_mask(const lamp_mask* m) {
     if (!m) return 0;
@@ -144,11 +115,8 @@ static inline bool wide_heads(int dk, int dv) { return dk > 128 || dv > 128; }
 static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, int lq, int lk, int d, int dk,
                     int dv, const lamp_mha_weights& w, const lamp_mask* mask, float* out, float* attn,
                     const MhaScratch& sc, hipStream_t s, bool kv_ready = false,
-                    const float* q_ready = nullptr, int P_batch = 0, int P_b0 = 0, const LnIn* in = nullptr,
-                    float* defer_part = nullptr) {
-    const bool defer_out = defer_part != nullptr;  // leave pre-norm rows in `out`, their row partials in defer_part
+                    const float* q_ready = nullptr, int P_batch = 0, int P_b0 = 0) {
     const int h = w.n_head;
-    if ((in || defer_out) && (h == 1 || xq_shared || !out)) return LAMP_E_UNSUPPORTED;  // needs fc and per-row residual
     if (h < 1 || dk < 1 || dv < 1) return LAMP_E_DIMS;
     if (!w.w_qs || !w.w_ks || !w.w_vs || (out && (!w.ln_g || !w.ln_b))) return LAMP_E_NULL;
     if (h == 1 && out && dv != d) return LAMP_E_DIMS;  // no fc: O is added to the residual directly
@@ -161,36 +129,16 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
 
     if (self && hdk == hdv && need_v) {
         float* C[3] = {sc.Q, sc.K, sc.V};
-        if (in) {  // the label state is pre-norm: folded Q/K/V weights, statistics kept for the residual below
-            if (!folded_ok(in->q) || !folded_ok(in->k) || !folded_ok(in->v)) return LAMP_E_NULL;
-            const float* W[3] = {in->q->w, in->k->w, in->v->w};
-            const float* bf[3] = {in->q->b, in->k->b, in->v->b};
-            LnGemm ln;
-            ln.s[0] = in->q->s; ln.s[1] = in->k->s; ln.s[2] = in->v->s;
-            ln.a_part = in->part;
-            LAMP_CK(linear(xq, Mq, d, d, W, 3, hdk, d, bf, nullptr, 0, 0, C, hdk, s, &ln));
-        } else {
-            const float* W[3] = {w.w_qs, w.w_ks, w.w_vs};
-            LAMP_CK(linear(xq, Mq, d, d, W, 3, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
-        }
+        const float* W[3] = {w.w_qs, w.w_ks, w.w_vs};
+        LAMP_CK(linear(xq, Mq, d, d, W, 3, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
     } else {
-        if (in && (self || q_ready)) return LAMP_E_UNSUPPORTED;
-        if (in) {
-            if (!folded_ok(in->q)) return LAMP_E_NULL;
-            const float* W[1] = {in->q->w};
-            const float* bf[1] = {in->q->b};
-            float* C[1] = {sc.Q};
-            LnGemm ln;
-            ln.s[0] = in->q->s;
-            ln.a_part = in->part;
-            LAMP_CK(linear(xq, Mq, d, d, W, 1, hdk, d, bf, nullptr, 0, 0, C, hdk, s, &ln));
-        } else if (!q_ready) {
+        if (!q_ready) {
             const float* W[1] = {w.w_qs};
             float* C[1] = {sc.Q};
             LAMP_CK(linear(xq, Mq, d, d, W, 1, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
         }
         if (kv_ready) {
-            // sc.K / sc.V were projected earlier (on the side stream, see forward_range)
+            // sc.K / sc.V were projected earlier (every decoder layer's K/V in one launch, see forward_range)
         } else if (need_v && hdk == hdv) {
             const float* W[2] = {w.w_ks, w.w_vs};
             float* C[2] = {sc.K, sc.V};
@@ -238,17 +186,7 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
             LAMP_CK(linear(sc.A, M, hdv, hdv, W, 1, d, hdv, nullptr, nullptr, 0, 0, C, d, s));
             return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, xq, r_mod, out, s);
         }
-        if (in || defer_out) {
-            LnGemm ln;
-            if (in) {  // residual = LayerNorm(xq) recomputed from the pre-norm rows and their statistics
-                ln.r_part = in->part; ln.r_g = in->g; ln.r_b = in->b;
-            }
-            ln.part_out = defer_part;
-            LAMP_CK(linear(sc.A, M, hdv, hdv, W, 1, d, hdv, nullptr, xq, d, 0, C, d, s, &ln));
-        } else {
-            LAMP_CK(linear(sc.A, M, hdv, hdv, W, 1, d, hdv, nullptr, xq, d, 0, C, d, s));
-        }
-        if (defer_out) return 0;  // `out` holds the pre-norm rows; the next sub-layer's GEMMs apply this LayerNorm
+        LAMP_CK(linear(sc.A, M, hdv, hdv, W, 1, d, hdv, nullptr, xq, d, 0, C, d, s));
         return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, out, s);
     }
     return launch_layernorm(sc.A, M, d, w.ln_g, w.ln_b, 1e-5f, xq, r_mod, out, s);
@@ -297,42 +235,20 @@ static int project_kv_layers(const float* x, int64_t Me, int d, int dk, int dv, 
 // PositionwiseFeedForward.forward (lamp/SubLayers.py:133-142); out may alias x.
 static int ffn_core(const float* x, int64_t M, int d, int dff, const lamp_ffn_weights& w, float* out,
                     float* hidden, hipStream_t s, const float* w_out = nullptr, int n_labels = 0,
-                    float* logits = nullptr, const LnIn* in = nullptr, float* defer_part = nullptr) {
+                    float* logits = nullptr) {
     if (!w.w1 || !w.b1 || !w.w2 || !w.b2 || !w.ln_g || !w.ln_b) return LAMP_E_NULL;
-    const bool defer_out = defer_part != nullptr;  // leave pre-norm rows in `out`, their row partials in defer_part
-    if (in) {  // x is pre-norm: folded W1, LayerNorm'd residual recomputed in the second epilogue
-        if (!folded_ok(in->w1)) return LAMP_E_NULL;
-        const float* W[1] = {in->w1->w};
-        const float* b[1] = {in->w1->b};
+    {
+        const float* W[1] = {w.w1};
+        const float* b[1] = {w.b1};
         float* C[1] = {hidden};
-        LnGemm ln;
-        ln.s[0] = in->w1->s;
-        ln.a_part = in->part;
-        LAMP_CK(linear(x, M, d, d, W, 1, dff, d, b, nullptr, 0, 1, C, dff, s, &ln));
-        const float* W2[1] = {w.w2};
-        const float* b2[1] = {w.b2};
-        float* C2[1] = {out};
-        LnGemm lr;
-        lr.r_part = in->part; lr.r_g = in->g; lr.r_b = in->b;
-        lr.part_out = defer_part;
-        LAMP_CK(linear(hidden, M, dff, dff, W2, 1, d, dff, b2, x, d, 0, C2, d, s, &lr));
-    } else {
-        {
-            const float* W[1] = {w.w1};
-            const float* b[1] = {w.b1};
-            float* C[1] = {hidden};
-            LAMP_CK(linear(x, M, d, d, W, 1, dff, d, b, nullptr, 0, 1, C, dff, s));
-        }
-        {
-            const float* W[1] = {w.w2};
-            const float* b[1] = {w.b2};
-            float* C[1] = {out};
-            LnGemm lp;
-            lp.part_out = defer_part;
-            LAMP_CK(linear(hidden, M, dff, dff, W, 1, d, dff, b, x, d, 0, C, d, s, defer_out ? &lp : nullptr));
-        }
+        LAMP_CK(linear(x, M, d, d, W, 1, dff, d, b, nullptr, 0, 1, C, dff, s));
     }
-    if (defer_out) return 0;  // `out` holds the pre-norm rows
+    {
+        const float* W[1] = {w.w2};
+        const float* b[1] = {w.b2};
+        float* C[1] = {out};
+        LAMP_CK(linear(hidden, M, dff, dff, W, 1, d, dff, b, x, d, 0, C, d, s));
+    }
     // with w_out: the final decoder LayerNorm also produces the logits and its output row is not stored
     return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, w_out ? nullptr : out, s, w_out, n_labels,
                             logits);
@@ -398,28 +314,6 @@ int lamp_linear_fwd(const float* A, int64_t M, int32_t K, int64_t lda, const flo
     float* Cs[1] = {C};
     if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return LAMP_E_DIMS;
     return linear(A, M, K, lda, Ws, 1, N, ldw, bs, residual, ldr, relu, Cs, ldc, hipStream_t(stream));
-}
-
-int lamp_layernorm_fold(const float* W, int32_t N, int32_t K, const float* gamma, const float* beta, const float* bias,
-                        float* W_folded, float* s, float* bias_folded, lamp_stream_t stream) {
-    return launch_fold_layernorm(W, N, K, gamma, beta, bias, W_folded, s, bias_folded, hipStream_t(stream));
-}
-
-int lamp_linear_ln_fwd(const float* a, int64_t M, int32_t K, int64_t lda, const float* a_part, const float* W, int32_t N,
-                       int64_t ldw, const float* s, const float* bias, float eps, const float* residual, int64_t ldr,
-                       const float* r_part, const float* r_gamma, const float* r_beta, int32_t relu, float* C, int64_t ldc,
-                       float* part_out, lamp_stream_t stream) {
-    if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return LAMP_E_DIMS;
-    if ((s && !a_part) || (r_part && (!residual || !r_gamma || !r_beta))) return LAMP_E_NULL;
-    GemmParams p{};
-    p.A = a; p.lda = lda; p.M = M; p.K = K; p.N = N; p.nseg = 1; p.ldw = ldw; p.ldc = ldc;
-    p.R = residual; p.ldr = ldr; p.relu = relu;
-    p.W[0] = W; p.bias[0] = bias; p.C[0] = C;
-    p.ln_s[0] = s; p.ln_eps = eps;
-    p.a_part = a_part; p.a_nparts = ln_parts(K);
-    p.r_part = r_part; p.r_nparts = ln_parts(N); p.r_gamma = r_gamma; p.r_beta = r_beta;
-    p.part_out = part_out;
-    return launch_gemm(p, hipStream_t(stream));
 }
 
 int lamp_layernorm_fwd(const float* x, int64_t M, int32_t d, const float* gamma, const float* beta, float eps,
@@ -584,10 +478,9 @@ struct FwdPlan {
     size_t per_sample_floats;  // times micro-batch
     int R;                     // rows per sample of the widest activation
     int hdk, hdv;
-    size_t side_kv_floats;     // per sample; only carved in two-stream mode
+    size_t side_kv_floats;     // per sample; K/V of every decoder layer's enc-attention, projected in one launch
     size_t score_floats;       // per sample; (h, Rq, R) score scratch of wide heads, else 0
     size_t lse_floats;         // per sample; (h, Rq)
-    size_t stats_floats;       // per sample; 2 x (R, d_model / 64, 2)
 };
 
 static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
@@ -613,10 +506,7 @@ static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
     pl->per_sample_floats += pl->score_floats;
     pl->lse_floats = size_t(h) * Rq;  // row log-sum-exp of an attention whose maps are requested
     pl->per_sample_floats += pl->lse_floats;
-    // two ping-pong buffers of row partials (sum, sum of squares per 64-column tile) for deferred LayerNorm
-    pl->stats_floats = size_t(2) * R * 2 * ln_parts(m->d_model);
-    pl->per_sample_floats += pl->stats_floats;
-    // K/V of decoder layers >= 1, projected ahead on the side stream (lamp_set_forward_streams(2))
+    // K/V of all decoder layers' enc-attention, projected together right after the encoder when the batch fits
     pl->side_kv_floats = size_t(m->n_layers_dec) * T * (pl->hdk + pl->hdv);
     return 0;
 }
@@ -627,51 +517,17 @@ size_t lamp_forward_workspace_bytes(const lamp_model* m, int32_t micro_batch, in
     return (pl.fixed_floats + (pl.per_sample_floats + pl.side_kv_floats) * size_t(micro_batch)) * sizeof(float);
 }
 
-// Side stream for lamp_set_forward_streams(2): one per device, created on first use and kept (an
-// immutable handle, like the kernels' attributes); fork/join with the caller's stream through events.
-namespace {
-constexpr int MAX_SIDE_EVENTS = 16;
-struct SideState {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr;
-    hipEvent_t ready[MAX_SIDE_EVENTS] = {};
-};
-std::mutex g_side_mu;
-SideState g_side[64];
-int g_forward_streams = 1;
-
-int side_state(SideState** out) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return int(e);
-    if (dev < 0 || dev >= 64) return LAMP_E_UNSUPPORTED;
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    SideState& st = g_side[dev];
-    if (!st.stream) {
-        if ((e = hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking)) != hipSuccess) return int(e);
-        if ((e = hipEventCreateWithFlags(&st.fork, hipEventDisableTiming)) != hipSuccess) return int(e);
-        for (int i = 0; i < MAX_SIDE_EVENTS; ++i)
-            if ((e = hipEventCreateWithFlags(&st.ready[i], hipEventDisableTiming)) != hipSuccess) return int(e);
-    }
-    *out = &st;
-    return 0;
-}
-}  // namespace
-
-// The whole batch in micro-batches that fit `workspace`.  `side` (nullable) enables the two-stream mode:
-// encoder and the K/V projections of EVERY decoder layer (they depend only on the encoder output and are
-// throughput bound, M = B*T rows) run full-size on the caller's stream; then the two halves of the micro-batch
-// go through the decoder stack concurrently, one on the caller's stream and one on the side stream -- the
-// decoder's kernels work on only B*L rows and are latency bound, so two of them in flight fill each other's
-// launch gaps and tails.  Samples are independent and the kernels/variants do not depend on the batch size, so
-// results are bit-identical to the one-stream order.
+// The whole batch in micro-batches that fit `workspace`.  `kv_ahead`: the enc-attention K/V projections of EVERY
+// decoder layer (they depend only on the encoder output) are issued as one multi-segment launch right after the
+// encoder.  Samples are independent and no kernel variant depends on the batch size, so a sample's results are
+// bit-identical for every micro-batch split.
+constexpr int MAX_AHEAD_LAYERS = 16;
 static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* src_seq, const int64_t* src_pos,
                          int32_t B, int32_t T, float* logits, float* enc_output, const lamp_aux* aux,
-                         void* workspace, size_t workspace_bytes, hipStream_t s, SideState* side, bool kv_ahead) {
+                         void* workspace, size_t workspace_bytes, hipStream_t s, bool kv_ahead) {
     const bool want_enc_attn = aux && aux->enc_self_attn;
     const int d = m->d_model, dff = m->d_inner, dk = m->d_k, dv = m->d_v, L = m->n_labels;
-    // layers whose enc K/V are projected (together) before the decoder starts
-    const int n_ahead = (side || kv_ahead) ? m->n_layers_dec : 0;
+    const int n_ahead = kv_ahead ? m->n_layers_dec : 0;
     const size_t per_sample = pl.per_sample_floats + (n_ahead ? pl.side_kv_floats : 0);
     const size_t ws_floats = workspace_bytes / sizeof(float);
     if (ws_floats < pl.fixed_floats + per_sample) return LAMP_E_WORKSPACE;
@@ -679,16 +535,9 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
     if (mb > B) mb = B;
 
     const int Rq = want_enc_attn ? pl.R : L;
-    float *H = nullptr, *Y = nullptr, *ln_stats = nullptr;
-    // Deferred LayerNorm (lamp_fused_ln): only without auxiliary outputs (intermediate predictions need the
-    // normalised states) and with an output projection in every attention block.
-    bool fused = m->fused_ln && !aux && m->fused_ln->dec && (m->n_layers_enc <= 1 || m->fused_ln->enc);
-    for (int i = 0; i < m->n_layers_dec && fused; ++i) {
-        const lamp_dec_layer& l = m->dec_layers[i];
-        if (l.enc_attn.n_head < 2 || (l.slf_attn.present && l.slf_attn.n_head < 2)) fused = false;
-    }
-    float* Kahead[MAX_SIDE_EVENTS] = {};
-    float* Vahead[MAX_SIDE_EVENTS] = {};
+    float *H = nullptr, *Y = nullptr;
+    float* Kahead[MAX_AHEAD_LAYERS] = {};
+    float* Vahead[MAX_AHEAD_LAYERS] = {};
     MhaScratch sc{};
     for (int attempt = 0; attempt < 2; ++attempt) {
         Carver c(workspace, workspace_bytes);
@@ -699,7 +548,6 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         sc.A = c.take(size_t(mb) * Rq * pl.hdv);
         sc.S = pl.score_floats ? c.take(size_t(mb) * pl.score_floats) : nullptr;
         sc.lse = c.take(size_t(mb) * pl.lse_floats);
-        ln_stats = c.take(size_t(mb) * pl.stats_floats);
         Y = c.take(size_t(mb) * L * d);
         for (int i = 0; i < n_ahead; ++i) {
             Kahead[i] = c.take(size_t(mb) * T * pl.hdk);
@@ -719,177 +567,70 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
 
         // ---- GraphEncoder.forward (lamp/Encoders.py:64-110) ----
         LAMP_CK(launch_embed(seq, pos, Me, m->src_word_emb, m->n_src_vocab, m->position_enc, m->n_position, d, x, s));
-        {
-            lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq, T, 0, nullptr, 0};
-            bool enc_pend = false;
-            const float *enc_pg = nullptr, *enc_pb = nullptr;
-            float* enc_part[2] = {ln_stats, ln_stats + size_t(mb) * pl.stats_floats / 2};  // ping-pong row partials
-            int enc_cur = 0;
-            for (int i = 0; i < m->n_layers_enc; ++i) {
-                const lamp_enc_layer& l = m->enc_layers[i];
-                if (want_enc_attn && aux->enc_self_attn[i]) {
-                    // lamp/Layers.py:16 -- only the attention map of this block is ever observable.  Maps are
-                    // (h*B, T, T) over the WHOLE batch: this micro-batch fills rows h*B + b0 + b.
-                    LAMP_CK(mha_core(x, false, x, nb, T, T, d, dk, dv, l.slf_attn, &pad_mask, nullptr,
-                                     aux->enc_self_attn[i], sc, s, false, nullptr, B, int(b0)));
-                }
-                // lamp/Layers.py:18.  With deferred LayerNorm a layer leaves its pre-norm rows in x when the next layer
-                // has folded weights for them; the last layer always normalises (enc_output is an output).
-                const bool last = i + 1 == m->n_layers_enc;
-                const bool defer = fused && !last && folded_ok(&m->fused_ln->enc[i + 1].w1);
-                LnIn in{enc_pg, enc_pb, enc_part[enc_cur]};
-                if (enc_pend) in.w1 = &m->fused_ln->enc[i].w1;
-                LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s, nullptr, 0, nullptr, enc_pend ? &in : nullptr,
-                                 defer ? enc_part[enc_cur ^ 1] : nullptr));
-                if (defer) enc_cur ^= 1;
-                enc_pend = defer;
-                enc_pg = l.pos_ffn.ln_g;
-                enc_pb = l.pos_ffn.ln_b;
+        lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq, T, 0, nullptr, 0};
+        for (int i = 0; i < m->n_layers_enc; ++i) {
+            const lamp_enc_layer& l = m->enc_layers[i];
+            if (want_enc_attn && aux->enc_self_attn[i]) {
+                // lamp/Layers.py:16 -- only the attention map of this block is ever observable.  Maps are
+                // (h*B, T, T) over the WHOLE batch: this micro-batch fills rows h*B + b0 + b.
+                LAMP_CK(mha_core(x, false, x, nb, T, T, d, dk, dv, l.slf_attn, &pad_mask, nullptr,
+                                 aux->enc_self_attn[i], sc, s, false, nullptr, B, int(b0)));
             }
+            LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s));  // lamp/Layers.py:18
         }
+        if (n_ahead > 0) LAMP_CK(project_kv_layers(x, Me, d, dk, dv, m->dec_layers, n_ahead, Kahead, Vahead, s));
 
-        // ---- GraphDecoder.forward (lamp/Decoders.py:127-163) for samples [r_lo, r_hi) of the micro-batch ----
-        auto decoder_range = [&](int r_lo, int r_hi, hipStream_t st) -> int {
-            const int nr = r_hi - r_lo;
-            if (nr <= 0) return 0;
-            const float* xr = x + int64_t(r_lo) * T * d;
-            float* Yr = Y + int64_t(r_lo) * L * d;
-            float* Hr = H + int64_t(r_lo) * pl.R * dff;
-            MhaScratch scr;
-            scr.Q = sc.Q + int64_t(r_lo) * Rq * pl.hdk;
-            scr.K = sc.K + int64_t(r_lo) * pl.R * pl.hdk;
-            scr.V = sc.V + int64_t(r_lo) * pl.R * pl.hdv;
-            scr.A = sc.A + int64_t(r_lo) * Rq * pl.hdv;
-            scr.S = sc.S ? sc.S + int64_t(r_lo) * pl.score_floats : nullptr;
-            scr.lse = sc.lse + int64_t(r_lo) * pl.lse_floats;
-            lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq + int64_t(r_lo) * T, T, 0, nullptr, 0};
-            // the label graph: bit-packed rows when the caller provides them (one dword per 32-key tile), else bytes
-            lamp_mask label_mask{LAMP_MASK_NONE, 0, nullptr, 0, 0, nullptr, 0};
-            if (m->label_mask_bits)
-                label_mask = lamp_mask{LAMP_MASK_BITS_U32, 0, m->label_mask_bits, 0, (L + 31) / 32, m->label_tiles,
-                                       (L + 31) / 32 + 1};
-            else if (m->label_mask)
-                label_mask = lamp_mask{LAMP_MASK_U8, 0, m->label_mask, 0, L, m->label_tiles, (L + 31) / 32 + 1};
-            const int64_t Md = int64_t(nr) * L;
-            int n_int = 0;
-            auto int_pred = [&](void) -> int {
-                if (aux && aux->int_preds && n_int < aux->n_int_preds && aux->int_preds[n_int])
-                    LAMP_CK(launch_diag(Yr, m->w_out, nr, L, d, aux->int_preds[n_int] + (b0 + r_lo) * L, st));
-                ++n_int;
-                return 0;
-            };
-            // deferred LayerNorm: `pend` = Yr holds PRE-norm rows of the sub-layer whose LayerNorm is (pg, pb)
-            bool pend = false;
-            const float *pg = nullptr, *pb = nullptr;
-            // ping-pong row partials of this range's label rows: a sub-layer reads its input's, writes its output's
-            const size_t half = size_t(mb) * pl.stats_floats / 2;
-            float* part[2] = {ln_stats + int64_t(r_lo) * (pl.stats_floats / 2), ln_stats + half + int64_t(r_lo) * (pl.stats_floats / 2)};
-            int cur = 0;
-            for (int i = 0; i < m->n_layers_dec; ++i) {
-                const lamp_dec_layer& l = m->dec_layers[i];
-                const lamp_fused_ln_dec_layer* fd = fused ? &m->fused_ln->dec[i] : nullptr;
-                const bool has_slf = l.slf_attn.present != 0;
-                float* Penc = (aux && aux->dec_enc_attn) ? aux->dec_enc_attn[i] : nullptr;
-                float* Pslf = (aux && aux->dec_self_attn) ? aux->dec_self_attn[i] : nullptr;
-                MhaScratch sci = scr;
-                const bool ahead = n_ahead > 0;
-                if (ahead) {
-                    sci.K = Kahead[i] + int64_t(r_lo) * T * pl.hdk;
-                    sci.V = Vahead[i] + int64_t(r_lo) * T * pl.hdv;
-                }
-                // input->label messages (lamp/Layers.py:35); layer 0's query is the label table itself (its LayerNorm
-                // kernel adds the shared residual, so it is never deferred)
-                if (i == 0) {
-                    LAMP_CK(mha_core(m->tgt_word_emb, true, xr, nr, L, T, d, dk, dv, l.enc_attn, &pad_mask, Yr, Penc,
-                                     sci, st, ahead, m->dec0_query, B, int(b0) + r_lo));
-                    pend = false;
-                } else {
-                    LnIn in{pg, pb, part[cur]};
-                    if (pend) in.q = &fd->enc_q;
-                    const bool defer = fused && folded_ok(&fd->ffn1_w1);
-                    LAMP_CK(mha_core(Yr, false, xr, nr, L, T, d, dk, dv, l.enc_attn, &pad_mask, Yr, Penc, sci, st, ahead, nullptr, B,
-                                     int(b0) + r_lo, pend ? &in : nullptr, defer ? part[cur ^ 1] : nullptr));
-                    if (defer) cur ^= 1;
-                    pend = defer;
-                    pg = l.enc_attn.ln_g;
-                    pb = l.enc_attn.ln_b;
-                }
-                {  // lamp/Layers.py:36
-                    LnIn in{pg, pb, part[cur]};
-                    if (pend) in.w1 = &fd->ffn1_w1;
-                    const bool next_ok = fused && (has_slf ? (folded_ok(&fd->slf_q) && folded_ok(&fd->slf_k) && folded_ok(&fd->slf_v))
-                                                           : folded_ok(&fd->ffn2_w1));
-                    LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn1, Yr, Hr, st, nullptr, 0, nullptr, pend ? &in : nullptr,
-                                     next_ok ? part[cur ^ 1] : nullptr));
-                    if (next_ok) cur ^= 1;
-                    pend = next_ok;
-                    pg = l.pos_ffn1.ln_g;
-                    pb = l.pos_ffn1.ln_b;
-                }
-                if (has_slf) {
-                    LAMP_CK(int_pred());  // dec_output_int, lamp/Decoders.py:149-151
-                    // label->label messages over the label graph (lamp/Layers.py:40)
-                    LnIn in{pg, pb, part[cur]};
-                    if (pend) {
-                        in.q = &fd->slf_q;
-                        in.k = &fd->slf_k;
-                        in.v = &fd->slf_v;
-                    }
-                    const bool defer = fused && folded_ok(&fd->ffn2_w1);
-                    LAMP_CK(mha_core(Yr, false, Yr, nr, L, L, d, dk, dv, l.slf_attn, &label_mask, Yr, Pslf, scr, st, false, nullptr,
-                                     B, int(b0) + r_lo, pend ? &in : nullptr, defer ? part[cur ^ 1] : nullptr));
-                    if (defer) cur ^= 1;
-                    pend = defer;
-                    pg = l.slf_attn.ln_g;
-                    pb = l.slf_attn.ln_b;
-                }
-                LnIn in2{pg, pb, part[cur]};
-                if (pend) in2.w1 = &fd->ffn2_w1;
-                if (i + 1 < m->n_layers_dec) {
-                    const bool defer = fused && folded_ok(&m->fused_ln->dec[i + 1].enc_q);
-                    LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn2, Yr, Hr, st, nullptr, 0, nullptr, pend ? &in2 : nullptr,
-                                     defer ? part[cur ^ 1] : nullptr));  // lamp/Layers.py:45
-                    LAMP_CK(int_pred());  // all but the last (lamp/Models.py:130)
-                    if (defer) cur ^= 1;
-                    pend = defer;
-                    pg = l.pos_ffn2.ln_g;
-                    pb = l.pos_ffn2.ln_b;
-                } else {
-                    // last layer: the read-out (lamp/Models.py:124-126) is fused into this LayerNorm
-                    LAMP_CK(ffn_core(Yr, Md, d, dff, l.pos_ffn2, Yr, Hr, st, m->w_out, L, logits + (b0 + r_lo) * L,
-                                     pend ? &in2 : nullptr, nullptr));
-                }
-            }
+        // ---- GraphDecoder.forward (lamp/Decoders.py:127-163) ----
+        // the label graph: bit-packed rows when the caller provides them (one dword per 32-key tile), else bytes
+        lamp_mask label_mask{LAMP_MASK_NONE, 0, nullptr, 0, 0, nullptr, 0};
+        if (m->label_mask_bits)
+            label_mask = lamp_mask{LAMP_MASK_BITS_U32, 0, m->label_mask_bits, 0, (L + 31) / 32, m->label_tiles,
+                                   (L + 31) / 32 + 1};
+        else if (m->label_mask)
+            label_mask = lamp_mask{LAMP_MASK_U8, 0, m->label_mask, 0, L, m->label_tiles, (L + 31) / 32 + 1};
+        const int64_t Md = int64_t(nb) * L;
+        int n_int = 0;
+        auto int_pred = [&](void) -> int {
+            if (aux && aux->int_preds && n_int < aux->n_int_preds && aux->int_preds[n_int])
+                LAMP_CK(launch_diag(Y, m->w_out, nb, L, d, aux->int_preds[n_int] + b0 * L, s));
+            ++n_int;
             return 0;
         };
-
-        if (n_ahead > 0 && side && nb >= 2) {
-            LAMP_CK(project_kv_layers(x, Me, d, dk, dv, m->dec_layers, n_ahead, Kahead, Vahead, s));
-            hipError_t e;
-            if ((e = hipEventRecord(side->fork, s)) != hipSuccess) return int(e);
-            if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return int(e);
-            const int mid = nb / 2;
-            const int rc_side = decoder_range(mid, nb, side->stream);
-            const hipError_t e1 = hipEventRecord(side->ready[0], side->stream);
-            const int rc_main = decoder_range(0, mid, s);
-            const hipError_t e2 = hipStreamWaitEvent(s, side->ready[0], 0);  // join, also on error
-            if (rc_side) return rc_side;
-            if (rc_main) return rc_main;
-            if (e1 != hipSuccess) return int(e1);
-            if (e2 != hipSuccess) return int(e2);
-        } else if (n_ahead > 0) {
-            LAMP_CK(project_kv_layers(x, Me, d, dk, dv, m->dec_layers, n_ahead, Kahead, Vahead, s));
-            LAMP_CK(decoder_range(0, nb, s));
-        } else {
-            LAMP_CK(decoder_range(0, nb, s));
+        for (int i = 0; i < m->n_layers_dec; ++i) {
+            const lamp_dec_layer& l = m->dec_layers[i];
+            const bool has_slf = l.slf_attn.present != 0;
+            float* Penc = (aux && aux->dec_enc_attn) ? aux->dec_enc_attn[i] : nullptr;
+            float* Pslf = (aux && aux->dec_self_attn) ? aux->dec_self_attn[i] : nullptr;
+            MhaScratch sci = sc;
+            const bool ahead = n_ahead > 0;
+            if (ahead) {
+                sci.K = Kahead[i];
+                sci.V = Vahead[i];
+            }
+            // input->label messages (lamp/Layers.py:35); layer 0's query is the label table itself (its LayerNorm
+            // kernel adds the shared residual)
+            if (i == 0)
+                LAMP_CK(mha_core(m->tgt_word_emb, true, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s,
+                                 ahead, m->dec0_query, B, int(b0)));
+            else
+                LAMP_CK(mha_core(Y, false, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s, ahead, nullptr,
+                                 B, int(b0)));
+            LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn1, Y, H, s));  // lamp/Layers.py:36
+            if (has_slf) {
+                LAMP_CK(int_pred());  // dec_output_int, lamp/Decoders.py:149-151
+                // label->label messages over the label graph (lamp/Layers.py:40)
+                LAMP_CK(mha_core(Y, false, Y, nb, L, L, d, dk, dv, l.slf_attn, &label_mask, Y, Pslf, sc, s, false, nullptr,
+                                 B, int(b0)));
+            }
+            if (i + 1 < m->n_layers_dec) {
+                LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn2, Y, H, s));  // lamp/Layers.py:45
+                LAMP_CK(int_pred());                                     // all but the last (lamp/Models.py:130)
+            } else {
+                // last layer: the read-out (lamp/Models.py:124-126) is fused into this LayerNorm
+                LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn2, Y, H, s, m->w_out, L, logits + b0 * L));
+            }
         }
     }
-    return 0;
-}
-
-int lamp_set_forward_streams(int32_t n) {
-    if (n < 1 || n > 2) return LAMP_E_UNSUPPORTED;
-    g_forward_streams = n;
     return 0;
 }
 
@@ -905,20 +646,12 @@ int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src
     FwdPlan pl;
     LAMP_CK(make_plan(m, T, aux && aux->enc_self_attn, &pl));
     if ((m->d_model & 3) || (m->d_inner & 3) || (m->d_k & 3) || (m->d_v & 3)) return LAMP_E_UNSUPPORTED;
-
-    SideState* side = nullptr;
-    if (g_forward_streams == 2 && B >= 2 && m->n_layers_dec <= MAX_SIDE_EVENTS) {
-        // only when the workspace holds at least one sample including the look-ahead K/V buffers
-        const size_t need = (pl.fixed_floats + pl.per_sample_floats + pl.side_kv_floats) * sizeof(float);
-        if (workspace_bytes >= need) LAMP_CK(side_state(&side));
-    }
     // One launch for every decoder layer's enc-attention K/V projection (they all read the finished encoder output)
     // when the whole batch still fits the workspace with the extra K/V buffers and the weights fit one segment list.
-    const bool kv_ahead = 2 * m->n_layers_dec <= GEMM_MAX_SEG && m->n_layers_dec > 1 && m->n_layers_dec <= MAX_SIDE_EVENTS &&
+    const bool kv_ahead = 2 * m->n_layers_dec <= GEMM_MAX_SEG && m->n_layers_dec > 1 && m->n_layers_dec <= MAX_AHEAD_LAYERS &&
                           workspace_bytes >= (pl.fixed_floats + (pl.per_sample_floats + pl.side_kv_floats) * size_t(B) +
                                               size_t(64) * (8 + 2 * m->n_layers_dec)) * sizeof(float);
-    return forward_range(m, pl, src_seq, src_pos, B, T, logits, enc_output, aux, workspace, workspace_bytes, s, side,
-                         kv_ahead);
+    return forward_range(m, pl, src_seq, src_pos, B, T, logits, enc_output, aux, workspace, workspace_bytes, s, kv_ahead);
 }
 
 // ------------------------------------------------------------------ profiling ABI

@@ -386,14 +386,9 @@ static int launch_attn_mk(const AttnParams& p, hipStream_t s) {
     constexpr size_t lds_c = KSPLIT > 1 ? size_t(4) * (DP + 2) * 32 * sizeof(float) : 0;
     constexpr size_t lds = lds_q > lds_c ? lds_q : lds_c;
     auto kern = attn_kernel<DP, KSPLIT, PM, MK>;
-    static bool attr_done[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (lds > 65536 && dev >= 0 && dev < 64 && !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (e != hipSuccess) return int(e);
-        attr_done[dev] = true;
+    if constexpr (lds > 65536) {
+        static AttrOnce once;
+        if (int e = once.set(reinterpret_cast<const void*>(kern), lds)) return e;
     }
     const int64_t nwg = int64_t((p.lq + 32 * QB - 1) / (32 * QB)) * p.H * p.B;
     if (nwg > 0x7fffffffLL) return LAMP_E_DIMS;
@@ -431,9 +426,13 @@ __global__ __launch_bounds__(256) void softmax_from_scores_kernel(float* __restr
     for (int c = lane; c < lk; c += 64) p[c] = __builtin_amdgcn_exp2f(p[c] - l);
 }
 
-// Debug/tuning hook (not part of the ABI header): 0 = heuristic, 1/2/4 = force that key split.
+#ifdef LAMP_TUNING
+// Tuning build only (liblamp_hip_tuning.so): 0 = heuristic, 1/2/4 = force that key split.
 static int g_force_attn = 0;
 extern "C" void lamp_debug_force_attn(int v) { g_force_attn = v; }
+#else
+constexpr int g_force_attn = 0;
+#endif
 
 int launch_attn(const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.H <= 0 || p.lq <= 0 || p.lk <= 0 || p.dk <= 0 || p.dv <= 0) return LAMP_E_DIMS;
@@ -466,7 +465,9 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = (p.lq <= 128 && nt >= 3) ? 2 : 1;
     if (ksplit == 4 && p.lse) ksplit = 2;
     int rc;
-    if (dmax <= 32)
+    if (attn_small_applies(p))   // at most 256 queries: 16-query blocks on 16x16x4 (attention_small.hip)
+        rc = launch_attn_small(p, g_force_attn, s);
+    else if (dmax <= 32)
         rc = launch_attn_dp<32>(p, ksplit, s);
     else if (dmax <= 64)
         rc = launch_attn_dp<64>(p, ksplit, s);

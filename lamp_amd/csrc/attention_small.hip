@@ -1,0 +1,328 @@
+// Fused masked attention for SMALL label / token counts (lq <= 256: reuters' 90 and bibtex's 159 labels), exact
+// fp32 on v_mfma_f32_16x16x4_f32.  Same mathematics, masks and NaN behaviour as attention.hip (which keeps the large
+// shapes: 32-query blocks on 32x32x2 are the better tile once a (sample, head) alone fills the chip).
+//
+// Why a second kernel.  With 90 queries the 32-row kernel has 3 query blocks per (sample, head) -- at batch 32 x 4
+// heads 384 blocks x 2 key halves = 768 waves of ~20 us for 1024 SIMDs: a quarter of the chip idle, the rest running
+// ONE wave per SIMD with nothing to cover its softmax and load latencies (round 1: 0.26 of the fp32-MFMA peak).
+// Here the unit is a 16-query x 16-key block (64 MFMAs of 32 cycles = 2048 cycles at d_k = d_v = 128):
+//   * a wave owns ONE 16-query block and a share of its key tiles; a workgroup = 4 waves = QB query blocks x KSPLIT
+//     key shares (merged lane-locally through LDS at the end).  reuters enc-dec (90 x 302): 768 workgroups, 3072 waves
+//     of 4-5 tiles -- three waves per SIMD, so one wave's exp2 / loads overlap another's MFMAs.
+//   * Q never touches LDS: with 16x16x4 the B operand of S^T = K Q^T is 32 registers per lane at d_k = 128 (the 32x32x2
+//     layout would need 64), loaded once, pre-scaled by log2(e)/temperature.
+//   * both products are TRANSPOSED as in attention.hip, so the query sits on the lane (column = lane & 15) in both
+//     accumulators and register r of S^T (key 4*(lane>>4) + r) is directly the B operand of PV step r.
+//   * row statistics: a lane sees 4 of a tile's 16 keys.  The running maximum must agree across the four lane groups of
+//     a query (they feed one PV product), so it is exchanged across groups -- but only inside the lazy-rescale branch
+//     (first tile, or a tile maximum 2^32 above the running one); the row SUM stays a per-lane partial until the end.
+// Variant (KSPLIT) and kernel choice depend on the per-sample shape only, never on the batch: a sample's bits do not
+// depend on the batch it is in.
+#include "lamp_kernels.h"
+
+namespace lamp {
+
+namespace {
+__device__ __forceinline__ float group_max(float v) {  // max over the 4 lane groups (lanes l, l^16, l^32, l^48)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+}  // namespace
+
+// PM = 0: O only.  PM = 2: additionally the scaled scores (log2 domain, -inf where blocked) into the map buffer and each
+// row's log2-sum-exp into lse; softmax_from_scores_kernel (attention.hip) then normalises in place.
+template <int DP, int KSPLIT, int PM, int MK>
+__global__ __launch_bounds__(256) void attn16_kernel(AttnParams p) {
+    constexpr int DKC = DP / 16;   // 16-wide k chunks of the QK^T product (one b128 fragment each)
+    constexpr int DV8 = DP / 16;   // floats of a V row per lane = number of 16-row blocks of O^T
+    constexpr int QB = 4 / KSPLIT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int qb = wave / KSPLIT, ks = wave % KSPLIT;
+    const int nqg = (p.lq + 16 * QB - 1) / (16 * QB);
+    const int item = xcd_remap(blockIdx.x, gridDim.x);  // the query groups of one (sample, head) stay on one XCD
+    const int qgrp = item % nqg;
+    const int bh = item / nqg;
+    const int h = bh % p.H, b = bh / p.H;
+    const int q0 = (qgrp * QB + qb) * 16;
+    const int qi = q0 + l15;
+    const bool wave_active = q0 < p.lq;
+    const int qc = qi < p.lq ? qi : p.lq - 1;
+
+    const int q_r = int(p.lay.q_r), k_r = int(p.lay.k_r), v_r = int(p.lay.v_r);
+    const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q + int64_t(b) * p.lay.q_b + int64_t(h) * p.lay.q_h,
+                                                 (uint64_t(p.lq - 1) * q_r + p.dk) * 4u);
+    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K + int64_t(b) * p.lay.k_b + int64_t(h) * p.lay.k_h,
+                                                 (uint64_t(p.lk - 1) * k_r + p.dk) * 4u);
+    const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.V + int64_t(b) * p.lay.v_b + int64_t(h) * p.lay.v_h,
+                                                 (uint64_t(p.lk - 1) * v_r + p.dv) * 4u);
+    const __amdgpu_buffer_rsrc_t rsM =
+        MK == LAMP_MASK_BITS_U32
+            ? make_rsrc(static_cast<const unsigned*>(p.mask) + int64_t(b) * p.m_sb,
+                        (uint64_t(p.lq - 1) * uint64_t(p.m_sq) + (p.lk + 31) / 32) * 4u)
+        : MK == LAMP_MASK_U8
+            ? make_rsrc(static_cast<const unsigned char*>(p.mask) + int64_t(b) * p.m_sb,
+                        uint64_t(p.lq - 1) * uint64_t(p.m_sq) + p.lk)
+        : MK == LAMP_MASK_KEY_TOKENS_I64
+            ? make_rsrc(static_cast<const long long*>(p.mask) + int64_t(b) * p.m_sb, uint64_t(p.lk) * 8u)
+            : make_rsrc(p.K, 0);
+
+    // ---- Q fragments: lane (query l15, group g) holds Q[q][16c + 4g + j], pre-scaled ----
+    float4 qf[DKC];
+#pragma unroll
+    for (int c = 0; c < DKC; ++c) {
+        const int col = 16 * c + 4 * g;
+        const float4 v = bload4(rsQ, (qi < p.lq && col < p.dk) ? unsigned(qi * q_r + col) * 4u : OOB, 0);
+        qf[c] = make_float4(v.x * p.scale_log2e, v.y * p.scale_log2e, v.z * p.scale_log2e, v.w * p.scale_log2e);
+    }
+
+    const int nt = (p.lk + 15) / 16;
+    float4 kf[DKC];
+    float vf[4][DV8];      // V[kt*16 + 4g + r][DV8*l15 + e]: block e of O^T holds the dv columns {DV8*i + e}
+    unsigned mbits = 0;    // bit r = key (kt*16 + 4g + r) is blocked for this lane's query (one tile ahead)
+
+    auto load_k = [&](int kt) {
+        const unsigned base = unsigned((kt * 16 + l15) * k_r + 4 * g) * 4u;
+#pragma unroll
+        for (int c = 0; c < DKC; ++c)
+            kf[c] = bload4(rsK, (kt < nt && 16 * c + 4 * g < p.dk) ? base + unsigned(c) * 64u : OOB, 0);
+    };
+    auto load_v = [&](int kt) {
+        const bool col_ok = kt < nt && DV8 * l15 < p.dv;  // d_v is a multiple of DV8 (attn_small_applies): all-or-nothing
+        const unsigned base = unsigned((kt * 16 + 4 * g) * v_r + DV8 * l15) * 4u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned off = col_ok ? base + unsigned(r * v_r) * 4u : OOB;
+            if constexpr (DV8 == 8) {
+                const float4 a = bload4(rsV, off, 0), c2 = bload4(rsV, off == OOB ? OOB : off + 16u, 0);
+                vf[r][0] = a.x; vf[r][1] = a.y; vf[r][2] = a.z; vf[r][3] = a.w;
+                vf[r][4] = c2.x; vf[r][5] = c2.y; vf[r][6] = c2.z; vf[r][7] = c2.w;
+            } else if constexpr (DV8 == 4) {
+                const float4 a = bload4(rsV, off, 0);
+                vf[r][0] = a.x; vf[r][1] = a.y; vf[r][2] = a.z; vf[r][3] = a.w;
+            } else {
+                const f32x2 a = bload2(rsV, off);
+                vf[r][0] = a.x; vf[r][1] = a.y;
+            }
+        }
+    };
+    auto load_mask = [&](int kt) {
+        const int kbase = kt * 16 + 4 * g;
+        if constexpr (MK == LAMP_MASK_BITS_U32) {
+            const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(
+                rsM, kt < nt ? unsigned(int64_t(qc) * p.m_sq + (kt >> 1)) * 4u : OOB, 0, 0);
+            mbits = (w >> ((kt & 1) * 16 + 4 * g)) & 0xFu;
+        } else if constexpr (MK == LAMP_MASK_U8) {
+            const unsigned mo = unsigned(int64_t(qc) * p.m_sq) + unsigned(kbase);
+            unsigned m = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m |= (bload_u8(rsM, kt < nt ? mo + r : OOB) != 0 ? 1u : 0u) << r;
+            mbits = m;
+        } else if constexpr (MK == LAMP_MASK_KEY_TOKENS_I64) {
+            unsigned m = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)  // past lk: reads 0 == PAD == blocked (forced to -inf below anyway)
+                m |= (bload_u64(rsM, unsigned(kbase + r) * 8u) == 0 ? 1u : 0u) << r;
+            mbits = m;
+        }
+    };
+    // S^T = K Q^T for the tile in kf (two accumulator chains, summed: the dependent-issue latency of the 16x16x4 MFMA
+    // is 40 cycles against 32 of issue), then -inf where blocked / past lk.
+    auto scores = [&](int kt, f32x4& s) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < DKC; c += 2) {
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].x, qf[c].x, s0, 0, 0, 0);
+            if (c + 1 < DKC) s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].x, qf[c + 1].x, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].y, qf[c].y, s0, 0, 0, 0);
+            if (c + 1 < DKC) s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].y, qf[c + 1].y, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].z, qf[c].z, s0, 0, 0, 0);
+            if (c + 1 < DKC) s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].z, qf[c + 1].z, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].w, qf[c].w, s0, 0, 0, 0);
+            if (c + 1 < DKC) s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].w, qf[c + 1].w, s1, 0, 0, 0);
+        }
+        const int kbase = kt * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = s0[r] + s1[r];
+            const bool blk = (MK != LAMP_MASK_NONE && ((mbits >> r) & 1u)) || kbase + r >= p.lk;
+            s[r] = blk ? -INFINITY : v;
+        }
+    };
+
+    f32x4 o[DV8];
+#pragma unroll
+    for (int e = 0; e < DV8; ++e) o[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_part = 0.f;   // m_run: this query's running maximum (equal in its 4 lane groups)
+    constexpr float RESCALE_THR = 32.0f;
+
+    if (wave_active && ks < nt) {
+        int kt = ks;
+        load_k(kt);
+        load_mask(kt);
+        load_v(kt);
+        for (; kt < nt; kt += KSPLIT) {
+            const int kn = kt + KSPLIT;   // past the end: range-checked zeros
+            f32x4 s;
+            scores(kt, s);
+            load_k(kn);      // flies under softmax + PV
+            load_mask(kn);
+            if constexpr (PM == 2) {
+                float* Srow = p.P + (int64_t(h) * p.P_batch + p.P_b0 + b) * int64_t(p.lq) * p.lk + int64_t(qi) * p.lk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * g + r;
+                    if (qi < p.lq && key < p.lk) Srow[key] = s[r];
+                }
+            }
+            const float tmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+            if (__any(tmax > m_run + RESCALE_THR)) {
+                const float m_new = fmaxf(m_run, group_max(tmax));
+                const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
+                l_part *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int e = 0; e < DV8; ++e)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[e][r] *= alpha;
+            }
+            const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
+            l_part += (s[0] + s[1]) + (s[2] + s[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < DV8; ++e)
+                    o[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r][e], s[r], o[e], 0, 0, 0);
+            load_v(kn);      // flies under the next QK^T
+        }
+    }
+
+    if constexpr (KSPLIT > 1) {
+        // ---- merge the KSPLIT partial results of each query block (lane-local positions, fixed order) ----
+        constexpr int CW = (DV8 * 4 + 2) * 64;  // floats per wave: o registers, m, l -- one 64-float row each
+        float* mine = smem + wave * CW;
+#pragma unroll
+        for (int e = 0; e < DV8; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(e * 4 + r) * 64 + lane] = o[e][r];
+        mine[(DV8 * 4) * 64 + lane] = m_run;
+        mine[(DV8 * 4 + 1) * 64 + lane] = l_part;
+        __syncthreads();
+        if (ks == 0 && wave_active) {
+            float m_all = m_run;
+#pragma unroll
+            for (int s2 = 1; s2 < KSPLIT; ++s2) m_all = fmaxf(m_all, smem[(wave + s2) * CW + (DV8 * 4) * 64 + lane]);
+            const float m_use = (m_all == -INFINITY) ? 0.f : m_all;
+            const float w0 = exp2f(m_run - m_use);
+            l_part *= w0;
+#pragma unroll
+            for (int e = 0; e < DV8; ++e)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[e][r] *= w0;
+#pragma unroll
+            for (int s2 = 1; s2 < KSPLIT; ++s2) {
+                const float* other = smem + (wave + s2) * CW;
+                const float ws = exp2f(other[(DV8 * 4) * 64 + lane] - m_use);
+                l_part = fmaf(other[(DV8 * 4 + 1) * 64 + lane], ws, l_part);  // explicit fma: same bits in every variant
+#pragma unroll
+                for (int e = 0; e < DV8; ++e)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[e][r] = fmaf(other[(e * 4 + r) * 64 + lane], ws, o[e][r]);
+            }
+            m_run = m_all;
+        }
+    }
+    if (!(wave_active && ks == 0)) return;
+    const float l_run = group_sum(l_part);   // the four lane groups of a query hold disjoint keys
+    if constexpr (PM == 2) {
+        // row log2-sum-exp of the scaled scores: probabilities = exp2(score - lse).  A fully blocked row has
+        // l = 0 -> lse = -inf -> exp2(-inf - -inf) = NaN, as the reference's softmax gives.
+        if (g == 0 && qi < p.lq)
+            p.lse[(int64_t(h) * p.B + b) * int64_t(p.lq) + qi] = ((m_run == -INFINITY) ? 0.f : m_run) + log2f(l_run);
+    }
+    const float inv_l = 1.0f / l_run;   // l = 0 (fully blocked row): 0 * inf = NaN, like torch
+
+    // ---- store: lane (query, g), register r, block e  <->  O[query][DV8*(4g + r) + e] ----
+    if (qi < p.lq) {
+        float* Orow = p.O + int64_t(b) * p.lay.o_b + int64_t(h) * p.lay.o_h + int64_t(qi) * p.lay.o_r;
+        const bool vec = ((p.lay.o_b | p.lay.o_h | p.lay.o_r) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.O) & 15u) == 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = DV8 * (4 * g + r);
+            if (col >= p.dv) continue;
+            if (DV8 >= 4 && vec) {
+#pragma unroll
+                for (int e = 0; e < DV8; e += 4)
+                    *reinterpret_cast<float4*>(Orow + col + e) =
+                        make_float4(o[e][r] * inv_l, o[e + 1 < DV8 ? e + 1 : e][r] * inv_l,
+                                    o[e + 2 < DV8 ? e + 2 : e][r] * inv_l, o[e + 3 < DV8 ? e + 3 : e][r] * inv_l);
+            } else {
+#pragma unroll
+                for (int e = 0; e < DV8; ++e) Orow[col + e] = o[e][r] * inv_l;
+            }
+        }
+    }
+}
+
+template <int DP, int KSPLIT, int PM, int MK>
+static int launch_small_mk(const AttnParams& p, hipStream_t s) {
+    constexpr int QB = 4 / KSPLIT;
+    constexpr size_t lds = KSPLIT > 1 ? size_t(4) * (DP / 16 * 4 + 2) * 64 * sizeof(float) : 0;
+    static_assert(lds <= 65536, "merge scratch fits the default LDS limit");
+    const int64_t nwg = int64_t((p.lq + 16 * QB - 1) / (16 * QB)) * p.H * p.B;
+    if (nwg > 0x7fffffffLL) return LAMP_E_DIMS;
+    hipLaunchKernelGGL((attn16_kernel<DP, KSPLIT, PM, MK>), dim3(unsigned(nwg)), dim3(256), lds, s, p);
+    return int(hipGetLastError());
+}
+
+template <int DP, int KSPLIT, int PM>
+static int launch_small_ks(const AttnParams& p, hipStream_t s) {
+    switch (p.mask_kind) {
+        case LAMP_MASK_U8: return launch_small_mk<DP, KSPLIT, PM, LAMP_MASK_U8>(p, s);
+        case LAMP_MASK_KEY_TOKENS_I64: return launch_small_mk<DP, KSPLIT, PM, LAMP_MASK_KEY_TOKENS_I64>(p, s);
+        case LAMP_MASK_BITS_U32: return launch_small_mk<DP, KSPLIT, PM, LAMP_MASK_BITS_U32>(p, s);
+        default: return launch_small_mk<DP, KSPLIT, PM, LAMP_MASK_NONE>(p, s);
+    }
+}
+
+template <int DP>
+static int launch_small_dp(const AttnParams& p, int ksplit, hipStream_t s) {
+    if (p.lse) {
+        if (ksplit == 4) return launch_small_ks<DP, 4, 2>(p, s);
+        return ksplit == 2 ? launch_small_ks<DP, 2, 2>(p, s) : launch_small_ks<DP, 1, 2>(p, s);
+    }
+    if (ksplit == 4) return launch_small_ks<DP, 4, 0>(p, s);
+    return ksplit == 2 ? launch_small_ks<DP, 2, 0>(p, s) : launch_small_ks<DP, 1, 0>(p, s);
+}
+
+// The shapes this kernel takes (a function of the per-sample shape ONLY): at most 256 queries, with V and O given and
+// either no maps or the single-pass map write-out.  The exact two-pass maps and map-only calls stay in attention.hip.
+bool attn_small_applies(const AttnParams& p) {
+    const int dmax = p.dk > p.dv ? p.dk : p.dv;
+    // a lane reads DP/16 consecutive floats of a V row: d_v must be a whole number of them (8 for 64 < d <= 128)
+    return p.lq <= 256 && p.V && p.O && (!p.P || p.lse) && dmax <= 128 && (dmax <= 64 || (p.dv & 7) == 0);
+}
+
+// force_ksplit: 0 = heuristic (tuning build may force 1 / 2 / 4).
+int launch_attn_small(const AttnParams& p, int force_ksplit, hipStream_t s) {
+    const int nt = (p.lk + 15) / 16;
+    // 16-key tiles per wave: 4-way split from 8 tiles on, 2-way from 4 (reuters enc-dec 19 tiles -> 4; its 90-label
+    // self-attention 6 -> 2; bibtex 10 / 7 -> 4 / 2)
+    int ksplit = force_ksplit;
+    if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = nt >= 8 ? 4 : (nt >= 4 ? 2 : 1);
+    const int dmax = p.dk > p.dv ? p.dk : p.dv;
+    if (dmax <= 32) return launch_small_dp<32>(p, ksplit, s);
+    if (dmax <= 64) return launch_small_dp<64>(p, ksplit, s);
+    return launch_small_dp<128>(p, ksplit, s);
+}
+
+}  // namespace lamp

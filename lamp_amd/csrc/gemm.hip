@@ -47,18 +47,13 @@ struct GemmTile {
     static_assert(BK % 8 == 0, "BK must be a multiple of 8");
 };
 
-// LNM (deferred LayerNorm, production tiles only; 0 = plain GEMM, identical code to before):
-//   bit 0  A holds pre-LayerNorm rows: (mean, rstd) from their partial sums, applied in the epilogue with folded weights
-//   bit 1  R holds pre-LayerNorm rows: the residual is LayerNorm(R), recomputed from R and its rows' statistics
-//   bit 2  the epilogue also writes per row and 16-column group the partial (sum, sum of squares) of the output
-// Nothing is added to the main loop.  Summation orders are fixed and independent of the tile configuration (16-column
-// butterflies, then groups in ascending column order), so a sample's bits still do not
-// depend on the batch it is in.
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, int LNM = 0>
+// RPRE: the epilogue's bias and residual values are fetched BEFORE the main loop (their round trip to L2 / the
+// Infinity Cache then hides under the MFMAs instead of standing between the last k-step and the stores).  Used by the
+// small tiles, whose accumulators -- hence the prefetched values -- are few registers; the large tiles amortise the
+// round trip over 8-16x more matrix work per wave and keep the registers for occupancy.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
-                                                                          int tiles_n) {
-    constexpr bool LN = (LNM & 1) != 0, LNR = (LNM & 2) != 0, PS = (LNM & 4) != 0;
-    static_assert(LNM == 0 || (MF == 16 && BN == 64), "deferred LayerNorm: 16x16x4 tiles with 64 columns");
+                                                                          int tiles_n, int tiles_m) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
     // lane -> (row within an MFMA block, which group of 4 consecutive k this lane's b128 read covers)
     constexpr int KQ = 64 / MF;             // 2 for 32x32x2, 4 for 16x16x4
@@ -70,7 +65,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;               // [2][BM][S]
     float* Bs = smem + 2 * BM * S;  // [2][BN][S]
-    float* ln_lds = smem + 2 * (BM + BN) * S;  // deferred LayerNorm: [BM][4] = (A mean, A rstd, R mean, R rstd)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -78,9 +72,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & (MF - 1), hi = lane / MF;  // row-in-block, k-group
 
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = tile / tiles_n;
-    const int tn_all = tile - tm * tiles_n;
+#ifdef LAMP_TUNING
+    const unsigned long long t_entry = p.trace ? wall_clock64() : 0ull;
+#endif
+    // Work-item order.  (1) xcd_remap: every XCD (workgroup b runs on XCD b % 8) gets a CONTIGUOUS range of items, so
+    // neighbours in item order share one 4 MiB L2.  (2) Inside that order the tiles are walked in groups of GROUP_M
+    // row-panels, column-panel by column-panel: the ~32-64 tiles an XCD has in flight then cover GROUP_M row-panels of
+    // A x a few column-panels of W (a working set of 2-3 MiB at K = 512), so A is fetched about once and W about once
+    // per group -- instead of the whole W once per ROW-PANEL, which is what the plain row-major walk cost as soon as W
+    // alone filled the L2 (K/V projection of reuters: 291 MB fetched for 24 MB of compulsory traffic, round 1).
+    // Placement only: every output element is computed by exactly one tile with a k-order fixed by (K, BK).
+    constexpr int GROUP_M = 8;
+    const int item = xcd_remap(blockIdx.x, gridDim.x);
+    const int group_sz = GROUP_M * tiles_n;
+    const int grp = item / group_sz;
+    const int in_grp = item - grp * group_sz;
+    const int first_m = grp * GROUP_M;
+    const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+    const int tn_all = in_grp / gm;
+    const int tm = first_m + (in_grp - tn_all * gm);
     const int seg = tn_all / tiles_n_seg;
     const int tn = tn_all - seg * tiles_n_seg;
     const int64_t m0 = int64_t(tm) * BM;
@@ -188,37 +198,45 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
 
     const int nk = (p.K + BK - 1) / BK;
     gload(0, ra0, rb0);
+
+    // Epilogue operands.  C/D layouts: 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16;
+    //                                  16x16 block: col = lane&15, row = 4*(lane>>4) + r,            r < 4.
+    // Stores to rows past M fall outside the descriptor and are dropped by the hardware; columns past N are steered
+    // to an out-of-range offset.
+    const int ldc = int(p.ldc), ldr = int(p.ldr);
+    const bool has_r = p.R != nullptr;
+    const __amdgpu_buffer_rsrc_t rsR =
+        make_rsrc(has_r ? p.R + m0 * p.ldr + n0 : p.A, has_r ? (uint64_t(rows_m - 1) * ldr + rows_n) * 4u : 0);
+    const float* bias = p.bias[seg];
+    const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias ? bias + n0 : p.A, bias ? uint64_t(rows_n) * 4u : 0);
+    auto blk_row = [&](int r) { return MF == 32 ? (r & 3) + 8 * (r >> 2) : r; };
+    const int lrow0 = wm * T::WTM + 4 * hi;
+    const int lcol0 = wn * T::WTN + l31;
+    constexpr int NPRE = RPRE ? T::MI * T::NI * NACC : 1;
+    float pre_r[NPRE], pre_b[RPRE ? T::NI : 1];
+    if constexpr (RPRE) {
+#pragma unroll
+        for (int j = 0; j < T::NI; ++j) {
+            const int lcol = lcol0 + j * MF;
+            const bool col_ok = lcol < rows_n;
+            pre_b[j] = bload1(rsBias, col_ok ? unsigned(lcol) * 4u : OOB);
+#pragma unroll
+            for (int i = 0; i < T::MI; ++i)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) {
+                    const int lrow = lrow0 + i * MF + blk_row(r);
+                    pre_r[(j * T::MI + i) * NACC + r] = bload1(rsR, col_ok ? unsigned(lrow * ldr + lcol) * 4u : OOB);
+                }
+        }
+    }
+
     lstore(0, ra0, rb0);
     if (nk > 1) gload(BK, ra0, rb0);      // tile 1 -> set 0
     if (nk > 2) gload(2 * BK, ra1, rb1);  // tile 2 -> set 1
-    // Deferred LayerNorm, consumer side: the rows' 16-column partial sums are LOADED here, together with the first tiles
-    // (16 lanes per row; lane l takes partials l, l + 16, ...), and reduced only after the main loop, so their latency
-    // hides under the MFMAs.
-    constexpr int LN_ROWS = (LN && LNR ? 2 : 1) * BM;   // A rows, then R rows
-    constexpr int LN_IT = (LN || LNR) ? (LN_ROWS * 16 + T::NT - 1) / T::NT : 1;
-    constexpr int LN_NP = 4;                             // partials per lane: up to 64 groups = d <= 1024
-    float lpa[LN_IT][LN_NP], lpb[LN_IT][LN_NP];
-    if constexpr (LN || LNR) {
-        const int sub = tid & 15;
-#pragma unroll
-        for (int it = 0; it < LN_IT; ++it) {
-            const int row = (tid >> 4) + it * (T::NT / 16);
-            const bool for_r = LNR && (!LN || row >= BM);
-            const int lr = row >= BM ? row - BM : row;
-            const float* part = for_r ? p.r_part : p.a_part;
-            const int np = for_r ? p.r_nparts : p.a_nparts;
-            const bool row_ok = row < LN_ROWS && lr < rows_m;
-            const float* q = part + (m0 + (row_ok ? lr : 0)) * int64_t(np) * 2;
-#pragma unroll
-            for (int u = 0; u < LN_NP; ++u) {
-                const int t2 = sub + 16 * u;
-                const bool ok = row_ok && t2 < np;
-                lpa[it][u] = ok ? q[2 * t2] : 0.f;
-                lpb[it][u] = ok ? q[2 * t2 + 1] : 0.f;
-            }
-        }
-    }
     __syncthreads();
+#ifdef LAMP_TUNING
+    const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
+#endif
 
     for (int kt = 0; kt < nk; kt += 2) {
         // even step: tile kt in LDS[0]; tile kt+1 in set 0, tile kt+2 in set 1
@@ -233,122 +251,64 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         if (kt + 4 < nk) gload((kt + 4) * BK, ra1, rb1);
         __syncthreads();
     }
+#ifdef LAMP_TUNING
+    const unsigned long long t_epi = p.trace ? wall_clock64() : 0ull;
+#endif
 
-    if constexpr (LN || LNR) {
-        // reduce the partials loaded before the main loop: ascending within a lane, then a DPP row sum (an order that
-        // depends on neither this kernel's nor the producer's tile configuration); (mean, rstd) -> LDS for the epilogue
-        const int sub = tid & 15;
-#pragma unroll
-        for (int it = 0; it < LN_IT; ++it) {
-            const int row = (tid >> 4) + it * (T::NT / 16);
-            const bool for_r = LNR && (!LN || row >= BM);
-            const int lr = row >= BM ? row - BM : row;
-            float a = ((lpa[it][0] + lpa[it][1]) + lpa[it][2]) + lpa[it][3];
-            float b = ((lpb[it][0] + lpb[it][1]) + lpb[it][2]) + lpb[it][3];
-            a = row16_sum(a);
-            b = row16_sum(b);
-            if (sub == 0 && row < LN_ROWS) {
-                const float inv_n = 1.0f / float(for_r ? p.N : p.K);
-                const float mean = a * inv_n;
-                const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, b * inv_n), 0.f) + p.ln_eps);
-                ln_lds[4 * lr + (for_r ? 2 : 0)] = mean;
-                ln_lds[4 * lr + (for_r ? 3 : 1)] = rstd;
-            }
-        }
-        __syncthreads();
-    }
-
-    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Stores to rows past M fall outside the descriptor and are dropped by the hardware; columns past
-    // N are steered to an out-of-range offset.
-    const int ldc = int(p.ldc), ldr = int(p.ldr);
     const __amdgpu_buffer_rsrc_t rsC =
         make_rsrc(p.C[seg] + m0 * p.ldc + n0, (uint64_t(rows_m - 1) * ldc + rows_n) * 4u);
-    const bool has_r = p.R != nullptr;
-    const __amdgpu_buffer_rsrc_t rsR =
-        make_rsrc(has_r ? p.R + m0 * p.ldr + n0 : p.A, has_r ? (uint64_t(rows_m - 1) * ldr + rows_n) * 4u : 0);
-    const float* bias = p.bias[seg];
-    const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias ? bias + n0 : p.A, bias ? uint64_t(rows_n) * 4u : 0);
-    const float* lns = LN ? p.ln_s[seg] : nullptr;
-    const __amdgpu_buffer_rsrc_t rsS = make_rsrc(lns ? lns + n0 : p.A, lns ? uint64_t(rows_n) * 4u : 0);
-    const bool r_ln = LNR && has_r;
-    const __amdgpu_buffer_rsrc_t rsRG = make_rsrc(r_ln ? p.r_gamma + n0 : p.A, r_ln ? uint64_t(rows_n) * 4u : 0);
-    const __amdgpu_buffer_rsrc_t rsRB = make_rsrc(r_ln ? p.r_beta + n0 : p.A, r_ln ? uint64_t(rows_n) * 4u : 0);
-    // C/D layouts: 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16;
-    //              16x16 block: col = lane&15, row = 4*(lane>>4) + r,            r < 4.
-    auto blk_row = [&](int r) { return MF == 32 ? (r & 3) + 8 * (r >> 2) : r; };
-    const int lrow0 = wm * T::WTM + 4 * hi;
-    const int lcol0 = wn * T::WTN + l31;
 #pragma unroll
     for (int j = 0; j < T::NI; ++j) {
         const int lcol = lcol0 + j * MF;
         const bool col_ok = lcol < rows_n;
-        const float bv = bload1(rsBias, col_ok ? unsigned(lcol) * 4u : OOB);
-        float sv = 0.f, rg = 1.f, rb = 0.f;
-        if constexpr (LN) sv = bload1(rsS, col_ok ? unsigned(lcol) * 4u : OOB);
-        if constexpr (LNR) {
-            rg = bload1(rsRG, (r_ln && col_ok) ? unsigned(lcol) * 4u : OOB);
-            rb = bload1(rsRB, (r_ln && col_ok) ? unsigned(lcol) * 4u : OOB);
-        }
+        float bv;
+        if constexpr (RPRE)
+            bv = pre_b[j];
+        else
+            bv = bload1(rsBias, col_ok ? unsigned(lcol) * 4u : OOB);
 #pragma unroll
         for (int i = 0; i < T::MI; ++i) {
             float res[NACC];
-            if (has_r) {
+            if constexpr (RPRE) {
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) res[r] = pre_r[(j * T::MI + i) * NACC + r];
+            } else if (has_r) {
 #pragma unroll
                 for (int r = 0; r < NACC; ++r) {
                     const int lrow = lrow0 + i * MF + blk_row(r);
                     res[r] = bload1(rsR, col_ok ? unsigned(lrow * ldr + lcol) * 4u : OOB);
-                    if constexpr (LNR)  // LayerNorm(z_prev) recomputed from z_prev and its row statistics (explicit fma)
-                        res[r] = fmaf((res[r] - ln_lds[4 * lrow + 2]) * ln_lds[4 * lrow + 3], rg, rb);
                 }
             }
 #pragma unroll
             for (int r = 0; r < NACC; ++r) {
                 const int lrow = lrow0 + i * MF + blk_row(r);
-                float v = acc[i][j][r];
-                if constexpr (LN) {
-                    if (lns)  // rstd * (acc - mean * s) + bias'
-                        v = fmaf(ln_lds[4 * lrow + 1], fmaf(-ln_lds[4 * lrow], sv, v), bv);
-                    else
-                        v += bv;
-                } else {
-                    v += bv;
-                }
+                float v = acc[i][j][r] + bv;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (has_r) v += res[r];
                 bstore1(rsC, col_ok ? unsigned(lrow * ldc + lcol) * 4u : OOB, v);
-                if constexpr (PS) {
-                    // 16-lane butterfly = the 16 columns of one group of this row; lane 0 of the group stores the
-                    // partial (sum, sum of squares) [row][group][2].  Columns past N contribute exact zeros.
-                    float a = col_ok ? v : 0.f, q = a * a;
-                    a = row16_sum(a);
-                    q = row16_sum(q);
-                    if (l31 == 0 && lrow < rows_m) {
-                        const int g = tn * 4 + ((wn * T::WTN + j * MF) >> 4);
-                        float* out = p.part_out + ((m0 + lrow) * int64_t(tiles_n_seg) * 4 + g) * 2;
-                        out[0] = a;
-                        out[1] = q;
-                    }
-                }
             }
         }
     }
+#ifdef LAMP_TUNING
+    if (p.trace && tid == 0) {
+        unsigned long long* t = p.trace + size_t(blockIdx.x) * 8;
+        t[0] = t_entry; t[1] = t_loop; t[2] = t_epi; t[3] = wall_clock64();
+        t[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID (wave / SIMD / CU / SH / SE ids)
+        t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        t[6] = unsigned(item);
+        t[7] = 0;
+    }
+#endif
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, int LNM = 0>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF>
 static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
-    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, LNM>;
-    constexpr size_t LDS = T::LDS_BYTES + (LNM ? size_t(BM) * 4 * sizeof(float) : 0);
-    static bool attr_done[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS));
-        if (e != hipSuccess) return int(e);
-        attr_done[dev] = true;
-    }
+    constexpr bool RPRE = T::MI * T::NI * (MF == 32 ? 16 : 4) <= 16;
+    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE>;
+    constexpr size_t LDS = T::LDS_BYTES;
+    static AttrOnce once;
+    if (int e = once.set(reinterpret_cast<const void*>(kern), LDS)) return e;
     // 32-bit in-tile byte offsets
     const int64_t ldmax = p.lda > p.ldw ? (p.lda > p.ldc ? p.lda : p.ldc) : (p.ldw > p.ldc ? p.ldw : p.ldc);
     if (ldmax * (BM > BN ? BM : BN) * 4 >= 0x7fffffffLL || (p.R && p.ldr * BM * 4 >= 0x7fffffffLL))
@@ -358,7 +318,7 @@ static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     const int tiles_n = tiles_n_seg * p.nseg;
     const int64_t nwg = tiles_m * tiles_n;
     if (nwg > 0x7fffffffLL) return LAMP_E_DIMS;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(T::NT), LDS, s, p, tiles_n_seg, tiles_n);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(T::NT), LDS, s, p, tiles_n_seg, tiles_n, int(tiles_m));
     return int(hipGetLastError());
 }
 
@@ -367,24 +327,25 @@ static int launch_cfg(const GemmParams& p, hipStream_t s) {
     if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF>(p, s);
     return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF>(p, s);
 }
-// production tiles only: the deferred-LayerNorm variants (the callers' d_model is a multiple of BK: no K tail)
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
-static int launch_cfg_ln(const GemmParams& p, int lnm, hipStream_t s) {
-    if (p.K % BK) return LAMP_E_UNSUPPORTED;
-    switch (lnm) {
-        case 1: return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, 16, 1>(p, s);
-        case 2: return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, 16, 2>(p, s);
-        case 4: return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, 16, 4>(p, s);
-        case 6: return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, 16, 6>(p, s);
-        default: return LAMP_E_UNSUPPORTED;  // A pre-norm never coincides with a residual or partials on this path
-    }
-}
 
-// Debug/tuning hook (not part of the ABI header): force a tile configuration.  0 = heuristic.
+#ifdef LAMP_TUNING
+// Tuning build only (liblamp_hip_tuning.so: tools/bench_kernels.py and the every-variant tests): force a tile
+// configuration (0 = heuristic) and collect a per-workgroup timeline.  The production library has neither.
 static int g_force_tile = 0;
+static unsigned long long* g_gemm_trace = nullptr;  // n_slabs slabs of slab_words u64: launch i records into slab i % n_slabs,
+static long long g_trace_slab = 0;                  // 8 words per workgroup (entry, loop start, loop end, exit: wall_clock64
+static int g_trace_slabs = 0, g_trace_count = 0;    // ticks; HW_ID; XCC_ID; work item; -)
 extern "C" void lamp_debug_force_gemm_tile(int cfg) { g_force_tile = cfg; }
+extern "C" void lamp_debug_set_gemm_trace(unsigned long long* buf, long long slab_words, int n_slabs) {
+    g_gemm_trace = buf;
+    g_trace_slab = slab_words;
+    g_trace_slabs = n_slabs;
+    g_trace_count = 0;
+}
+#endif
 
-int launch_gemm(const GemmParams& p, hipStream_t s) {
+int launch_gemm(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.nseg < 1 || p.nseg > GEMM_MAX_SEG) return LAMP_E_DIMS;
     if ((p.K & 3) || (p.lda & 3) || (p.ldw & 3)) return LAMP_E_ALIGN;
     if (!p.A) return LAMP_E_NULL;
@@ -397,6 +358,14 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     const double bytes = 4.0 * (double(p.M) * p.K + double(p.N) * p.nseg * p.K +
                                 double(p.M) * p.N * p.nseg * (p.R ? 2 : 1));
     ProfScope prof(LAMP_K_GEMM, flops, bytes, s);
+    p.trace = nullptr;
+#ifdef LAMP_TUNING
+    if (g_gemm_trace && g_trace_slabs > 0) {
+        // upper bound of the grid over the tile menu: 32x64 tiles
+        const long long wg_max = ((p.M + 31) / 32) * ((p.N + 63) / 64) * p.nseg;
+        if (wg_max * 8 <= g_trace_slab) p.trace = g_gemm_trace + (g_trace_count % g_trace_slabs) * g_trace_slab;
+        ++g_trace_count;
+    }
     switch (g_force_tile) {
         case 1: return launch_cfg<128, 128, 32, 2, 2>(p, s);
         case 2: return launch_cfg<64, 64, 32, 2, 2>(p, s);
@@ -418,6 +387,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
         case 18: return launch_cfg<128, 64, 16, 2, 2, 16>(p, s);
         default: break;
     }
+#endif
     // Tile choice, from tools/bench_kernels.py on MI355X (profiles/r01_gemm_tiles.txt).  Every configuration the
     // heuristic may pick is built on the 16x16x4 MFMA, whose k-accumulation order (16c + {j, 4+j, 8+j, 12+j} for
     // j = 0..3 in every 16-chunk) does not depend on BM/BN/BK -- so the choice, which depends on M (i.e. on the
@@ -427,21 +397,9 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     // some SIMD runs two in sequence (16.4 us) however the blocks are grouped into workgroups -- measured 21.5 us for
     // every 32x32x2 tile from 32x32 (1 wave) to 128x64.  16x16 blocks are 2 us chains: 5760 / 1024 -> 12.3 us,
     // measured 17.5 us.  On the large shapes 128x64x16 with 64x32 wave tiles (4x2 blocks) reaches 135-144 TFLOP/s,
-    // also ahead of the best 32x32x2 tile (128x128x32: 128-139).  The 32x32x2 tiles remain as forced configs 1-8.
+    // also ahead of the best 32x32x2 tile (128x128x32: 128-139).  The 32x32x2 tiles exist in the tuning build only.
     auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nseg; };
     const int64_t t64 = tiles(64, 64);
-    int lnm = (p.r_part ? 2 : 0) | (p.part_out ? 4 : 0);
-    for (int i = 0; i < p.nseg; ++i) lnm |= p.ln_s[i] ? 1 : 0;
-    if (lnm) {  // same menu, deferred-LayerNorm instantiations
-        if ((lnm & 1) && (!p.a_part || p.a_nparts < 1)) return LAMP_E_NULL;
-        if ((lnm & 2) && (!p.R || !p.r_gamma || !p.r_beta || p.r_nparts < 1)) return LAMP_E_NULL;
-        if (((lnm & 1) && p.a_nparts > 64) || ((lnm & 2) && p.r_nparts > 64)) return LAMP_E_UNSUPPORTED;  // d <= 1024
-        if ((lnm & 4) && p.nseg != 1) return LAMP_E_UNSUPPORTED;
-        if (tiles(128, 64) >= 2048 && p.K >= 512) return launch_cfg_ln<128, 64, 16, 2, 2>(p, lnm, s);
-        if (t64 >= 2048) return launch_cfg_ln<64, 64, 32, 2, 2>(p, lnm, s);
-        if (t64 >= 1200) return launch_cfg_ln<64, 64, 16, 2, 2>(p, lnm, s);
-        return launch_cfg_ln<32, 64, 32, 1, 4>(p, lnm, s);
-    }
     if (tiles(128, 64) >= 2048 && p.K >= 512) return launch_cfg<128, 64, 16, 2, 2, 16>(p, s);  // short K: fewer, deeper steps
     if (t64 >= 2048) return launch_cfg<64, 64, 32, 2, 2, 16>(p, s);
     if (t64 >= 1200) return launch_cfg<64, 64, 16, 2, 2, 16>(p, s);

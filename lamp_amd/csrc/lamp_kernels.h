@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <mutex>
 #include "../../include/lamp_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -29,22 +31,7 @@ struct GemmParams {
     const float* R;  // residual, same for every segment (only meaningful with nseg == 1)
     int64_t ldr;
     int relu;
-    // ---- deferred LayerNorm (see gemm.hip) ----
-    // Producer (part_out): beside C, the epilogue writes per row and 16-column group the partial (sum, sum of squares)
-    // of the output values, [M][4 * ceil(N / 64)][2] -- the row statistics a later LayerNorm of C needs.
-    // Consumer, A pre-norm (ln_s): A holds PRE-LayerNorm rows z with partials a_part; the weights in W are folded,
-    // W'[n,k] = W[n,k] * gamma[k], bias' = W.beta + bias, ln_s[n] = sum_k W'[n,k]; the epilogue applies
-    //   C = rstd * (A.W'^T - mean * ln_s) + bias'  =  LayerNorm(z).W^T + bias   without LayerNorm(z) ever being stored.
-    // Consumer, R pre-norm (r_part): residual = (R - mean) * rstd * r_gamma + r_beta.
-    const float* ln_s[GEMM_MAX_SEG];  // all null = A is used as it is
-    float ln_eps;
-    const float* a_part;  // [M][a_nparts][2]
-    int a_nparts;
-    const float* r_part;  // [M][r_nparts][2]; null = R is used as it is
-    int r_nparts;
-    const float* r_gamma;
-    const float* r_beta;
-    float* part_out;      // nullable; nseg must be 1
+    unsigned long long* trace;  // tuning build only (per-workgroup timeline, see gemm.hip); NULL in production
 };
 
 struct AttnParams {
@@ -71,6 +58,8 @@ struct AttnParams {
 int launch_gemm(const GemmParams& p, hipStream_t s);
 int launch_attn(const AttnParams& p, hipStream_t s);
 int launch_attn_general(const AttnParams& p, hipStream_t s);  // any d_k / d_v: scores through memory
+bool attn_small_applies(const AttnParams& p);                  // attention_small.hip: lq <= 256 (shape-only rule)
+int launch_attn_small(const AttnParams& p, int force_ksplit, hipStream_t s);
 size_t gemm_gen_workspace_bytes(int M, int N, int K, int batch);
 int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStream_t s);
 // Counter-based dropout (lamp_dropout): element e of a site is kept iff mix32(e, seed) >= threshold, kept values are
@@ -120,8 +109,6 @@ int launch_embed(const int64_t* seq, const int64_t* pos, int64_t n_tok, const fl
 int launch_diag(const float* y, const float* w, int B, int L, int d, float* logits, hipStream_t s);
 int launch_prior_graph(const int64_t* ids, const int64_t* offsets, int64_t n_samples, int L, float* adj,
                        uint8_t* blocked, hipStream_t s);
-int launch_fold_layernorm(const float* W, int N, int K, const float* gamma, const float* beta, const float* bias, float* Wf,
-                          float* s, float* bf, hipStream_t st);
 int launch_sigmoid_bce(const float* logits, const float* targets, int64_t n_rows, int L, float* probs,
                        float* row_loss, hipStream_t s);
 
@@ -200,6 +187,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
+
+// hipFuncSetAttribute once per (kernel instantiation, device), safe under DataParallel-style threads.
+struct AttrOnce {
+    std::mutex mu;
+    bool done[64] = {};
+    int set(const void* kern, size_t lds) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return int(e);
+        if (dev < 0 || dev >= 64) return LAMP_E_UNSUPPORTED;
+        std::lock_guard<std::mutex> lk(mu);
+        if (done[dev]) return 0;
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return int(e);
+        done[dev] = true;
+        return 0;
+    }
+};
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

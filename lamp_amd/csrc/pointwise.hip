@@ -169,33 +169,6 @@ __global__ __launch_bounds__(256) void prior_graph_pairs_kernel(const int64_t* _
     }
 }
 
-// Folding a LayerNorm's affine part into the linear map that consumes its output (weights only: once per weight
-// version):  Wf[n,k] = W[n,k] * gamma[k],  s[n] = sum_k Wf[n,k],  bf[n] = sum_k W[n,k] * beta[k] + bias[n].
-// Then LayerNorm(z) . W^T + bias = rstd * (z . Wf^T - mean * s) + bf  (see gemm.hip, deferred LayerNorm).
-__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ W, int N, int K,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta,
-                                                             const float* __restrict__ bias, float* __restrict__ Wf,
-                                                             float* __restrict__ s, float* __restrict__ bf) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    float ss = 0.f, sb = 0.f;
-    for (int k = lane; k < K; k += 64) {
-        const float w = W[int64_t(n) * K + k];
-        const float wf = w * gamma[k];
-        Wf[int64_t(n) * K + k] = wf;
-        ss += wf;
-        sb += w * beta[k];
-    }
-    ss = wave_sum(ss);
-    sb = wave_sum(sb);
-    if (lane == 0) {
-        s[n] = ss;
-        bf[n] = sb + (bias ? bias[n] : 0.f);
-    }
-}
-
 static inline int grid4(int64_t rows, unsigned* g) {
     const int64_t n = (rows + 3) / 4;
     if (n > 0x7fffffffLL) return LAMP_E_DIMS;
@@ -252,14 +225,6 @@ int launch_layernorm(const float* x, int64_t M, int d, const float* g, const flo
     else
         LAMP_LN_LAUNCH(16);
 #undef LAMP_LN_LAUNCH
-    return int(hipGetLastError());
-}
-
-int launch_fold_layernorm(const float* W, int N, int K, const float* gamma, const float* beta, const float* bias, float* Wf,
-                          float* s, float* bf, hipStream_t st) {
-    if (N <= 0 || K <= 0) return LAMP_E_DIMS;
-    if (!W || !gamma || !beta || !Wf || !s || !bf) return LAMP_E_NULL;
-    hipLaunchKernelGGL(fold_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, st, W, N, K, gamma, beta, bias, Wf, s, bf);
     return int(hipGetLastError());
 }
 

@@ -17,13 +17,20 @@ import itertools
 import torch
 
 from . import _native as N
+from . import sharding
 from .data import get_gold_binary
 
 
 def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True, int_preds=False, streams=1,
-               prefetch=256):
+               prefetch=256, world_size=1, rank=0, group=None):
     """-> (all_predictions (n, L) cpu, all_targets (n, L) cpu, bce_total float), as test.py:16-78 returns
     them.  `batches` yields ((src_seq, src_pos), adj, tgt) like lamp_amd.data.EvalBatcher.
+
+    Multi-GPU (replaces nn.DataParallel's per-forward scatter, main.py:106-108): with world_size > 1
+    this process -- one per GPU, torch.distributed initialised by the caller -- runs only its contiguous share of the
+    BATCHES (sharding.shard_bounds); no collective touches the forward path.  After the last batch the per-rank
+    prediction / target rows and BCE sums are combined once (all_reduce over disjoint rows), so every rank returns the
+    full matrices.  A sample's numbers do not depend on world_size.
 
     Up to `prefetch` batches are staged on the device before their forwards are issued: a host-to-device copy from
     pageable memory blocks the host until the stream reaches it, so copies interleaved with forwards (as the
@@ -34,7 +41,8 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
     all_predictions = torch.zeros(n, n_labels)
     bce_total = 0.0
     lanes = [torch.cuda.Stream(device=device) for _ in range(streams)] if streams > 1 else [None]
-    it = iter(enumerate(batches))
+    b_lo, b_hi = sharding.shard_bounds(len(batches), world_size, rank) if world_size > 1 else (0, len(batches))
+    it = iter((bi, b) for bi, b in enumerate(batches) if b_lo <= bi < b_hi)
     while True:
         host = []
         for bi, ((src_seq, src_pos), adj, tgt) in itertools.islice(it, prefetch):
@@ -82,6 +90,23 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
             all_predictions[lo:lo + real] = probs_all[off:off + real]
             off += real
         del staged, done, host
+    if world_size > 1:
+        import torch.distributed as dist
+        on_gpu = dist.get_backend(group) == 'nccl'
+        packed = torch.cat((all_predictions.reshape(-1), all_targets.reshape(-1),
+                            torch.tensor([bce_total], dtype=torch.float32)))
+        # rows are disjoint across ranks and zero elsewhere: the sum IS the concatenation (NaN rows cannot occur here --
+        # padded rows were sliced off above); bce in float64 to keep the reference's python-float accumulation exact enough
+        bce = torch.tensor([bce_total], dtype=torch.float64)
+        if on_gpu:
+            packed, bce = packed.to(device), bce.to(device)
+        dist.all_reduce(packed, group=group)
+        dist.all_reduce(bce, group=group)
+        packed = packed.cpu()
+        k = n * n_labels
+        all_predictions = packed[:k].view(n, n_labels)
+        all_targets = packed[k:2 * k].view(n, n_labels)
+        bce_total = float(bce.cpu())
     return all_predictions, all_targets, bce_total
 
 

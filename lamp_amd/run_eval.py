@@ -3,18 +3,25 @@ on the MI355X path.
 
     python -m lamp_amd.run_eval -data data/reuters/train_valid_test.pt -dataset reuters \
            -d_model 512 -d_inner_hid 512 -n_layers_enc 2 -n_head 4 -label_mask prior \
-           [-checkpoint results/.../model.chkpt] [-split test] [-batch_size 32] [-streams 2]
+           [-checkpoint results/.../model.chkpt] [-split test] [-batch_size 32] [-streams 2] [-gpus N]
+
+-gpus N starts one process per GPU (rendezvous on 127.0.0.1; "nccl" = RCCL for the final gather only); every rank
+evaluates its contiguous share of the batches -- the forward path needs no collective (lamp_amd/sharding.py).
 
 Flag names and derived defaults follow the reference's config_args.py (single-dash flags; n_layers_dec =
 n_layers_enc :87-88, d_k = d_v = d_model / n_head :96-99, d_inner_hid = 2 d_model :110-111, no position
 embedding for bibtext / delicious / bookmarks / sider :104-105, n_head2 = n_head :135-136).  The model is
 built from the dataset exactly as main.py:53-88 does (vocabulary sizes, max sequence length, prior label
 adjacency from the train split).  Metrics are the thresholded multi-label basics the reference prints first
-(utils/evals.py: subset accuracy, Hamming accuracy, example-/micro-/macro-F1 at -br_threshold); the
-sklearn-based ranking metrics are CPU post-processing outside this path.
+(utils/evals.py:316-372: subset accuracy, Hamming accuracy, example-/micro-/macro-F1 at -br_threshold, with the
+reference's conventions for empty samples / labels); the sklearn-based ranking metrics are CPU post-processing
+outside this path.
 """
 import argparse
 import json
+import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,6 +51,7 @@ def parse(argv=None):
     ap.add_argument('-br_threshold', type=float, default=0.5)
     ap.add_argument('-streams', type=int, default=2, choices=[1, 2, 3, 4], help='batches in flight (HIP streams)')
     ap.add_argument('-seed', type=int, default=0, help='weight init seed when no checkpoint is given')
+    ap.add_argument('-gpus', type=int, default=1, help='processes (one per GPU) the batches are sharded over')
     opt = ap.parse_args(argv)
     if opt.n_layers_dec is None:
         opt.n_layers_dec = opt.n_layers_enc
@@ -59,29 +67,86 @@ def parse(argv=None):
 
 
 def multilabel_metrics(pred, target, threshold):
-    """Thresholded metrics on (n, L) cpu tensors; rows with NaN predictions are counted as all-negative."""
-    p = (torch.nan_to_num(pred, nan=0.0) >= threshold).float()
-    t = target.float()
+    """Thresholded metrics on (n, L) cpu tensors, with the conventions of the reference's utils/evals.py:
+    example-based F1 averages only over samples with at least one gold or predicted label (example_f1_score
+    :105-123 deletes zero denominators), macro-F1 only over labels with tp + fp + fn > 0 (f1_score_from_stats
+    :141-147 drops the non-finite ratios).  Rows with NaN predictions are counted as all-negative."""
+    p = (torch.nan_to_num(pred, nan=0.0) >= threshold).double()
+    t = target.double()
     tp = (p * t).sum(0)
     fp = (p * (1 - t)).sum(0)
     fn = ((1 - p) * t).sum(0)
-    f1 = lambda a, b, c: (2 * a / (2 * a + b + c).clamp_min(1e-12))  # noqa: E731
     ex_tp = (p * t).sum(1)
-    ex_den = (p.sum(1) + t.sum(1)).clamp_min(1e-12)
+    ex_den = p.sum(1) + t.sum(1)
+    ex_ok = ex_den > 0
+    lab_den = 2 * tp + fp + fn
+    lab_ok = lab_den > 0
+    nan = float('nan')
     return {
-        'subset_accuracy': (p == t).all(dim=1).float().mean().item(),
-        'hamming_accuracy': (p == t).float().mean().item(),
-        'example_f1': (2 * ex_tp / ex_den).mean().item(),
-        'micro_f1': f1(tp.sum(), fp.sum(), fn.sum()).item(),
-        'macro_f1': f1(tp, fp, fn).mean().item(),
+        'subset_accuracy': (p == t).all(dim=1).double().mean().item(),
+        'hamming_accuracy': (p == t).double().mean().item(),
+        'example_f1': (2 * ex_tp[ex_ok] / ex_den[ex_ok]).mean().item() if ex_ok.any() else nan,
+        'micro_f1': (2 * tp.sum() / lab_den.sum()).item() if lab_den.sum() > 0 else nan,
+        'macro_f1': (2 * tp[lab_ok] / lab_den[lab_ok]).mean().item() if lab_ok.any() else nan,
     }
 
 
+def load_checkpoint_state(path):
+    """state_dict of a reference checkpoint ({'model': state_dict, ...} or a bare state_dict).  Hosts with more than
+    one GPU save from inside nn.DataParallel (main.py:106-108 before utils.save_model): `module.`-prefixed keys, which
+    LAMP.load_state_dict strips."""
+    ckpt = torch.load(path, map_location='cpu', weights_only=False)
+    return ckpt['model'] if isinstance(ckpt, dict) and 'model' in ckpt else ckpt
+
+
+def spawn_ranks(n, argv):
+    """One process per GPU, each re-running this module with RANK / WORLD_SIZE set; rank 0 prints the result."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, '-m', 'lamp_amd.run_eval'] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in alive:   # a dead rank leaves the others in a collective: stop exactly the ones we started
+                    q.terminate()
+    return rc
+
+
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
     opt = parse(argv)
     if not torch.cuda.is_available():
         raise SystemExit('lamp_amd.run_eval needs an MI355X: no HIP device visible (there is no CPU path)')
-    device = torch.device('cuda', torch.cuda.current_device())
+    if opt.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        rc = spawn_ranks(opt.gpus, argv)
+        if rc:
+            raise SystemExit(rc)
+        return None
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    dev_index = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count() if world > 1 else torch.cuda.current_device()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
+    if world > 1:
+        import torch.distributed as dist
+        backend = os.environ.get('LAMP_EVAL_BACKEND', 'nccl')   # gloo lets several ranks share one GPU (tests)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     data = D.load_dataset(opt.data)
     n_src, n_labels = D.vocabulary_sizes(data)
     adj = (D.prior_adjacency_device(data['train']['tgt'], len(data['dict']['tgt']), device).cpu()
@@ -94,23 +159,28 @@ def main(argv=None):
                  no_enc_pos_embedding=opt.no_enc_pos_embedding, no_dec_self_att=opt.no_dec_self_att,
                  label_adj_matrix=adj, label_mask=opt.label_mask, dec_dropout2=False)
     if opt.checkpoint:
-        ckpt = torch.load(opt.checkpoint, map_location='cpu', weights_only=False)
-        model.load_state_dict(ckpt['model'] if 'model' in ckpt else ckpt)
+        model.load_state_dict(load_checkpoint_state(opt.checkpoint))
     model = model.to(device).eval()
     split = data[opt.split]
     batches = D.EvalBatcher(split['src'], split['tgt'], opt.batch_size)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    preds, targets, bce_total = test_epoch(model, batches, n_labels, opt.batch_size, device, streams=opt.streams)
+    preds, targets, bce_total = test_epoch(model, batches, n_labels, opt.batch_size, device, streams=opt.streams,
+                                           world_size=world, rank=rank)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = {'split': opt.split, 'n_samples': batches.n_insts, 'n_labels': n_labels, 'n_batches': len(batches),
            'bce_total': bce_total, 'seconds': dt, 'samples_per_s': batches.n_insts / dt,
-           'checkpoint': opt.checkpoint}
+           'checkpoint': opt.checkpoint, 'n_gpus': world}
     out.update(multilabel_metrics(preds, targets, opt.br_threshold))
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return out
 
 
 if __name__ == '__main__':
-    main(sys.argv[1:])
+    main()

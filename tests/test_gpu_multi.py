@@ -1,0 +1,211 @@
+"""-m gpu: the N > 1 and threaded entry points of the HIP path on ONE box (SURVEY.md 8e, 8b "Threading").
+
+* bench.py --gpus 2 started plainly (no torchrun): the script spawns the ranks itself; with LAMP_BENCH_BACKEND=gloo the
+  two ranks share the only GPU of the test box.
+* run_eval -gpus 2: the batches of a test split sharded over two ranks running the HIP forward, against one rank.
+* nn.DataParallel wrapping (main.py:106-108), DataParallel-style replicas driven from two host threads, and two
+  threads on two streams: bitwise equal to the plain call.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from test_gpu_parity import CONFIGS, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from lamp_amd import _native as N
+    N.lib()
+    return torch.device('cuda:0')
+
+
+def _bench(args, env_extra=None):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True,
+                       env=env, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_spawns_its_own_ranks(dev):
+    common = ['--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--no-pipelined', '--no-extra-workloads']
+    r1, one = _bench(['--gpus', '1'] + common)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert one['n_gpus'] == 1 and one['ranks_seen'] == [0] and len(one['per_rank']) == 1
+    assert one['metric'] == 'forward samples/sec, reuters d512 2+2L 4h' and one['steps'] == 5 and one['unit'] == 'samples/s'
+    r2, two = _bench(['--gpus', '2'] + common, {'LAMP_BENCH_BACKEND': 'gloo'})
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert two['n_gpus'] == 2 and two['ranks_seen'] == [0, 1] and len(two['per_rank']) == 2
+    assert two['config']['launcher'] == 'self-spawned ranks' and two['physical_devices'] == 1
+    assert all(p['value'] > 0 for p in two['per_rank'])
+    # aggregate = all samples / slowest rank's time
+    slowest = max(p['ms_per_step'] for p in two['per_rank'])
+    assert abs(two['value'] - 2 * 32 / (slowest * 1e-3)) < 1e-6 * two['value']
+    assert 'cpu_baseline' not in two
+    # the same under the launcher the driver uses
+    env = dict(os.environ, LAMP_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r3 = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                         '--master-addr', '127.0.0.1', '--master-port', '29517', os.path.join(ROOT, 'bench.py'),
+                         '--gpus', '2'] + common, capture_output=True, text=True, env=env, timeout=900)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    three = json.loads([l for l in r3.stdout.splitlines() if l.startswith('{')][-1])
+    assert three['n_gpus'] == 2 and three['config']['launcher'] == 'torch.distributed.run'
+    # a rank count that does not match --gpus is an error, not a silent n_gpus: 1
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r4 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + common, capture_output=True,
+                        text=True, env=env, timeout=900)
+    assert r4.returncode != 0
+
+
+def test_run_eval_sharded_over_two_ranks_equals_one(dev, tmp_path):
+    """Two processes (gloo, sharing this box's GPU) each run the HIP forward on their share of the test batches;
+    the gathered result must equal the one-process run: same BCE, same metrics."""
+    d, sd = load_golden('harness')
+
+    def unflatten(flat, off):
+        return [flat[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+    splits = {name: {part: unflatten(d['%s_%s_flat' % (name, part)], d['%s_%s_off' % (name, part)])
+                     for part in ('src', 'tgt')} for name in ('train', 'valid', 'test')}
+    src = {('w%d' % i): i for i in range(d['n_src_dict'])}
+    tgt = {('l%d' % i): i for i in range(d['n_tgt_dict'])}
+    data = {'settings': argparse.Namespace(max_seq_len=d['max_seq_len']), 'dict': {'src': src, 'tgt': tgt}, **splits}
+    torch.save(data, tmp_path / 'train_valid_test.pt')
+    torch.save({'model': {'module.' + k: v for k, v in sd.items()}}, tmp_path / 'model.chkpt')  # DataParallel-style keys
+    dm = sd['decoder.tgt_word_emb.weight'].size(1)
+    args = ['-data', str(tmp_path / 'train_valid_test.pt'), '-checkpoint', str(tmp_path / 'model.chkpt'), '-d_model', str(dm),
+            '-d_inner_hid', str(2 * dm), '-n_layers_enc', '2', '-n_head', str(d['n_head']), '-label_mask', 'prior',
+            '-batch_size', str(d['batch_size'])]
+    env = dict(os.environ, LAMP_EVAL_BACKEND='gloo', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    env.pop('WORLD_SIZE', None)
+    outs = []
+    for gpus in (1, 2):
+        r = subprocess.run([sys.executable, '-m', 'lamp_amd.run_eval'] + args + ['-gpus', str(gpus)], capture_output=True,
+                           text=True, env=env, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1]))
+    one, two = outs
+    assert one['n_gpus'] == 1 and two['n_gpus'] == 2 and d['n_batches'] >= 2
+    assert abs(one['bce_total'] - d['bce_total']) < 2e-5 * d['n_batches']
+    assert abs(two['bce_total'] - one['bce_total']) < 1e-9
+    for k in ('subset_accuracy', 'hamming_accuracy', 'example_f1', 'micro_f1', 'macro_f1', 'n_samples'):
+        assert two[k] == one[k], k
+
+
+def test_dataparallel_wrapper_is_bitwise_the_plain_call(dev):
+    m, sd, blocked, seq, spos, h = make_case(CONFIGS['bibtex'], dev)
+    src = (seq.to(dev), spos.to(dev))
+    plain, enc_plain, _ = m(src, None, None, None)
+    dp = torch.nn.DataParallel(m, device_ids=[0])
+    out, enc, third = dp(src, None, None, None)
+    assert third is None and torch.equal(out, plain) and torch.equal(enc, enc_plain)
+
+
+def _replicas(m, n):
+    """What nn.DataParallel builds on every forward (torch/nn/parallel/replicate.py), on ONE device: shallow module
+    copies with empty _parameters and fresh tensor copies of every weight as plain attributes."""
+    try:
+        from torch.nn.parallel import replicate
+        return replicate(m, [0] * n)
+    except Exception:
+        reps = []
+        for _ in range(n):
+            memo = {}
+            for mod in m.modules():
+                memo[mod] = mod._replicate_for_data_parallel()
+            for mod, rep in memo.items():
+                for k, child in mod._modules.items():
+                    rep._modules[k] = memo[child] if child is not None else None
+                for k, p in mod._parameters.items():
+                    if p is not None:
+                        setattr(rep, k, p.detach().clone())
+                for k, b in mod._buffers.items():
+                    if b is not None:
+                        setattr(rep, k, b.clone())
+            reps.append(memo[m])
+        return reps
+
+
+def test_replicas_in_threads_match_the_original(dev):
+    """DataParallel-style: replicas (no Parameters, fresh tensors, a stale copied cache) run in one host thread each."""
+    m, sd, blocked, seq, spos, h = make_case(CONFIGS['reuters_ragged'], dev)
+    seq, spos = seq.to(dev), spos.to(dev)
+    plain, enc_plain, _ = m((seq, spos), None, None, None)      # also fills the original's descriptor cache
+    for _ in range(2):                                          # replicas are rebuilt per forward, as DataParallel does
+        reps = _replicas(m, 2)
+        assert all(getattr(r, '_is_replica', False) and not list(r.parameters()) for r in reps)
+        chunks = [(seq[:3], spos[:3]), (seq[3:], spos[3:])]
+        results, errors = [None, None], []
+
+        def work(i):
+            try:
+                with torch.cuda.device(0), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    results[i] = reps[i](chunks[i], None, None, None)[0]
+                    torch.cuda.current_stream().synchronize()
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errors, errors
+        assert torch.equal(torch.cat(results), plain)
+
+
+def test_two_threads_two_streams_are_bitwise_the_plain_call(dev):
+    """The library is re-entrant: two host threads drive the SAME model on their own HIP streams concurrently."""
+    m, sd, blocked, seq, spos, h = make_case(CONFIGS['reuters_ragged'], dev)
+    m2, *_ = make_case(CONFIGS['bibtex'], dev)
+    seq, spos = seq.to(dev), spos.to(dev)
+    seq2, spos2 = (t.to(dev) for t in make_case(CONFIGS['bibtex'], dev)[3:5])
+    want = m((seq, spos), None, None, None)[0]
+    want2 = m2((seq2, spos2), None, None, None)[0]
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(model, s, p, ref):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(25):
+                    out = model((s, p), None, None, None)[0]
+                st.synchronize()
+            assert torch.equal(out, ref)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+    ts = [threading.Thread(target=work, args=a) for a in ((m, seq, spos, want), (m2, seq2, spos2, want2), (m, seq, spos, want))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+
+
+def test_data_written_through_dot_data_needs_explicit_invalidation(dev):
+    """Parameter._version does not move on `.data` writes: invalidate_native_cache() (also called by load_state_dict,
+    train() / eval(), .to()) refreshes the hoisted layer-0 query."""
+    m, sd, blocked, seq, spos, h = make_case(CONFIGS['bibtex'], dev)
+    src = (seq.to(dev), spos.to(dev))
+    before, _, _ = m(src, None, None, None)
+    m.decoder.layer_stack[0].enc_attn.w_qs.weight.data.mul_(1.5)
+    m.invalidate_native_cache()
+    after, _, _ = m(src, None, None, None)
+    m.cache_layer0_query = False
+    m.invalidate_native_cache()
+    ref, _, _ = m(src, None, None, None)
+    assert torch.equal(after, ref) and not torch.equal(after, before)
+    # load_state_dict and eval() invalidate on their own
+    m.cache_layer0_query = True
+    m.load_state_dict(sd)
+    again, _, _ = m.to(dev).eval()(src, None, None, None)
+    assert torch.equal(again, before)

@@ -22,6 +22,18 @@ def dev():
     return torch.device('cuda:0')
 
 
+@pytest.fixture(scope='module')
+def tuning():
+    """The -DLAMP_TUNING build of the same sources: the only library that exports the lamp_debug_* hooks."""
+    import ctypes
+    from lamp_amd import _native as N
+    t = N.load_library(N.TUNING_LIB_PATH)
+    for name in ('lamp_debug_force_gemm_tile', 'lamp_debug_force_attn'):
+        getattr(t, name).argtypes = [ctypes.c_int]
+        getattr(t, name).restype = None
+    return t
+
+
 # ------------------------------------------------------------------ building blocks
 @pytest.mark.parametrize('M,K,N_', [(1, 4, 1), (7, 36, 5), (64, 64, 64), (90, 512, 512), (200, 128, 96),
                                     (2880, 512, 512), (9664, 512, 512), (333, 1024, 2048)])
@@ -40,13 +52,11 @@ def test_linear_vs_torch_fp64(dev, M, K, N_):
 
 
 @pytest.mark.parametrize('cfg', list(range(1, 19)))
-def test_linear_every_tile_config(dev, cfg):
+def test_linear_every_tile_config(dev, tuning, cfg):
     """Every GEMM tile configuration (32x32x2 and 16x16x4 MFMA variants) against fp64, on shapes with
-    ragged M / N edges and a K that is not a multiple of BK."""
-    import ctypes
+    ragged M / N edges and a K that is not a multiple of BK (tuning build of the library)."""
     from lamp_amd import _native as N
-    force = N.lib().lamp_debug_force_gemm_tile
-    force.argtypes = [ctypes.c_int]
+    force = tuning.lamp_debug_force_gemm_tile
     try:
         force(cfg)
         for M, K, N_ in ((300, 512, 200), (67, 72, 130), (1, 4, 1)):
@@ -56,7 +66,7 @@ def test_linear_every_tile_config(dev, cfg):
             b = torch.randn(N_, generator=g)
             r = torch.randn(M, N_, generator=g)
             ref = (x.double() @ w.double().t() + b.double()).clamp_min(0) + r.double()
-            out = N.linear(x.to(dev), w.to(dev), b.to(dev), residual=r.to(dev), relu=True)
+            out = N.linear(x.to(dev), w.to(dev), b.to(dev), residual=r.to(dev), relu=True, _lib=tuning)
             assert max_abs_diff(out, ref) < 2e-5, (cfg, M, K, N_)
     finally:
         force(0)
@@ -121,14 +131,12 @@ def test_sdpa_vs_oracle_shapes(dev, lq, lk, dk):
 
 
 @pytest.mark.parametrize('mode', [1, 2, 4])
-@pytest.mark.parametrize('lq,lk,dk', [(90, 302, 128), (70, 33, 64), (200, 513, 32), (5, 1, 16)])
-def test_sdpa_every_kernel_variant(dev, mode, lq, lk, dk):
-    """The attention kernel with 1/2/4-way key split must agree with the oracle in every variant, masks
-    and dead rows included."""
-    import ctypes
+@pytest.mark.parametrize('lq,lk,dk', [(90, 302, 128), (70, 33, 64), (200, 513, 32), (5, 1, 16), (300, 130, 128), (260, 40, 24)])
+def test_sdpa_every_kernel_variant(dev, tuning, mode, lq, lk, dk):
+    """The attention kernels (16-query blocks up to 256 queries, 32-query blocks beyond and for exact maps) with
+    1/2/4-way key split must agree with the oracle in every variant, masks and dead rows included."""
     from lamp_amd import _native as N
-    force = N.lib().lamp_debug_force_attn
-    force.argtypes = [ctypes.c_int]
+    force = tuning.lamp_debug_force_attn
     g = torch.Generator().manual_seed(lq + lk + mode)
     n = 3
     q, k, v = (torch.randn(n, l, dk, generator=g) for l in (lq, lk, lk))
@@ -138,8 +146,8 @@ def test_sdpa_every_kernel_variant(dev, mode, lq, lk, dk):
     ref_o, ref_a = R.sdpa(q.double(), k.double(), v.double(), mask)
     try:
         force(mode)
-        o, _ = N.sdpa(q.to(dev), k.to(dev), v.to(dev), mask.to(dev), 1.0 / dk ** 0.5, need_attn=False)
-        o2, a2 = N.sdpa(q.to(dev), k.to(dev), v.to(dev), mask.to(dev), 1.0 / dk ** 0.5, need_attn=True)
+        o, _ = N.sdpa(q.to(dev), k.to(dev), v.to(dev), mask.to(dev), 1.0 / dk ** 0.5, need_attn=False, _lib=tuning)
+        o2, a2 = N.sdpa(q.to(dev), k.to(dev), v.to(dev), mask.to(dev), 1.0 / dk ** 0.5, need_attn=True, _lib=tuning)
     finally:
         force(0)
     assert max_abs_diff(o, ref_o) < 2e-5
@@ -238,6 +246,13 @@ CONFIGS = {
     'inveye_8h': (300, 70, 50, 256, 512, 8, 'inveye', True, 3, 0.0, [50, 1, 23]),
     # 4096 labels (configs[4]'s label graph: 128 key tiles per label row, sparse prior mask), narrow model
     'labels4096': (500, 4096, 64, 256, 512, 2, 'prior', True, 2, 0.05, [64, 30]),
+    # BASELINE.json configs[1] at its full batch, directly against the oracle (0.15 s of CPU)
+    'reuters_b32': (23666, 90, 302, 512, 512, 4, 'prior', True, 32, 0.10, None),
+    # BASELINE.json configs[4] EXACTLY: 4096 labels x 512 tokens, d_model 1024, 8 heads, d_ff 2048,
+    # prior p = 0.05 -- one full and one ragged sample (the oracle needs ~0.8 TFLOP and ~2 GB of host memory), and
+    # its fully connected variant
+    'synthetic4096_full': (32004, 4096, 512, 1024, 2048, 8, 'prior', True, 2, 0.05, [512, 300]),
+    'synthetic4096_full_none': (32004, 4096, 512, 1024, 2048, 8, 'none', True, 1, 0.0, None),
 }
 
 
@@ -294,55 +309,64 @@ def test_samples_are_independent_bitwise(dev):
     assert torch.equal(split, full) and torch.equal(enc_split, enc_full)
 
 
-def test_two_stream_forward_is_bit_identical(dev):
-    """lamp_set_forward_streams(2): the K/V projections of decoder layers >= 1 run ahead on a side
-    stream; the results must not change by a bit, for odd batches, int_preds and micro-batched runs."""
-    from lamp_amd import _native as N
+def test_delicious_batch32_properties_bitwise(dev):
+    """BASELINE.json configs[3] at its full batch (983 labels, d_model 1024, 8 heads, mask none, B = 32): too large for
+    the oracle in seconds, so it is tied to the oracle-checked B = 2 case through the size-independent properties --
+    every sample equals its own single-sample / sliced / permuted / micro-batched run bit for bit."""
+    cfg = list(CONFIGS['delicious'])
+    cfg[8] = 32
+    cfg[10] = [40, 17, 5, 33] * 8
+    m, sd, blocked, seq, spos, h = make_case(tuple(cfg), dev)
+    seq, spos = seq.to(dev), spos.to(dev)
+    full, enc_full, _ = m((seq, spos), None, None, None)
+    assert torch.isfinite(full).all()
+    # samples 0 and 1 are exactly the oracle-checked 'delicious' case (same seed, same lengths)
+    with torch.no_grad():
+        ref, ref_enc, _ = R.forward(sd, seq[:2].cpu(), spos[:2].cpu(), h, blocked)
+    assert max_abs_diff(full[:2], ref) < TOL_LOGIT and max_abs_diff(enc_full[:2], ref_enc) < TOL_ACT
+    for lo, hi in ((0, 2), (0, 16), (16, 32), (7, 8)):
+        part, enc_part, _ = m((seq[lo:hi], spos[lo:hi]), None, None, None)
+        assert torch.equal(part, full[lo:hi]) and torch.equal(enc_part, enc_full[lo:hi])
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(2)).to(dev)
+    shuffled, _, _ = m((seq[perm], spos[perm]), None, None, None)
+    assert torch.equal(shuffled, full[perm])
+    m.workspace_limit_bytes = 512 << 20   # forces micro-batches inside lamp_forward
+    split, enc_split, _ = m((seq, spos), None, None, None)
+    assert torch.equal(split, full) and torch.equal(enc_split, enc_full)
+
+
+def test_requested_maps_do_not_change_logits(dev):
+    """Requested maps come from the same single-pass kernels (scores + row log-sum-exp written on the side): the
+    logits do not change by a bit when maps or intermediate predictions are asked for, nor under micro-batching."""
     cfg = list(CONFIGS['reuters_ragged'])
     cfg[8] = 7
     cfg[10] = [302, 20, 150, 77, 201, 33, 9]
     m, sd, blocked, seq, spos, h = make_case(tuple(cfg), dev)
     src = (seq.to(dev), spos.to(dev))
     one, enc_one, _ = m(src, None, None, None)
-    _, _, ips_one = m(src, None, None, None, int_preds=True)
-    try:
-        N.set_forward_streams(2)
-        for _ in range(3):
-            two, enc_two, _ = m(src, None, None, None)
-            assert torch.equal(two, one) and torch.equal(enc_two, enc_one)
-        _, _, ips_two = m(src, None, None, None, int_preds=True)
-        for a, b in zip(ips_one, ips_two):
-            assert torch.equal(a, b)
-        m.workspace_limit_bytes = 64 << 20
-        split, _, _ = m(src, None, None, None)
-        assert torch.equal(split, one)
-        # requested maps come from the same single-pass kernel (scores + row log-sum-exp written on the side):
-        # the logits do not change by a bit when maps are asked for
-        lg, _, _, _ = m(src, None, None, None, return_attns=True)
-        assert torch.equal(lg, one)
-    finally:
-        N.set_forward_streams(1)
+    lg, _, _, _ = m(src, None, None, None, return_attns=True)
+    assert torch.equal(lg, one)
+    lg2, _, ips = m(src, None, None, None, int_preds=True)
+    assert torch.equal(lg2, one) and len(ips) == 3
+    m.workspace_limit_bytes = 64 << 20
+    split, enc_split, _ = m(src, None, None, None)
+    assert torch.equal(split, one) and torch.equal(enc_split, enc_one)
 
 
-def test_attention_maps_survive_micro_batching_and_two_streams(dev):
-    """return_attns=True with the batch split into micro-batches (tiny workspace) and with the two-stream
-    decoder: every (h*B, lq, lk) map must equal the single-pass one."""
-    from lamp_amd import _native as N
+def test_attention_maps_survive_micro_batching(dev):
+    """return_attns=True with the batch split into micro-batches (tiny workspace): every (h*B, lq, lk) map must
+    equal the single-pass one."""
     m, sd, blocked, seq, spos, h = make_case(CONFIGS['inveye_8h'], dev)
     src = (seq.to(dev), spos.to(dev))
     lg, enc, enc_attns, dec2 = m(src, None, None, None, return_attns=True)
     flat = [a for a in enc_attns[0]] + [a for a in dec2[0]] + [a for a in dec2[1]]
-    try:
-        for streams, limit in ((1, 3 << 20), (2, 8 << 30), (2, 6 << 20)):
-            N.set_forward_streams(streams)
-            m.workspace_limit_bytes = limit
-            lg2, enc2, ea2, d2 = m(src, None, None, None, return_attns=True)
-            flat2 = [a for a in ea2[0]] + [a for a in d2[0]] + [a for a in d2[1]]
-            assert torch.equal(lg2, lg) and torch.equal(enc2, enc)
-            for a, b in zip(flat, flat2):
-                assert max_abs_diff(a, b) == 0.0
-    finally:
-        N.set_forward_streams(1)
+    for limit in (3 << 20, 6 << 20):
+        m.workspace_limit_bytes = limit
+        lg2, enc2, ea2, d2 = m(src, None, None, None, return_attns=True)
+        flat2 = [a for a in ea2[0]] + [a for a in d2[0]] + [a for a in d2[1]]
+        assert torch.equal(lg2, lg) and torch.equal(enc2, enc)
+        for a, b in zip(flat, flat2):
+            assert max_abs_diff(a, b) == 0.0
 
 
 def test_layer0_query_cache_tracks_weight_updates(dev):
@@ -670,83 +694,3 @@ def test_model_with_wide_heads_vs_oracle(dev):
         with torch.no_grad():
             lg2, _, _ = m((seq.to(dev), spos.to(dev)), None, None, None)
         assert torch.equal(lg2, logits)
-
-
-# ------------------------------------------------------------------ deferred LayerNorm (LN folded into the consuming GEMM)
-@pytest.mark.parametrize('M,K,N_', [(2880, 512, 512), (9664, 512, 512), (2880, 512, 1536), (31456, 1024, 2048), (77, 64, 96), (5, 96, 7)])
-def test_linear_with_deferred_layernorm_vs_torch(dev, M, K, N_):
-    """act(LayerNorm(z) W^T + b) + LayerNorm_r(z_prev) without either LayerNorm being materialised: z and z_prev come out
-    of producer GEMMs whose epilogues also write the rows' partial sums; the consumer derives (mean, rstd) from them.
-    Every production tile (the shapes pick all four), ragged edges, partial tiles of 64 columns."""
-    from lamp_amd import _native as N
-    g = torch.Generator().manual_seed(M + K)
-    x0 = torch.randn(M, 64, generator=g)
-    w0, b0 = torch.randn(K, 64, generator=g) * 0.2, torch.randn(K, generator=g) * 0.5 + 0.3
-    w1, b1 = torch.randn(N_, 64, generator=g) * 0.2, torch.randn(N_, generator=g) * 0.5 - 0.2
-    z, zpart = N.linear_ln(x0.to(dev), w0.to(dev), bias=b0.to(dev), want_part=True)          # producer of z   (M, K)
-    zprev, zprev_part = N.linear_ln(x0.to(dev), w1.to(dev), bias=b1.to(dev), want_part=True)  # producer of z_prev (M, N)
-    zd, zpd = z.double().cpu(), zprev.double().cpu()
-    assert max_abs_diff(z, x0.double() @ w0.double().t() + b0.double()) < 2e-5
-    assert max_abs_diff(zpart.sum(1)[:, 0], zd.sum(1)) < 1e-3 and max_abs_diff(zpart.sum(1)[:, 1], (zd * zd).sum(1)) < 2e-3
-    w = torch.randn(N_, K, generator=g) / K ** 0.5
-    b = torch.randn(N_, generator=g)
-    gam, bet = 1 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
-    rg, rb = 1 + 0.2 * torch.randn(N_, generator=g), 0.1 * torch.randn(N_, generator=g)
-    y = torch.nn.functional.layer_norm(zd, (K,), gam.double(), bet.double(), 1e-5)
-    res = torch.nn.functional.layer_norm(zpd, (N_,), rg.double(), rb.double(), 1e-5)
-    ref = (y @ w.double().t() + b.double()).clamp_min(0) + res
-    wf, s, bf = N.layernorm_fold(w.to(dev), gam.to(dev), bet.to(dev), b.to(dev))
-    out = N.linear_ln(z, wf, s=s, bias=bf, a_part=zpart, relu=True)                 # consumer with A pre-norm
-    assert max_abs_diff(out, (y @ w.double().t() + b.double()).clamp_min(0)) < 5e-5
-    if N_ <= 1024:   # a pre-norm operand's LayerNorm width is limited to 1024 (64 partials per row)
-        out2, part2 = N.linear_ln(y.float().to(dev), w.to(dev), bias=b.to(dev), residual=zprev, r_part=zprev_part,
-                                  r_gamma=rg.to(dev), r_beta=rb.to(dev), want_part=True)  # R pre-norm + producer
-        ref2 = y.float().double() @ w.double().t() + b.double() + res
-        assert max_abs_diff(out2, ref2) < 5e-5
-        assert max_abs_diff(part2.sum(1)[:, 0], out2.double().sum(1)) < 2e-3
-    # deterministic and independent of the rows around it (batch invariance across tile configurations)
-    m3 = max(1, M // 3)
-    z3, zp3 = N.linear_ln(x0[:m3].to(dev), w0.to(dev), bias=b0.to(dev), want_part=True)
-    assert torch.equal(z3, z[:m3]) and torch.equal(zp3, zpart[:m3])
-    out3 = N.linear_ln(z3, wf, s=s, bias=bf, a_part=zp3, relu=True)
-    assert torch.equal(out3, out[:m3])
-
-
-@pytest.mark.parametrize('name', sorted(CONFIGS))
-def test_deferred_layernorm_forward_vs_oracle(dev, name):
-    """LAMP.fuse_layernorm: 7 of 10 LayerNorm launches elided (folded into the consuming GEMMs); logits and enc_output
-    against the oracle at BASELINE sizes, agreement with the plain path to rounding, sample independence."""
-    m, sd, blocked, seq, spos, h = make_case(CONFIGS[name], dev)
-    src = (seq.to(dev), spos.to(dev))
-    with torch.no_grad():
-        ref_logits, ref_enc, _ = R.forward(sd, seq, spos, h, blocked)
-        plain, enc_plain, _ = m(src, None, None, None)
-        m.fuse_layernorm = True
-        logits, enc, _ = m(src, None, None, None)
-        assert max_abs_diff(enc, ref_enc) < TOL_ACT
-        assert max_abs_diff(logits, ref_logits) < TOL_LOGIT
-        assert max_abs_diff(logits, plain) < 2e-5
-        # a sample's bits do not depend on the batch it is in, nor on the micro-batch split
-        one, _, _ = m((src[0][:1], src[1][:1]), None, None, None)
-        assert torch.equal(one, logits[:1])
-        m.workspace_limit_bytes = 1
-        split, _, _ = m(src, None, None, None)
-        assert torch.equal(split, logits)
-        # auxiliary outputs fall back to the plain path
-        ip = m(src, None, None, None, int_preds=True)
-        assert torch.equal(ip[0], plain)
-
-
-def test_deferred_layernorm_tracks_weight_updates(dev):
-    m, sd, blocked, seq, spos, h = make_case(CONFIGS['inveye_8h'], dev)
-    m.fuse_layernorm = True
-    src = (seq.to(dev), spos.to(dev))
-    with torch.no_grad():
-        a, _, _ = m(src, None, None, None)
-        m.decoder.layer_stack[0].pos_ffn1.layer_norm.weight.mul_(1.5)     # folded into slf_attn's projections
-        m.decoder.layer_stack[1].pos_ffn1.w_1.weight.add_(0.01)
-        b, _, _ = m(src, None, None, None)
-        m.fuse_layernorm = False
-        c, _, _ = m(src, None, None, None)
-    assert not torch.equal(a, b)
-    assert max_abs_diff(b, c) < 2e-5

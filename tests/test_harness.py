@@ -1,10 +1,12 @@
 """Eval harness either side of the hot path against golden/harness.npz, which holds what
 the reference's process_data / DataLoader / test_epoch produced on a synthetic dataset."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, max_abs_diff
+from conftest import GOLDEN, load_golden, max_abs_diff
 from oracle import lamp_ref as oracle
 from lamp_amd import data as D
 
@@ -110,6 +112,34 @@ def test_multilabel_metrics_known_values():
     assert abs(m['hamming_accuracy'] - 7 / 9) < 1e-6
     assert abs(m['micro_f1'] - 2 * 3 / (2 * 3 + 1 + 1)) < 1e-6
     assert abs(m['example_f1'] - (1.0 + 2 / 3 + 0.0) / 3) < 1e-6
+
+
+def test_multilabel_metrics_match_reference_evals():
+    """run_eval.multilabel_metrics vs the reference's own utils/evals.py:compute_metrics (tests/golden/evals.npz, made by
+    make_golden_evals.py): empty samples are dropped from example-F1, never-seen labels from macro-F1."""
+    import numpy as np
+    from lamp_amd.run_eval import multilabel_metrics
+    z = np.load(os.path.join(GOLDEN, 'evals.npz'))
+    for i in range(int(z['n_cases'])):
+        m = multilabel_metrics(torch.from_numpy(z['pred_%d' % i]), torch.from_numpy(z['tgt_%d' % i]), 0.5)
+        got = [m['subset_accuracy'], m['hamming_accuracy'], m['example_f1'], m['micro_f1'], m['macro_f1']]
+        for a, b in zip(got, z['ref_%d' % i].tolist()):
+            assert abs(a - b) < 1e-6, (i, got, z['ref_%d' % i])
+
+
+def test_dataparallel_checkpoint_keys_load(fx, tmp_path):
+    """main.py:106-108 wraps the model in nn.DataParallel before utils.save_model on multi-GPU hosts: the checkpoint's
+    keys then carry a `module.` prefix.  run_eval's loader + LAMP.load_state_dict accept both forms."""
+    from lamp_amd import run_eval
+    from test_host_cpu import build_from_fixture
+    m, d, sd = build_from_fixture('model_prior_pos1_h4')
+    torch.save({'model': {'module.' + k: v for k, v in sd.items()}, 'epoch': 1}, tmp_path / 'dp.chkpt')
+    state = run_eval.load_checkpoint_state(str(tmp_path / 'dp.chkpt'))
+    assert all(k.startswith('module.') for k in state)
+    res = m.load_state_dict(state)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
 
 
 @pytest.mark.gpu

@@ -4,6 +4,7 @@ construction), and the product refuses -- loudly -- to run anywhere but on a HIP
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 import torch
@@ -29,7 +30,13 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(N.PROTOTYPES) == names  # the ctypes binding covers the whole header
-    assert N.lib().lamp_version() == 1
+    assert N.lib().lamp_version() == N.ABI_VERSION == 2
+    # the product library exports no tuning / debug hook (those live in the -DLAMP_TUNING build only)
+    exported = subprocess.run(['nm', '-D', '--defined-only', N.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'lamp_debug' not in exported and 'lamp_set_forward_streams' not in exported
+    assert sorted(set(re.findall(r' T (lamp_[a-z0-9_]+)', exported))) == names  # ... and nothing the header does not declare
+    tuned = subprocess.run(['nm', '-D', '--defined-only', N.TUNING_LIB_PATH], capture_output=True, text=True).stdout
+    assert 'lamp_debug_force_gemm_tile' in tuned and 'lamp_debug_force_attn' in tuned
     assert b'workspace' in N.lib().lamp_strerror(-3)
 
 
@@ -41,8 +48,7 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(N.FfnWeights) == 48
     assert ctypes.sizeof(N.EncLayer) == 104
     assert ctypes.sizeof(N.DecLayer) == 208
-    assert ctypes.sizeof(N.Model) == 128
-    assert ctypes.sizeof(N.FusedLnDecLayer) == 144 and ctypes.sizeof(N.FusedLnEncLayer) == 24
+    assert ctypes.sizeof(N.Model) == 120
     assert ctypes.sizeof(N.Aux) == 40
     assert ctypes.sizeof(N.GemmDesc) == 160
 

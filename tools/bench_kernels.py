@@ -10,7 +10,10 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the -DLAMP_TUNING build of the library: the only one that exports the lamp_debug_* hooks used below
+os.environ.setdefault('LAMP_HIP_LIBRARY', os.path.join(ROOT, 'lamp_amd', 'liblamp_hip_tuning.so'))
 from lamp_amd import _native as N  # noqa: E402
 
 TILES = {0: 'heuristic', 1: '128x128x32', 2: '64x64x32', 3: '128x64x32', 4: '64x128x32', 5: '128x128x16',
@@ -180,7 +183,8 @@ def sparse():
 def attn():
     dev = torch.device('cuda:0')
     cases = [('reuters enc-attn', 32, 4, 90, 302, 128), ('reuters self', 32, 4, 90, 90, 128),
-             ('bibtex self', 32, 4, 159, 159, 128), ('delicious self', 32, 8, 983, 983, 128),
+             ('bibtex enc-attn', 32, 4, 159, 100, 128), ('bibtex self', 32, 4, 159, 159, 128),
+             ('delicious self', 32, 8, 983, 983, 128),
              ('synthetic self', 4, 8, 4096, 4096, 128), ('synthetic enc', 4, 8, 4096, 512, 128)]
     for name, B, H, lq, lk, dk in cases:
         q = torch.randn(B, lq, H * dk, device=dev)
@@ -194,7 +198,11 @@ def attn():
         force = N.lib().lamp_debug_force_attn
         force.argtypes = [ctypes.c_int]
         for mode in (0, 1, 2, 4):  # 0 = heuristic, else forced key split
-          for mname, ms in (('none', None), ('shared-u8', N.Mask(N.LAMP_MASK_U8, 0, mask.data_ptr(), 0, lk))):
+          bits = N.pack_mask_bits(mask).to(dev)
+          toks = (torch.rand(B, lk, device=dev) < 0.9).long()
+          for mname, ms in (('none', None), ('shared-u8', N.Mask(N.LAMP_MASK_U8, 0, mask.data_ptr(), 0, lk)),
+                            ('shared-bits', N.Mask(N.LAMP_MASK_BITS_U32, 0, bits.data_ptr(), 0, bits.size(1))),
+                            ('key-tokens', N.Mask(N.LAMP_MASK_KEY_TOKENS_I64, 0, toks.data_ptr(), lk, 0))):
             force(mode)
 
             def fn():
@@ -208,6 +216,60 @@ def attn():
             print('%-20s mode=%d mask=%-10s %9.1f us  %6.1f TFLOP/s' % (name, mode, mname, us, fl / us / 1e6))
 
 
+def gemm_trace():
+    """Per-workgroup timeline of the GEMM launches of ONE reuters forward (in situ: every launch runs behind its real
+    predecessor), from the wall_clock64 stamps the tuning build records at kernel entry, after the prologue (first
+    tile staged, two more in flight), after the main loop and at exit.  Prints, per launch: grid, span (first entry ->
+    last exit), how the workgroups' start times spread, and the median / max length of the three phases."""
+    import statistics
+    sys.path.insert(0, ROOT)
+    import bench
+    lib = N.lib()
+    hook = lib.lamp_debug_set_gemm_trace
+    hook.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int]
+    hook.restype = None
+    dev = torch.device('cuda:0')
+    wl = sys.argv[2] if len(sys.argv) > 2 else 'reuters'
+    w = dict(bench.WORKLOADS[wl])
+    model, sd, adj, seq, pos = bench.build(w, 32, dev)
+    src = (seq.to(dev), pos.to(dev))
+    for _ in range(50):
+        model(src, None, None, None)
+    torch.cuda.synchronize()
+    slab, n_slabs = 8 * 8192, 32
+    buf = torch.zeros(slab * n_slabs, dtype=torch.int64, device=dev)
+    hook(buf.data_ptr(), slab, n_slabs)
+    model(src, None, None, None)
+    torch.cuda.synchronize()
+    hook(None, 0, 0)
+    t = buf.cpu().view(n_slabs, -1, 8)
+    tick_ns = 10.0  # wall_clock64: 100 MHz constant clock
+    print('# %s, batch 32: GEMM launches of one forward; times in us (wall_clock64, %g ns ticks)' % (wl, tick_ns))
+    print('%3s %6s %8s | %-26s | %-17s %-17s %-17s | %s' % ('#', 'WGs', 'span', 'WG start: p50 p90 max', 'prologue p50 max',
+                                                          'main loop p50 max', 'epilogue p50 max', 'WGs/CU max, CUs used'))
+    for i in range(n_slabs):
+        rows = t[i][t[i][:, 3] != 0]
+        if rows.numel() == 0:
+            continue
+        t0 = rows[:, 0].min().item()
+        us = lambda x: (x - t0) * tick_ns / 1e3  # noqa: E731
+        start = sorted(us(v) for v in rows[:, 0].tolist())
+        ph = [sorted(((rows[:, j + 1] - rows[:, j]).double() * tick_ns / 1e3).tolist()) for j in range(3)]
+        span = us(rows[:, 3].max().item())
+        hw = rows[:, 4].tolist()
+        xcc = rows[:, 5].tolist()
+        # HW_ID (gfx9): wave_id[3:0] simd_id[5:4] pipe_id[7:6] cu_id[11:8] sh_id[12] se_id[15:13]; XCC_ID[3:0]
+        cu = [((x & 0xf), (h >> 13) & 7, (h >> 12) & 1, (h >> 8) & 0xf) for h, x in zip(hw, xcc)]
+        per_cu = {}
+        for c in cu:
+            per_cu[c] = per_cu.get(c, 0) + 1
+        q = lambda a, f: a[min(len(a) - 1, int(f * len(a)))]  # noqa: E731
+        print('%3d %6d %8.2f | %7.2f %7.2f %7.2f    | %7.2f %7.2f   %7.2f %7.2f   %7.2f %7.2f   | %d, %d' %
+              (i, len(start), span, q(start, 0.5), q(start, 0.9), start[-1], q(ph[0], 0.5), ph[0][-1], q(ph[1], 0.5),
+               ph[1][-1], q(ph[2], 0.5), ph[2][-1], max(per_cu.values()), len(per_cu)))
+
+
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
-    {'gemm': gemm, 'gemm_ab': gemm_ab, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse}[which]()
+    {'gemm': gemm, 'gemm_ab': gemm_ab, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
+     'gemm_trace': gemm_trace}[which]()
