@@ -427,7 +427,8 @@ __global__ __launch_bounds__(256) void softmax_from_scores_kernel(float* __restr
 }
 
 #ifdef LAMP_TUNING
-// Tuning build only (liblamp_hip_tuning.so): 0 = heuristic, 1/2/4 = force that key split.
+// Tuning build only (liblamp_hip_tuning.so): 0 = heuristic; bits 0-2: force that key split (1/2/4); bits 4-6: query
+// blocks per workgroup of the small-shape kernel (attention_small.hip).
 static int g_force_attn = 0;
 extern "C" void lamp_debug_force_attn(int v) { g_force_attn = v; }
 #else
@@ -461,7 +462,7 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     const int nt = (p.lk + 31) / 32;
     if (p.tiles && (p.m_sb != 0 || (p.mask_kind != LAMP_MASK_U8 && p.mask_kind != LAMP_MASK_BITS_U32)))
         return LAMP_E_UNSUPPORTED;  // the sparsity hint belongs to shared masks
-    int ksplit = g_force_attn;
+    int ksplit = g_force_attn & 7;
     if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = (p.lq <= 128 && nt >= 3) ? 2 : 1;
     if (ksplit == 4 && p.lse) ksplit = 2;
     int rc;

@@ -6,11 +6,12 @@
 // heads 384 blocks x 2 key halves = 768 waves of ~20 us for 1024 SIMDs: a quarter of the chip idle, the rest running
 // ONE wave per SIMD with nothing to cover its softmax and load latencies (round 1: 0.26 of the fp32-MFMA peak).
 // Here the unit is a 16-query x 16-key block (64 MFMAs of 32 cycles = 2048 cycles at d_k = d_v = 128):
-//   * a wave owns ONE 16-query block and a share of its key tiles; a workgroup = 4 waves = QB query blocks x KSPLIT
-//     key shares (merged lane-locally through LDS at the end).  reuters enc-dec (90 x 302): 768 workgroups, 3072 waves
-//     of 4-5 tiles -- three waves per SIMD, so one wave's exp2 / loads overlap another's MFMAs.
-//   * Q never touches LDS: with 16x16x4 the B operand of S^T = K Q^T is 32 registers per lane at d_k = 128 (the 32x32x2
-//     layout would need 64), loaded once, pre-scaled by log2(e)/temperature.
+//   * a wave owns ONE 16-query block and a share of its key tiles; a workgroup = QB query blocks x KSPLIT key shares
+//     (merged lane-locally through LDS at the end).  reuters enc-dec (90 x 302): 3072 waves of 4-5 tiles -- three waves
+//     per SIMD, so one wave's exp2 / loads overlap another's MFMAs.
+//   * the Q block (16 x d_k, pre-scaled by log2(e)/temperature) sits in LDS and is re-read per key tile as b128
+//     fragments: keeping it in registers (32 per lane at d_k = 128) put the kernel at 212 registers = two waves per
+//     SIMD; from LDS it fits three, and all 768 workgroups of the reuters shape are resident at once.
 //   * both products are TRANSPOSED as in attention.hip, so the query sits on the lane (column = lane & 15) in both
 //     accumulators and register r of S^T (key 4*(lane>>4) + r) is directly the B operand of PV step r.
 //   * row statistics: a lane sees 4 of a tile's 16 keys.  The running maximum must agree across the four lane groups of
@@ -35,11 +36,15 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // PM = 0: O only.  PM = 2: additionally the scaled scores (log2 domain, -inf where blocked) into the map buffer and each
 // row's log2-sum-exp into lse; softmax_from_scores_kernel (attention.hip) then normalises in place.
-template <int DP, int KSPLIT, int PM, int MK>
-__global__ __launch_bounds__(256) void attn16_kernel(AttnParams p) {
+// A workgroup = QB query blocks x KSPLIT key shares = QB * KSPLIT waves (4 .. 12): the QB waves that hold the same key
+// share walk the same K / V tiles in step, so all but the first of them find the tile in the CU's L1 -- with one query
+// block per workgroup every wave pulled its own 16 KB per tile from L2 and the kernel sat on the L2 -> L1 path
+// (reuters enc-dec: 28 us against 15 us of MFMA issue).
+template <int DP, int QB, int KSPLIT, int PM, int MK>
+__global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p) {
     constexpr int DKC = DP / 16;   // 16-wide k chunks of the QK^T product (one b128 fragment each)
     constexpr int DV8 = DP / 16;   // floats of a V row per lane = number of 16-row blocks of O^T
-    constexpr int QB = 4 / KSPLIT;
+    constexpr int QS = DP + 4;     // LDS row stride of the Q block (floats)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -74,14 +79,24 @@ __global__ __launch_bounds__(256) void attn16_kernel(AttnParams p) {
             ? make_rsrc(static_cast<const long long*>(p.mask) + int64_t(b) * p.m_sb, uint64_t(p.lk) * 8u)
             : make_rsrc(p.K, 0);
 
-    // ---- Q fragments: lane (query l15, group g) holds Q[q][16c + 4g + j], pre-scaled ----
-    float4 qf[DKC];
+    // ---- Q block -> LDS (pre-scaled); the KSPLIT waves of a block share the copy work ----
+    float* Qs = smem + qb * 16 * QS;
+    {
+        constexpr int C4 = DP / 4;
+        constexpr int PER_WAVE = 16 * C4 / KSPLIT;  // float4 per wave
 #pragma unroll
-    for (int c = 0; c < DKC; ++c) {
-        const int col = 16 * c + 4 * g;
-        const float4 v = bload4(rsQ, (qi < p.lq && col < p.dk) ? unsigned(qi * q_r + col) * 4u : OOB, 0);
-        qf[c] = make_float4(v.x * p.scale_log2e, v.y * p.scale_log2e, v.z * p.scale_log2e, v.w * p.scale_log2e);
+        for (int i = 0; i < (PER_WAVE + 63) / 64; ++i) {
+            const int idx = ks * PER_WAVE + i * 64 + lane;
+            const int row = idx / C4, c = (idx - row * C4) * 4;
+            const int q = q0 + row;
+            if (i * 64 + lane < PER_WAVE) {
+                const float4 v = bload4(rsQ, (q < p.lq && c < p.dk) ? unsigned(q * q_r + c) * 4u : OOB, 0);
+                *reinterpret_cast<float4*>(Qs + row * QS + c) =
+                    make_float4(v.x * p.scale_log2e, v.y * p.scale_log2e, v.z * p.scale_log2e, v.w * p.scale_log2e);
+            }
+        }
     }
+    __syncthreads();
 
     const int nt = (p.lk + 15) / 16;
     float4 kf[DKC];
@@ -137,16 +152,19 @@ __global__ __launch_bounds__(256) void attn16_kernel(AttnParams p) {
     // is 40 cycles against 32 of issue), then -inf where blocked / past lk.
     auto scores = [&](int kt, f32x4& s) {
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        const float* qp = Qs + l15 * QS + 4 * g;   // lane (query l15, group g): Q[q][16c + 4g + j]
 #pragma unroll
         for (int c = 0; c < DKC; c += 2) {
-            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].x, qf[c].x, s0, 0, 0, 0);
-            if (c + 1 < DKC) s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].x, qf[c + 1].x, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].y, qf[c].y, s0, 0, 0, 0);
-            if (c + 1 < DKC) s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].y, qf[c + 1].y, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].z, qf[c].z, s0, 0, 0, 0);
-            if (c + 1 < DKC) s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].z, qf[c + 1].z, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].w, qf[c].w, s0, 0, 0, 0);
-            if (c + 1 < DKC) s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].w, qf[c + 1].w, s1, 0, 0, 0);
+            const float4 qa = *reinterpret_cast<const float4*>(qp + 16 * c);
+            const float4 qb2 = *reinterpret_cast<const float4*>(qp + 16 * c + 16);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].x, qa.x, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].x, qb2.x, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].y, qa.y, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].y, qb2.y, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].z, qa.z, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].z, qb2.z, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].w, qa.w, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].w, qb2.w, s1, 0, 0, 0);
         }
         const int kbase = kt * 16 + 4 * g;
 #pragma unroll
@@ -172,6 +190,9 @@ __global__ __launch_bounds__(256) void attn16_kernel(AttnParams p) {
             const int kn = kt + KSPLIT;   // past the end: range-checked zeros
             f32x4 s;
             scores(kt, s);
+            // pin the order "MFMAs of this tile, THEN the next tile's loads into the registers they just freed": hoisted
+            // above the MFMAs the loads need a second register set (K and V double-buffered = +64 VGPRs, spills at 3 waves)
+            __builtin_amdgcn_sched_barrier(0);
             load_k(kn);      // flies under softmax + PV
             load_mask(kn);
             if constexpr (PM == 2) {
@@ -202,25 +223,25 @@ __global__ __launch_bounds__(256) void attn16_kernel(AttnParams p) {
 #pragma unroll
                 for (int e = 0; e < DV8; ++e)
                     o[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r][e], s[r], o[e], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             load_v(kn);      // flies under the next QK^T
         }
     }
 
     if constexpr (KSPLIT > 1) {
         // ---- merge the KSPLIT partial results of each query block (lane-local positions, fixed order) ----
-        constexpr int CW = (DV8 * 4 + 2) * 64;  // floats per wave: o registers, m, l -- one 64-float row each
+        constexpr int CW = (DV8 * 4 + 4) * 64;  // floats per wave: o blocks as float4 per lane, then (m, l, -, -) per lane
+        __syncthreads();                        // every wave is done reading its Q block: the region is reused
         float* mine = smem + wave * CW;
 #pragma unroll
         for (int e = 0; e < DV8; ++e)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mine[(e * 4 + r) * 64 + lane] = o[e][r];
-        mine[(DV8 * 4) * 64 + lane] = m_run;
-        mine[(DV8 * 4 + 1) * 64 + lane] = l_part;
+            *reinterpret_cast<float4*>(mine + (e * 64 + lane) * 4) = make_float4(o[e][0], o[e][1], o[e][2], o[e][3]);
+        *reinterpret_cast<float4*>(mine + (DV8 * 64 + lane) * 4) = make_float4(m_run, l_part, 0.f, 0.f);
         __syncthreads();
         if (ks == 0 && wave_active) {
             float m_all = m_run;
 #pragma unroll
-            for (int s2 = 1; s2 < KSPLIT; ++s2) m_all = fmaxf(m_all, smem[(wave + s2) * CW + (DV8 * 4) * 64 + lane]);
+            for (int s2 = 1; s2 < KSPLIT; ++s2) m_all = fmaxf(m_all, smem[(wave + s2) * CW + (DV8 * 64 + lane) * 4]);
             const float m_use = (m_all == -INFINITY) ? 0.f : m_all;
             const float w0 = exp2f(m_run - m_use);
             l_part *= w0;
@@ -231,12 +252,17 @@ __global__ __launch_bounds__(256) void attn16_kernel(AttnParams p) {
 #pragma unroll
             for (int s2 = 1; s2 < KSPLIT; ++s2) {
                 const float* other = smem + (wave + s2) * CW;
-                const float ws = exp2f(other[(DV8 * 4) * 64 + lane] - m_use);
-                l_part = fmaf(other[(DV8 * 4 + 1) * 64 + lane], ws, l_part);  // explicit fma: same bits in every variant
+                const float4 ml = *reinterpret_cast<const float4*>(other + (DV8 * 64 + lane) * 4);
+                const float ws = exp2f(ml.x - m_use);
+                l_part = fmaf(ml.y, ws, l_part);  // explicit fma: same bits in every variant
 #pragma unroll
-                for (int e = 0; e < DV8; ++e)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[e][r] = fmaf(other[(e * 4 + r) * 64 + lane], ws, o[e][r]);
+                for (int e = 0; e < DV8; ++e) {
+                    const float4 v = *reinterpret_cast<const float4*>(other + (e * 64 + lane) * 4);
+                    o[e][0] = fmaf(v.x, ws, o[e][0]);
+                    o[e][1] = fmaf(v.y, ws, o[e][1]);
+                    o[e][2] = fmaf(v.z, ws, o[e][2]);
+                    o[e][3] = fmaf(v.w, ws, o[e][3]);
+                }
             }
             m_run = m_all;
         }
@@ -273,35 +299,54 @@ __global__ __launch_bounds__(256) void attn16_kernel(AttnParams p) {
     }
 }
 
-template <int DP, int KSPLIT, int PM, int MK>
+template <int DP, int QB, int KSPLIT, int PM, int MK>
 static int launch_small_mk(const AttnParams& p, hipStream_t s) {
-    constexpr int QB = 4 / KSPLIT;
-    constexpr size_t lds = KSPLIT > 1 ? size_t(4) * (DP / 16 * 4 + 2) * 64 * sizeof(float) : 0;
-    static_assert(lds <= 65536, "merge scratch fits the default LDS limit");
+    constexpr int NW = QB * KSPLIT;
+    constexpr size_t lds_q = size_t(QB) * 16 * (DP + 4) * sizeof(float);
+    constexpr size_t lds_c = KSPLIT > 1 ? size_t(NW) * (DP / 16 * 4 + 4) * 64 * sizeof(float) : 0;
+    constexpr size_t lds = lds_q > lds_c ? lds_q : lds_c;
+    auto kern = attn16_kernel<DP, QB, KSPLIT, PM, MK>;
+    if constexpr (lds > 65536) {
+        static AttrOnce once;
+        if (int e = once.set(reinterpret_cast<const void*>(kern), lds)) return e;
+    }
     const int64_t nwg = int64_t((p.lq + 16 * QB - 1) / (16 * QB)) * p.H * p.B;
     if (nwg > 0x7fffffffLL) return LAMP_E_DIMS;
-    hipLaunchKernelGGL((attn16_kernel<DP, KSPLIT, PM, MK>), dim3(unsigned(nwg)), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(unsigned(nwg)), dim3(NW * 64), lds, s, p);
     return int(hipGetLastError());
 }
 
-template <int DP, int KSPLIT, int PM>
+template <int DP, int QB, int KSPLIT, int PM>
 static int launch_small_ks(const AttnParams& p, hipStream_t s) {
     switch (p.mask_kind) {
-        case LAMP_MASK_U8: return launch_small_mk<DP, KSPLIT, PM, LAMP_MASK_U8>(p, s);
-        case LAMP_MASK_KEY_TOKENS_I64: return launch_small_mk<DP, KSPLIT, PM, LAMP_MASK_KEY_TOKENS_I64>(p, s);
-        case LAMP_MASK_BITS_U32: return launch_small_mk<DP, KSPLIT, PM, LAMP_MASK_BITS_U32>(p, s);
-        default: return launch_small_mk<DP, KSPLIT, PM, LAMP_MASK_NONE>(p, s);
+        case LAMP_MASK_U8: return launch_small_mk<DP, QB, KSPLIT, PM, LAMP_MASK_U8>(p, s);
+        case LAMP_MASK_KEY_TOKENS_I64: return launch_small_mk<DP, QB, KSPLIT, PM, LAMP_MASK_KEY_TOKENS_I64>(p, s);
+        case LAMP_MASK_BITS_U32: return launch_small_mk<DP, QB, KSPLIT, PM, LAMP_MASK_BITS_U32>(p, s);
+        default: return launch_small_mk<DP, QB, KSPLIT, PM, LAMP_MASK_NONE>(p, s);
     }
 }
 
+template <int DP, int QB, int KSPLIT>
+static int launch_small_pm(const AttnParams& p, hipStream_t s) {
+    return p.lse ? launch_small_ks<DP, QB, KSPLIT, 2>(p, s) : launch_small_ks<DP, QB, KSPLIT, 0>(p, s);
+}
+
 template <int DP>
-static int launch_small_dp(const AttnParams& p, int ksplit, hipStream_t s) {
-    if (p.lse) {
-        if (ksplit == 4) return launch_small_ks<DP, 4, 2>(p, s);
-        return ksplit == 2 ? launch_small_ks<DP, 2, 2>(p, s) : launch_small_ks<DP, 1, 2>(p, s);
+static int launch_small_dp(const AttnParams& p, int qb, int ksplit, hipStream_t s) {
+    switch (qb * 8 + ksplit) {
+        case 1 * 8 + 1: return launch_small_pm<DP, 4, 1>(p, s);   // one key share: always four query blocks per workgroup
+        case 2 * 8 + 1: return launch_small_pm<DP, 4, 1>(p, s);
+        case 3 * 8 + 1: return launch_small_pm<DP, 4, 1>(p, s);
+        case 4 * 8 + 1: return launch_small_pm<DP, 4, 1>(p, s);
+        case 1 * 8 + 2: return launch_small_pm<DP, 2, 2>(p, s);   // at least four waves per workgroup
+        case 2 * 8 + 2: return launch_small_pm<DP, 2, 2>(p, s);
+        case 3 * 8 + 2: return launch_small_pm<DP, 3, 2>(p, s);
+        case 4 * 8 + 2: return launch_small_pm<DP, 4, 2>(p, s);
+        case 1 * 8 + 4: return launch_small_pm<DP, 1, 4>(p, s);
+        case 2 * 8 + 4: return launch_small_pm<DP, 2, 4>(p, s);
+        case 3 * 8 + 4: return launch_small_pm<DP, 3, 4>(p, s);
+        default: return launch_small_pm<DP, 2, 4>(p, s);           // 4 x 4 = 16 waves do not fit three per SIMD
     }
-    if (ksplit == 4) return launch_small_ks<DP, 4, 0>(p, s);
-    return ksplit == 2 ? launch_small_ks<DP, 2, 0>(p, s) : launch_small_ks<DP, 1, 0>(p, s);
 }
 
 // The shapes this kernel takes (a function of the per-sample shape ONLY): at most 256 queries, with V and O given and
@@ -312,17 +357,30 @@ bool attn_small_applies(const AttnParams& p) {
     return p.lq <= 256 && p.V && p.O && (!p.P || p.lse) && dmax <= 128 && (dmax <= 64 || (p.dv & 7) == 0);
 }
 
-// force_ksplit: 0 = heuristic (tuning build may force 1 / 2 / 4).
-int launch_attn_small(const AttnParams& p, int force_ksplit, hipStream_t s) {
+// force: 0 = heuristic; else (tuning build) key shares in bits 0-2, query blocks per workgroup in bits 4-6.
+int launch_attn_small(const AttnParams& p, int force, hipStream_t s) {
     const int nt = (p.lk + 15) / 16;
+    const int nqb = (p.lq + 15) / 16;
     // 16-key tiles per wave: 4-way split from 8 tiles on, 2-way from 4 (reuters enc-dec 19 tiles -> 4; its 90-label
     // self-attention 6 -> 2; bibtex 10 / 7 -> 4 / 2)
-    int ksplit = force_ksplit;
+    int ksplit = force & 7;
     if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = nt >= 8 ? 4 : (nt >= 4 ? 2 : 1);
+    // query blocks per workgroup: the largest of 3, 2 (, 4 with two key shares) that pads the query blocks least
+    int qb = (force >> 4) & 7;
+    if (qb < 1 || qb > 4) {
+        int best_pad = 1 << 30;
+        for (int c = (ksplit == 4 ? 3 : 4); c >= 1; --c) {
+            const int pad = (nqb + c - 1) / c * c - nqb;
+            if (pad < best_pad) {
+                best_pad = pad;
+                qb = c;
+            }
+        }
+    }
     const int dmax = p.dk > p.dv ? p.dk : p.dv;
-    if (dmax <= 32) return launch_small_dp<32>(p, ksplit, s);
-    if (dmax <= 64) return launch_small_dp<64>(p, ksplit, s);
-    return launch_small_dp<128>(p, ksplit, s);
+    if (dmax <= 32) return launch_small_dp<32>(p, qb, ksplit, s);
+    if (dmax <= 64) return launch_small_dp<64>(p, qb, ksplit, s);
+    return launch_small_dp<128>(p, qb, ksplit, s);
 }
 
 }  // namespace lamp

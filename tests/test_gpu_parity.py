@@ -130,7 +130,7 @@ def test_sdpa_vs_oracle_shapes(dev, lq, lk, dk):
     assert max_abs_diff(o2, ref_o) < 2e-5
 
 
-@pytest.mark.parametrize('mode', [1, 2, 4])
+@pytest.mark.parametrize('mode', [1, 2, 4, 0x12, 0x22, 0x32, 0x42, 0x14, 0x24, 0x34, 0x41])
 @pytest.mark.parametrize('lq,lk,dk', [(90, 302, 128), (70, 33, 64), (200, 513, 32), (5, 1, 16), (300, 130, 128), (260, 40, 24)])
 def test_sdpa_every_kernel_variant(dev, tuning, mode, lq, lk, dk):
     """The attention kernels (16-query blocks up to 256 queries, 32-query blocks beyond and for exact maps) with

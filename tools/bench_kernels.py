@@ -197,12 +197,15 @@ def attn():
                            lq * H * dk, dk, H * dk)
         force = N.lib().lamp_debug_force_attn
         force.argtypes = [ctypes.c_int]
-        for mode in (0, 1, 2, 4):  # 0 = heuristic, else forced key split
+        small = lq <= 256
+        # 0 = heuristic; bits 0-2 forced key split, bits 4-6 query blocks per workgroup (small-shape kernel)
+        for mode in ((0, 0x14, 0x24, 0x34, 0x12, 0x22, 0x32, 0x42, 0x41) if small else (0, 1, 2, 4)):
           bits = N.pack_mask_bits(mask).to(dev)
           toks = (torch.rand(B, lk, device=dev) < 0.9).long()
-          for mname, ms in (('none', None), ('shared-u8', N.Mask(N.LAMP_MASK_U8, 0, mask.data_ptr(), 0, lk)),
-                            ('shared-bits', N.Mask(N.LAMP_MASK_BITS_U32, 0, bits.data_ptr(), 0, bits.size(1))),
-                            ('key-tokens', N.Mask(N.LAMP_MASK_KEY_TOKENS_I64, 0, toks.data_ptr(), lk, 0))):
+          masks = (('none', None), ('shared-u8', N.Mask(N.LAMP_MASK_U8, 0, mask.data_ptr(), 0, lk)),
+                   ('shared-bits', N.Mask(N.LAMP_MASK_BITS_U32, 0, bits.data_ptr(), 0, bits.size(1))),
+                   ('key-tokens', N.Mask(N.LAMP_MASK_KEY_TOKENS_I64, 0, toks.data_ptr(), lk, 0)))
+          for mname, ms in (masks if mode == 0 else masks[2:]):
             force(mode)
 
             def fn():
@@ -213,7 +216,7 @@ def attn():
             us = time_fn(fn, iters=10)
             force(0)
             fl = 4.0 * B * H * lq * lk * dk
-            print('%-20s mode=%d mask=%-10s %9.1f us  %6.1f TFLOP/s' % (name, mode, mname, us, fl / us / 1e6))
+            print('%-20s mode=%02x mask=%-10s %9.1f us  %6.1f TFLOP/s' % (name, mode, mname, us, fl / us / 1e6))
 
 
 def gemm_trace():
