@@ -9,8 +9,9 @@ the device as uint8 and broadcast over batch and heads by the kernel, instead of
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
-from . import utils
+from . import Constants, utils
 from . import _native as N
 from .Layers import DecoderLayer
 from .SubLayers import _eval_only
@@ -37,9 +38,7 @@ class GraphDecoder(nn.Module):
                  no_dec_self_att=False, label_adj_matrix=None, label_mask=None, enc_vec=True,
                  graph_conv=False, attn_type='softmax'):
         super().__init__()
-        if enc_vec:
-            raise NotImplementedError('vector encoders (mlp / enc_transform) are outside the hot path')
-        self.enc_vec = enc_vec
+        self.enc_vec = enc_vec   # the encoder hands over ONE vector per sample (mlp / enc_transform): no key-padding mask
         self.dropout = nn.Dropout(dropout)
         self.constant_input = torch.from_numpy(np.arange(n_tgt_vocab)).view(-1, 1)
         self.tgt_word_emb = nn.Embedding(n_tgt_vocab, d_word_vec)
@@ -78,7 +77,8 @@ class GraphDecoder(nn.Module):
         B = src_seq.size(0)
         T = enc_output.size(1)
         y = self.tgt_word_emb.weight.unsqueeze(0).expand(B, -1, -1).contiguous()
-        pad_mask, keep = N.key_token_mask(src_seq[:, :T], T)
+        # lamp/Decoders.py:136-138: with a vector encoder there is nothing to pad-mask
+        pad_mask, keep = (None, None) if self.enc_vec else N.key_token_mask(src_seq[:, :T], T)
         label_mask = self.label_mask_struct()
         int_outs, slf_attns, enc_attns = [], [], []
         for layer in self.layer_stack:
@@ -100,12 +100,95 @@ class GraphDecoder(nn.Module):
 
 
 class MLPDecoder(nn.Module):
-    def __init__(self, *args, **kwargs):
+    """Binary-relevance baseline (lamp/Decoders.py:76-93): Linear -> ReLU -> Dropout -> Linear over the encoder's
+    vector; returns ((B, 1, n_tgt_vocab),).  Plain PyTorch, parameter names as in the reference."""
+
+    def __init__(self, n_tgt_vocab, n_max_seq_e, n_max_seq_d, n_layers=6, n_head=8, d_k=64, d_v=64, d_word_vec=512,
+                 d_model=512, d_inner_hid=1024, dropout=0.1, enc_transform='mean'):
         super().__init__()
-        raise NotImplementedError("decoder='mlp' is a baseline model outside the label-graph hot path")
+        self.n_max_seq = n_max_seq_e
+        self.d_model = d_model
+        self.dropout = nn.Dropout(dropout)
+        self.enc_transform = enc_transform
+        if enc_transform in ['flatten']:
+            raise NotImplementedError
+        self.linear1 = nn.Linear(d_model, d_model)
+        self.linear4 = nn.Linear(d_model, n_tgt_vocab)
+
+    def forward(self, tgt_seq, src_seq, enc_output, return_attns=False, int_preds=False):
+        batch_size = src_seq.size(0)
+        out1 = self.dropout(F.relu(self.linear1(enc_output.float())))
+        return self.linear4(out1).view(batch_size, 1, -1),
+
+
+def _dot_attention(q, k, v, temperature, blocked):
+    """lamp/SubLayers.py:27-43 in plain PyTorch (eval-mode dropout = identity is applied by the caller's module):
+    the RNN decoder's one-query attention over the encoder states."""
+    attn = torch.bmm(q, k.transpose(1, 2)) / temperature
+    if blocked is not None:
+        attn = attn.masked_fill(blocked.bool(), float('-inf'))
+    attn = torch.softmax(attn, dim=2)
+    return attn
+
+
+class _PlainAttention(nn.Module):
+    """ScaledDotProductAttention as the RNN decoder holds it (no parameters; temperature = d_model as the reference
+    passes it, lamp/Decoders.py:30), differentiable PyTorch so that train.py works for the baseline too."""
+
+    def __init__(self, temperature, dropout=0.1):
+        super().__init__()
+        self.temperature = temperature
+        self.dropout = nn.Dropout(dropout)
+        self.attn_type = nn.Softmax(dim=2)
+
+    def forward(self, q, k, v, attn_mask=None, stop_sig=False):
+        attn = self.dropout(_dot_attention(q, k, v, self.temperature, attn_mask))
+        return torch.bmm(attn, v), attn
 
 
 class RNNDecoder(nn.Module):
-    def __init__(self, *args, **kwargs):
+    """Autoregressive GRU baseline with attention over the encoder states (lamp/Decoders.py:16-72): every step feeds
+    the arg-max label of the previous one; returns ((B, len, n_tgt_vocab),).  Plain PyTorch."""
+
+    def __init__(self, n_tgt_vocab, n_max_seq, n_layers=6, n_head=8, d_k=64, d_v=64, d_word_vec=512, d_model=512,
+                 d_inner_hid=1024, dropout=0.1):
         super().__init__()
-        raise NotImplementedError("decoder='rnn_m' is a baseline model outside the label-graph hot path")
+        self.n_max_seq = n_max_seq
+        self.d_model = d_model
+        self.n_tgt_vocab = n_tgt_vocab
+        self.tgt_word_emb = nn.Embedding(n_tgt_vocab, d_word_vec, padding_idx=Constants.PAD)
+        self.dropout = nn.Dropout(dropout)
+        self.attention_stack = nn.ModuleList([_PlainAttention(d_model, dropout=dropout) for _ in range(n_layers)])
+        self.rnn_layer_stack = nn.ModuleList(
+            [nn.GRU(d_model + d_word_vec, d_model, batch_first=True, dropout=dropout) for _ in range(n_layers)])
+        self.U = nn.Linear(self.d_model, self.n_tgt_vocab)
+        self.V = nn.Linear(self.d_model, self.n_tgt_vocab)
+        self.C = nn.Linear(self.d_model, self.n_tgt_vocab)
+
+    def forward_step(self, input_var, decoder_hidden, encoder_outputs, dec_enc_attn_pad_mask=None):
+        batch_size = input_var.size(0)
+        embedded = self.tgt_word_emb(input_var)
+        decoder_hidden = decoder_hidden.view(batch_size, 1, -1)
+        if encoder_outputs.size(1) == 1:
+            dec_enc_attn_pad_mask = None
+        for idx, dec_layer in enumerate(self.rnn_layer_stack):
+            context, attn = self.attention_stack[idx](decoder_hidden.view(batch_size, 1, -1), encoder_outputs,
+                                                      encoder_outputs, dec_enc_attn_pad_mask)
+            rnn_input = torch.cat((embedded, context), 2)
+            embedded, decoder_hidden = dec_layer(rnn_input, decoder_hidden.view(1, batch_size, -1).contiguous())
+        output = self.U(decoder_hidden)
+        output = output + self.V(embedded.view(batch_size, -1))
+        output = output + self.C(context.view(batch_size, -1))
+        return output, decoder_hidden, attn
+
+    def forward(self, tgt_seq, src_seq, enc_output, return_attns=False, int_preds=False):
+        batch_size = enc_output.size(0)
+        pad_mask = utils.get_attn_padding_mask(tgt_seq, src_seq, unsqueeze=False)
+        dec_output = torch.zeros(tgt_seq.size(0), tgt_seq.size(1), self.n_tgt_vocab, device=enc_output.device)
+        dec_input = tgt_seq[:, 0].unsqueeze(1)
+        decoder_hidden = enc_output.mean(1)
+        for di in range(tgt_seq.size(1)):
+            decoder_output, decoder_hidden, _ = self.forward_step(dec_input, decoder_hidden, enc_output, pad_mask)
+            dec_output[:, di, :] = decoder_output
+            dec_input = F.log_softmax(decoder_output.view(batch_size, -1), dim=1).topk(1)[1].view(batch_size, -1)
+        return dec_output,

@@ -1,11 +1,15 @@
-"""Graph encoder of LaMP (reference: lamp/Encoders.py:31-110).
+"""Encoders of LaMP (reference: lamp/Encoders.py).
 
-Only the branch the label-graph path uses is built: token (+ sinusoid position) embeddings and a
-stack of EncoderLayers.  The genomics one-hot/conv branch, the per-sample ``adj`` branch and
-``enc_transform`` pooling, and the MLP/RNN baseline encoders are outside the hot path (SURVEY.md
-section 2) and raise at construction.
+GraphEncoder (lamp/Encoders.py:31-110) is the hot path: token (+ sinusoid position) embeddings and a stack of
+EncoderLayers on the HIP kernels.  ``enc_transform`` pooling (:96-105) is a cheap reduction of its output, done in
+PyTorch on the device.  MLPEncoder (:16-27) and RNNEncoder (:112-137) are the reference's baseline models (SURVEY.md
+8f n4): plain PyTorch modules with the reference's parameter names and shapes, so every ``main.py -encoder`` choice
+constructs and reference checkpoints load; they run wherever their tensors live.  The genomics one-hot/conv branch
+and the per-sample ``adj`` branch stay outside the scope (they raise).
 """
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import Constants, utils
 from . import _native as N
@@ -18,8 +22,10 @@ class GraphEncoder(nn.Module):
                  d_model=512, d_inner_hid=1024, onehot=False, enc_transform='', dropout=0.1,
                  no_enc_pos_embedding=False):
         super().__init__()
-        if onehot or enc_transform != '':
-            raise NotImplementedError('onehot / enc_transform encoders are outside the label-graph hot path')
+        if onehot:
+            raise NotImplementedError('the one-hot / Conv1d genomics encoder is outside the label-graph hot path')
+        if enc_transform not in ('', 'sum', 'mean', 'flatten', 'max'):
+            raise NotImplementedError('enc_transform=%r' % (enc_transform,))
         self.n_max_seq = n_max_seq
         self.d_model = d_model
         self.onehot = onehot
@@ -46,16 +52,58 @@ class GraphEncoder(nn.Module):
             if return_attns:
                 attns.append(a)
         del keep
+        x = pool_encoder_output(x, src_seq, self.enc_transform)
         return (x, attns) if return_attns else (x, None)
 
 
+def pool_encoder_output(enc_output, src_seq, enc_transform):
+    """lamp/Encoders.py:96-105: collapse the token states to ONE vector per sample, (B, 1, .).  'mean' divides the
+    sum over ALL positions by the number of non-PAD tokens, exactly as the reference does; 'max' is a NameError in the
+    reference (an undefined `x`, :98) and is rejected here."""
+    if enc_transform == '':
+        return enc_output
+    B = enc_output.size(0)
+    if enc_transform == 'sum':
+        out = enc_output.sum(1)
+    elif enc_transform == 'mean':
+        out = enc_output.sum(1) / ((src_seq > 0).sum(dim=1).float().view(-1, 1))
+    elif enc_transform == 'flatten':
+        out = enc_output.reshape(B, -1).float()
+    else:
+        raise NotImplementedError("enc_transform='max' raises NameError in the reference (lamp/Encoders.py:98)")
+    return out.view(B, 1, -1)
+
+
 class MLPEncoder(nn.Module):
-    def __init__(self, *args, **kwargs):
+    """Bag-of-features baseline (lamp/Encoders.py:16-27): one Linear over the (B, n_src_vocab) FLOAT feature rows the
+    caller passes as ``src_seq``; returns ((B, 1, d_model), None)."""
+
+    def __init__(self, n_src_vocab, n_max_seq, n_layers=6, n_head=8, d_k=64, d_v=64, d_word_vec=512, d_model=512,
+                 d_inner_hid=1024, onehot=False, dropout=0.1):
         super().__init__()
-        raise NotImplementedError("encoder='mlp' is a baseline model outside the label-graph hot path")
+        self.n_max_seq = n_max_seq
+        self.d_model = d_model
+        self.linear1 = nn.Linear(n_src_vocab, d_model)
+
+    def forward(self, src_seq, adj, src_pos, return_attns=False):
+        enc_output = self.linear1(src_seq)
+        return enc_output.view(src_seq.size(0), 1, -1), None
 
 
 class RNNEncoder(nn.Module):
-    def __init__(self, *args, **kwargs):
+    """Bidirectional-GRU baseline (lamp/Encoders.py:112-137): embedding -> n_layers BiGRU -> Linear(2d, d)."""
+
+    def __init__(self, n_src_vocab, n_max_seq, n_layers=6, n_head=8, d_k=64, d_v=64, d_word_vec=512, d_model=512,
+                 d_inner_hid=1024, onehot=False, dropout=0.1):
         super().__init__()
-        raise NotImplementedError("encoder='rnn' is a baseline model outside the label-graph hot path")
+        if onehot:
+            raise NotImplementedError('the one-hot / Conv1d genomics encoder is outside the label-graph hot path')
+        self.onehot = onehot
+        self.src_word_emb = nn.Embedding(n_src_vocab, d_word_vec, padding_idx=Constants.PAD)
+        self.brnn = nn.GRU(d_word_vec, d_model, n_layers, batch_first=True, bidirectional=True, dropout=dropout)
+        self.U = nn.Linear(d_model * 2, d_model)
+
+    def forward(self, src_seq, adj, src_pos, return_attns=False):
+        enc_input = self.src_word_emb(src_seq)
+        enc_output, _ = self.brnn(enc_input)
+        return self.U(enc_output), None

@@ -37,9 +37,13 @@ class LAMP(nn.Module):
                 d_model=d_model, d_k=d_k, d_v=d_v, d_inner_hid=d_inner_hid, onehot=onehot, dropout=dropout,
                 no_enc_pos_embedding=no_enc_pos_embedding, enc_transform=enc_transform)
         elif encoder == 'mlp':
-            self.encoder = MLPEncoder()
+            self.encoder = MLPEncoder(
+                n_src_vocab, n_max_seq_e, n_layers=n_layers_enc, n_head=n_head, d_word_vec=d_word_vec, d_model=d_model,
+                d_k=d_k, d_v=d_v, d_inner_hid=d_inner_hid, onehot=onehot, dropout=dropout)
         elif encoder == 'rnn':
-            self.encoder = RNNEncoder()
+            self.encoder = RNNEncoder(
+                n_src_vocab, n_max_seq_e, n_layers=n_layers_enc, n_head=n_head, d_word_vec=d_word_vec, d_model=d_model,
+                d_k=d_k, d_v=d_v, d_inner_hid=d_inner_hid, onehot=onehot, dropout=dropout)
         else:
             raise NotImplementedError(encoder)
 
@@ -51,24 +55,33 @@ class LAMP(nn.Module):
                 label_adj_matrix=label_adj_matrix, label_mask=label_mask, enc_vec=self.enc_vec,
                 graph_conv=graph_conv, attn_type=attn_type)
         elif decoder == 'mlp':
-            self.decoder = MLPDecoder()
+            self.decoder = MLPDecoder(
+                n_tgt_vocab, n_max_seq_e, n_max_seq_d, n_layers=n_layers_dec, n_head=n_head, d_word_vec=d_word_vec,
+                d_model=d_model, d_k=d_k, d_v=d_v, d_inner_hid=d_inner_hid, dropout=dec_dropout,
+                enc_transform=enc_transform)
         elif decoder == 'rnn_m':
-            self.decoder = RNNDecoder()
+            self.decoder = RNNDecoder(
+                n_tgt_vocab, n_max_seq_d, n_layers=n_layers_dec, n_head=n_head, d_word_vec=d_word_vec, d_model=d_model,
+                d_k=d_k, d_v=d_v, d_inner_hid=d_inner_hid, dropout=dec_dropout)
         else:
-            raise NotImplementedError(decoder)
+            raise NotImplementedError(decoder)   # 'sa_m' & co. exist in the reference's argparse only (lamp/Models.py:76-77)
 
         # Read-out.  Assigning the embedding Parameter to `tgt_word_proj.weight` registers a second
         # key on the XavierLinear wrapper but does NOT tie `tgt_word_proj.linear.weight`, which stays
         # the matrix the forward uses -- exactly the reference's (accidental) behaviour; both keys
         # are needed for checkpoint compatibility (lamp/Models.py:87-94).
         bias = self.decoder_type in ('mlp', 'graph', 'star') and not proj_share_weight
-        if proj_share_weight:
-            self.tgt_word_proj = XavierLinear(d_model, n_tgt_vocab, bias=bias)
-            self.tgt_word_proj.weight = self.decoder.tgt_word_emb.weight
-        else:
-            self.tgt_word_proj = XavierLinear(d_model, 1, bias=bias)
-        if int_preds:
-            self.tgt_word_proj_copy = XavierLinear(d_model, n_tgt_vocab, bias=bias)
+        if self.decoder_type != 'mlp':   # lamp/Models.py:86-94: the mlp decoder carries its own output layer
+            if proj_share_weight:
+                self.tgt_word_proj = XavierLinear(d_model, n_tgt_vocab, bias=bias)
+                self.tgt_word_proj.weight = self.decoder.tgt_word_emb.weight
+            else:
+                self.tgt_word_proj = XavierLinear(d_model, 1, bias=bias)
+            if int_preds:
+                self.tgt_word_proj_copy = XavierLinear(d_model, n_tgt_vocab, bias=bias)
+        # the fused lamp_forward launcher takes the graph model with per-token encoder states; everything else runs
+        # module by module (graph parts on the HIP kernels, the baseline parts in plain PyTorch)
+        self._fused = (encoder == 'graph' and decoder == 'graph' and not self.enc_vec)
 
         self.d_model, self.d_inner, self.d_k, self.d_v = d_model, d_inner_hid, d_k, d_v
         self.n_labels = n_tgt_vocab
@@ -110,6 +123,8 @@ class LAMP(nn.Module):
         """Every weight tensor the descriptor points to, in a fixed order, fetched by ATTRIBUTE: a DataParallel
         replica (torch/nn/parallel/replicate.py) has an empty ``_parameters`` -- ``self.parameters()`` yields nothing
         there -- but carries its device's copies as plain attributes."""
+        if not self._fused:
+            raise NotImplementedError('the lamp_model descriptor exists for the graph encoder + graph decoder only')
         enc, dec = self.encoder, self.decoder
         out = [enc.src_word_emb.weight, dec.tgt_word_emb.weight, self.tgt_word_proj.linear.weight]
         if hasattr(enc, 'position_enc'):
@@ -191,9 +206,37 @@ class LAMP(nn.Module):
             self._native_cache = (key, built)
         return built
 
+    def _forward_composite(self, src, adj, tgt_seq, return_attns, int_preds):
+        """lamp/Models.py:110-137 module by module, for the model combinations outside the fused launcher: the mlp /
+        rnn baselines (plain PyTorch) and the graph decoder fed by a vector encoder (mlp, or graph + enc_transform)."""
+        src_seq, src_pos = src
+        batch_size = src_seq.size(0)
+        if self.decoder_type in ('sa_m', 'rnn_m'):
+            tgt_seq = tgt_seq[:, :-1]
+        enc_output, *enc_self_attns = self.encoder(src_seq, adj, src_pos, return_attns=return_attns)
+        dec_output, *dec_output2 = self.decoder(tgt_seq, src_seq, enc_output, return_attns=return_attns,
+                                                int_preds=int_preds)
+        if self.decoder_type in ('rnn_m', 'mlp'):
+            seq_logit = dec_output
+        else:
+            w = self.tgt_word_proj.linear.weight
+            if self.decoder_type == 'graph' and w.size(0) == dec_output.size(1) and self.tgt_word_proj.linear.bias is None:
+                seq_logit = N.diag_logits(dec_output, w)   # diag(y W^T) without the (B, L, L) product (SURVEY.md G4)
+            else:
+                seq_logit = self.tgt_word_proj(dec_output)
+                if self.decoder_type == 'graph':
+                    seq_logit = torch.diagonal(seq_logit, 0, 1, 2)
+        if int_preds:
+            w = self.tgt_word_proj.linear.weight.detach()
+            preds = [N.diag_logits(o, w) for o in dec_output2[0][:-1]]
+            return seq_logit.reshape(-1, seq_logit.size(-1)), enc_output, preds
+        if return_attns:
+            return seq_logit.reshape(-1, seq_logit.size(-1)), enc_output, enc_self_attns, dec_output2
+        return seq_logit.reshape(-1, seq_logit.size(-1)), enc_output, None
+
     def forward(self, src, adj, tgt_seq, binary_tgt, return_attns=False, int_preds=False):
-        if self.decoder_type != 'graph':
-            raise NotImplementedError(self.decoder_type)
+        if not self._fused:
+            return self._forward_composite(src, adj, tgt_seq, return_attns, int_preds)
         if adj:
             raise NotImplementedError('per-sample adjacency for the encoder is outside the hot path')
         src_seq, src_pos = src
