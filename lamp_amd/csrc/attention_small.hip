@@ -361,22 +361,15 @@ bool attn_small_applies(const AttnParams& p) {
 int launch_attn_small(const AttnParams& p, int force, hipStream_t s) {
     const int nt = (p.lk + 15) / 16;
     const int nqb = (p.lq + 15) / 16;
-    // 16-key tiles per wave: 4-way split from 8 tiles on, 2-way from 4 (reuters enc-dec 19 tiles -> 4; its 90-label
-    // self-attention 6 -> 2; bibtex 10 / 7 -> 4 / 2)
+    // Key shares (measured, profiles/r02_attn_variants.txt): four from 12 sixteen-key tiles on (reuters enc-dec: 19), two
+    // from 4 (reuters' 90-label self-attention: 6; bibtex 7 / 10), else one.  Always four waves per workgroup: larger
+    // workgroups (several query blocks sharing their K / V tiles through L1) measured equal or slower on every shape
+    // and exist for the tuning build's every-variant tests only.
     int ksplit = force & 7;
-    if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = nt >= 8 ? 4 : (nt >= 4 ? 2 : 1);
-    // query blocks per workgroup: the largest of 3, 2 (, 4 with two key shares) that pads the query blocks least
+    if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = nt >= 12 ? 4 : (nt >= 4 ? 2 : 1);
     int qb = (force >> 4) & 7;
-    if (qb < 1 || qb > 4) {
-        int best_pad = 1 << 30;
-        for (int c = (ksplit == 4 ? 3 : 4); c >= 1; --c) {
-            const int pad = (nqb + c - 1) / c * c - nqb;
-            if (pad < best_pad) {
-                best_pad = pad;
-                qb = c;
-            }
-        }
-    }
+    if (qb < 1 || qb > 4) qb = 4 / ksplit;
+    (void)nqb;
     const int dmax = p.dk > p.dv ? p.dk : p.dv;
     if (dmax <= 32) return launch_small_dp<32>(p, qb, ksplit, s);
     if (dmax <= 64) return launch_small_dp<64>(p, qb, ksplit, s);

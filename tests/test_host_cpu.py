@@ -156,11 +156,16 @@ def test_product_has_no_cpu_path():
         m.tgt_word_proj(torch.zeros(1, 2, 64))
 
 
-def test_out_of_scope_models_raise_at_construction():
+def test_out_of_scope_branches_raise_at_construction():
+    """What stays outside: the genomics one-hot / Conv1d input branch, enc_transform='max' (a NameError in the
+    reference itself) and decoder names the reference's own LAMP rejects."""
+    from lamp_amd.Encoders import GraphEncoder, pool_encoder_output
     with pytest.raises(NotImplementedError):
-        LAMP(10, 5, 4, 5, encoder='mlp', decoder='graph', label_mask='none')
+        GraphEncoder(10, 4, n_layers=1, n_head=1, d_k=8, d_v=8, d_word_vec=8, d_model=8, d_inner_hid=16, onehot=True)
     with pytest.raises(NotImplementedError):
-        LAMP(10, 5, 4, 5, encoder='graph', decoder='rnn_m', label_mask='none')
+        pool_encoder_output(torch.zeros(2, 3, 4), torch.ones(2, 3, dtype=torch.long), 'max')
+    with pytest.raises(NotImplementedError):
+        LAMP(10, 5, 4, 5, encoder='graph', decoder='sa_m', label_mask='none')
 
 
 def test_argument_errors_come_back_as_status_codes_without_a_gpu():
