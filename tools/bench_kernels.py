@@ -219,6 +219,20 @@ def attn():
             print('%-20s mode=%02x mask=%-10s %9.1f us  %6.1f TFLOP/s' % (name, mode, mname, us, fl / us / 1e6))
 
 
+def ln():
+    """Stand-alone LayerNorm launches at the shapes of one forward."""
+    dev = torch.device('cuda:0')
+    for M, d in ((2880, 512), (9664, 512), (5088, 512), (31456, 1024), (131072, 1024)):
+        x = torch.randn(M, d, device=dev)
+        g_, b_ = torch.randn(d, device=dev), torch.randn(d, device=dev)
+        y = torch.empty_like(x)
+
+        def fn():
+            N.check(N.lib().lamp_layernorm_fwd(x.data_ptr(), M, d, g_.data_ptr(), b_.data_ptr(), 1e-5, y.data_ptr(), N.stream()), 'ln')
+        us = time_fn(fn, iters=50)
+        print('layernorm %6d x %4d  %7.2f us  %7.1f GB/s' % (M, d, us, 8.0 * M * d / us / 1e3))
+
+
 def gemm_trace():
     """Per-workgroup timeline of the GEMM launches of ONE reuters forward (in situ: every launch runs behind its real
     predecessor), from the wall_clock64 stamps the tuning build records at kernel entry, after the prologue (first
@@ -275,4 +289,4 @@ def gemm_trace():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
     {'gemm': gemm, 'gemm_ab': gemm_ab, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
-     'gemm_trace': gemm_trace}[which]()
+     'gemm_trace': gemm_trace, 'ln': ln}[which]()

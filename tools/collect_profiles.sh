@@ -9,6 +9,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-workloads > "$OUT/bench_driver_style_20steps.json" 2>/dev/null
 for wl in bibtex delicious; do
   python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/bench_$wl.json" 2>/dev/null
 done
@@ -16,17 +17,21 @@ python bench.py --workload synthetic4096 --steps 3 --warmup 1 --no-cpu-baseline 
 python bench.py --ragged --no-cpu-baseline > "$OUT/bench_reuters_ragged.json" 2>/dev/null
 python bench.py --workload synthetic4096 --batch 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined > "$OUT/bench_synthetic4096_b1024.json" 2>/dev/null
 python bench.py --workload synthetic4096 --mask none --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined > "$OUT/bench_synthetic4096_none.json" 2>/dev/null
+LAMP_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 5 --no-pipelined > "$OUT/bench_two_ranks_one_gpu_gloo.json" 2>/dev/null
 python tools/bench_kernels.py gemm_ab 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles.txt"
 python tools/bench_kernels.py gemm 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles_sweep.txt"
 python tools/bench_kernels.py attn 2>&1 | grep -v amdgpu.ids > "$OUT/attn_variants.txt"
 python tools/bench_kernels.py sparse 2>&1 | grep -v amdgpu.ids > "$OUT/sparse_label_attention.txt"
-BENCH="python $PWD/bench.py --no-cpu-baseline --no-pipelined"
+python tools/bench_kernels.py gemm_trace 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_trace.txt"
+BENCH="python $PWD/bench.py --no-cpu-baseline --no-pipelined --no-extra-workloads"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o p -f csv -- $BENCH --steps 100 --warmup 10 > "$OUT/bench_under_rocprof.json" 2>/dev/null )
 # PMC passes are separate runs, each with --kernel-trace only (never combined with other trace domains)
 ( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
       -d "$OUT/pmc_sq" -o p -f csv -- $BENCH --steps 5 --warmup 3 > /dev/null 2>&1 )
-for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o p -f csv -- $BENCH --steps 5 --warmup 3 > /dev/null 2>&1 )
+for wl in reuters bibtex delicious; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_${c}_$wl" -o p -f csv -- $BENCH --workload $wl --steps 5 --warmup 3 > /dev/null 2>&1 )
+  done
 done
 python tools/bench_train.py > "$OUT/train_reuters.json" 2>/dev/null
 python tests/time_oracle_train_step.py > "$OUT/train_reuters_cpu_oracle.json" 2>/dev/null

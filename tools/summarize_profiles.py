@@ -5,6 +5,7 @@
 """
 import collections
 import csv
+import json
 import os
 import shutil
 import sys
@@ -38,7 +39,8 @@ def main():
     cp = lambda a, b: shutil.copy(os.path.join(src, a), os.path.join(dst, '%s_%s' % (tag, b)))
     cp('bench.json', 'bench.json')
     cp('bench_under_rocprof.json', 'bench_under_rocprof.json')
-    for wl in ('bibtex', 'delicious', 'synthetic4096', 'reuters_ragged', 'synthetic4096_b1024', 'synthetic4096_none'):
+    for wl in ('bibtex', 'delicious', 'synthetic4096', 'reuters_ragged', 'synthetic4096_b1024', 'synthetic4096_none',
+               'driver_style_20steps', 'two_ranks_one_gpu_gloo'):
         if not os.path.exists(os.path.join(src, 'bench_%s.json' % wl)):
             continue
         cp('bench_%s.json' % wl, 'bench_%s.json' % wl)
@@ -46,6 +48,8 @@ def main():
     cp('gemm_tiles_sweep.txt', 'gemm_tiles_sweep.txt')
     cp('attn_variants.txt', 'attn_variants.txt')
     cp('sparse_label_attention.txt', 'sparse_label_attention.txt')
+    if os.path.exists(os.path.join(src, 'gemm_trace.txt')):
+        cp('gemm_trace.txt', 'gemm_trace.txt')
     cp('stats/p_kernel_stats.csv', 'bench_kernel_stats.csv')
     for f in ('train_reuters.json', 'train_reuters_cpu_oracle.json', 'train_delicious.json', 'gemm_gen.txt'):
         if os.path.exists(os.path.join(src, f)):
@@ -69,21 +73,42 @@ def main():
                                                              d['SQ_WAIT_ANY'] / wc, d['SQ_WAIT_INST_ANY'] / wc))
     open(os.path.join(dst, '%s_mfma_busy.txt' % tag), 'w').write('\n'.join(L) + '\n')
 
-    res = {}
-    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-        disp, _ = load_pmc(os.path.join(src, 'pmc_' + c))
-        res[c] = [(disp[k]['name'], disp[k]['grid'], disp[k].get(c, 0.0)) for k in last_forward(disp)]
-    L = ['# HBM-side traffic of ONE forward (reuters, batch 32), rocprofv3 PMC, separate passes for FETCH_SIZE and WRITE_SIZE.',
-         '# The counters are in KiB; per the MI355X guide FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950,',
-         '# so "fetch MB(x2)" doubles it.',
-         '%-46s %10s %12s %12s' % ('kernel', 'grid', 'fetch MB(x2)', 'write MB')]
-    tf = tw = 0.0
-    for (n, g, f), (_, _, w) in zip(res['FETCH_SIZE'], res['WRITE_SIZE']):
-        fm, wm = f * 1024 * 2 / 1e6, w * 1024 / 1e6
-        tf, tw = tf + fm, tw + wm
-        L.append('%-46s %10d %12.2f %12.2f' % (short(n), g, fm, wm))
-    L.append('%-46s %10s %12.2f %12.2f' % ('TOTAL per forward', '', tf, tw))
-    open(os.path.join(dst, '%s_hbm_traffic.txt' % tag), 'w').write('\n'.join(L) + '\n')
+    traffic = {}
+    tables = []
+    for wl in ('reuters', 'bibtex', 'delicious'):
+        res = {}
+        ok = True
+        for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(src, 'pmc_%s_%s' % (c, wl))
+            if not os.path.exists(os.path.join(d, 'p_counter_collection.csv')):
+                ok = False
+                break
+            disp, _ = load_pmc(d)
+            res[c] = [(disp[k]['name'], disp[k]['grid'], disp[k].get(c, 0.0)) for k in last_forward(disp)]
+        if not ok:
+            continue
+        L = ['# HBM-side traffic of ONE forward (%s, batch 32), rocprofv3 PMC, separate passes for FETCH_SIZE and WRITE_SIZE.' % wl,
+             '# The counters are in KiB; per the MI355X guide FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950,',
+             '# so "fetch MB(x2)" doubles it.  These are the L2s\' memory-side requests: Infinity-Cache hits are included.',
+             '%-46s %10s %12s %12s' % ('kernel', 'grid', 'fetch MB(x2)', 'write MB')]
+        tf = tw = gf = gw = 0.0
+        ng = 0
+        for (n, g, f), (_, _, w) in zip(res['FETCH_SIZE'], res['WRITE_SIZE']):
+            fm, wm = f * 1024 * 2 / 1e6, w * 1024 / 1e6
+            tf, tw = tf + fm, tw + wm
+            if 'gemm_nt_kernel' in n:
+                gf, gw, ng = gf + fm, gw + wm, ng + 1
+            L.append('%-46s %10d %12.2f %12.2f' % (short(n), g, fm, wm))
+        L.append('%-46s %10s %12.2f %12.2f' % ('TOTAL per forward', '', tf, tw))
+        L.append('%-46s %10d %12.2f %12.2f' % ('GEMM launches per forward', ng, gf, gw))
+        tables.append('\n'.join(L))
+        traffic[wl] = {'batch': 32, 'gemm_launches': ng, 'gemm_fetch_bytes': gf * 1e6, 'gemm_write_bytes': gw * 1e6,
+                       'forward_fetch_bytes': tf * 1e6, 'forward_write_bytes': tw * 1e6,
+                       'source': 'profiles/%s_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; '
+                                 'FETCH_SIZE x2 per the gfx950 calibration of MI355X_MICROARCH.md)' % tag}
+    if tables:
+        open(os.path.join(dst, '%s_hbm_traffic.txt' % tag), 'w').write('\n\n'.join(tables) + '\n')
+        json.dump(traffic, open(os.path.join(dst, 'hbm_traffic.json'), 'w'), indent=1)
     print('wrote', sorted(f for f in os.listdir(dst) if f.startswith(tag)))
 
 
