@@ -41,12 +41,20 @@ class GraphEncoder(nn.Module):
 
     def forward(self, src_seq, adj, src_pos, return_attns=False):
         _eval_only(self)
-        if adj:
-            raise NotImplementedError('per-sample adjacency for the encoder is outside the hot path')
         pos_table = self.position_enc.weight if hasattr(self, 'position_enc') else None
         x = N.embed(src_seq, src_pos, self.src_word_emb.weight, pos_table)
         attns = []
         pad_mask, keep = (N.key_token_mask(src_seq, src_seq.size(1)) if return_attns else (None, None))
+        if adj and return_attns:
+            # per-sample input graphs (lamp/Encoders.py:81-85): inside each sample's n x n corner the self-attention mask
+            # is the complement of its adjacency instead of the key-padding pattern.  The encoder's self-attention OUTPUT
+            # is discarded (lamp/Layers.py:16-18), so this only ever shows in the returned attention maps.
+            T = src_seq.size(1)
+            m = utils.get_attn_padding_mask(src_seq, src_seq).to(torch.uint8).contiguous()
+            for i, a in enumerate(adj):
+                n = a.size(0)
+                m[i, :n, :n] = utils.swap_0_1(a.to(m.device), 1, 0).to(torch.uint8)
+            pad_mask, keep = m, None
         for layer in self.layer_stack:
             x, a = layer(x, slf_attn_mask=pad_mask, need_attn=return_attns)
             if return_attns:

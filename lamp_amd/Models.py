@@ -237,14 +237,16 @@ class LAMP(nn.Module):
     def forward(self, src, adj, tgt_seq, binary_tgt, return_attns=False, int_preds=False):
         if not self._fused:
             return self._forward_composite(src, adj, tgt_seq, return_attns, int_preds)
-        if adj:
-            raise NotImplementedError('per-sample adjacency for the encoder is outside the hot path')
+        if adj and return_attns and not int_preds and not self.training:
+            # per-sample input graphs only shape the encoder's attention MAPS (its output is dead compute): the maps come
+            # from the module-by-module route, everything else from the fused launcher below, which may ignore `adj`
+            return self._forward_composite(src, adj, tgt_seq, return_attns, int_preds)
         src_seq, src_pos = src
-        N.require_device(src_seq, src_pos)
-        if src_seq.device.index != torch.cuda.current_device():
+        if src_seq.is_cuda and src_seq.device.index != torch.cuda.current_device():
             # every launch goes to the CURRENT device's stream: make the tensors' device current for the call
             with torch.cuda.device(src_seq.device):
                 return self.forward(src, adj, tgt_seq, binary_tgt, return_attns=return_attns, int_preds=int_preds)
+        N.require_device(src_seq, src_pos)
         if self.training:
             # train.py:36: the autograd-recording path (HIP kernels forward and backward, lamp_amd/training.py)
             from . import training

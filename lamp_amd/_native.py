@@ -162,10 +162,20 @@ def check(status, where):
 
 # ------------------------------------------------------------------ tensor plumbing
 def require_device(*tensors):
+    """Every tensor lives on a HIP device, and on the CURRENT one: launches go to the current device's stream
+    (stream() below), so a tensor of another GPU would be read by kernels enqueued on the wrong device."""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError('lamp_amd runs on an MI355X HIP device only; got a %s tensor (%s). '
                                'There is no CPU path.' % (t.device, tuple(t.shape)))
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError('lamp_amd: tensor on %s but the current device is cuda:%d -- wrap the call in '
+                               '`with torch.cuda.device(tensor.device):` (LAMP.forward does so itself)' % (t.device, cur))
 
 
 def f32c(t):

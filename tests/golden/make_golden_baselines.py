@@ -139,6 +139,23 @@ def main():
         save('baseline_graph_mean_graph', m.state_dict(), src_seq=seq, src_pos=pos, logits=logits, enc_output=enc,
              n_labels=L, d_model=d, n_src=V, n_max_seq=T, n_head=4, label_adj_matrix=adj)
 
+        # 7. per-sample input graphs (`adj`, lamp/Encoders.py:81-85) on the plain graph model: they only show in the
+        #    encoder's attention maps
+        m = build('graph', 'graph', V, L, T, d, n_head=4, label_mask='prior', adj=adj.clone())
+        lengths = [9, 2, 5, 9, 7]
+        seq, pos = tokens(5, V, T, lengths, g)
+        in_adj = []
+        for n in lengths:
+            a = (torch.rand(n, n, generator=g) < 0.5).float()
+            a.fill_diagonal_(1)
+            in_adj.append(a)
+        logits, enc, enc_attns, dec2 = m((seq, pos), in_adj, None, None, return_attns=True)
+        flat = torch.cat([a.reshape(-1) for a in in_adj])
+        save('baseline_input_adj', m.state_dict(), src_seq=seq, src_pos=pos, logits=logits, enc_output=enc,
+             n_labels=L, d_model=d, n_src=V, n_max_seq=T, n_head=4, label_adj_matrix=adj, in_adj_flat=flat,
+             lengths=torch.tensor(lengths), attn_enc_0=enc_attns[0][0], attn_enc_1=enc_attns[0][1],
+             attn_dec_slf_1=dec2[0][1], attn_dec_enc_1=dec2[1][1])
+
 
 if __name__ == '__main__':
     main()

@@ -152,6 +152,30 @@ def test_vector_encoder_variants_of_the_graph_model(name, dec, et, mask):
 
 
 @pytest.mark.gpu
+def test_per_sample_input_graphs_shape_only_the_encoder_maps():
+    """`adj` (lamp/Encoders.py:81-85): the encoder's self-attention mask inside each sample's corner; its output is dead
+    compute, so logits equal the adj-free call bit for bit and only the returned encoder maps change."""
+    d, sd = load_golden('baseline_input_adj')
+    dev = torch.device('cuda:0')
+    m = _model(d, sd, 'graph', 'graph', label_mask='prior').to(dev)
+    lengths = d['lengths'].tolist()
+    adj, off = [], 0
+    for n in lengths:
+        adj.append(d['in_adj_flat'][off:off + n * n].view(n, n).to(dev))
+        off += n * n
+    src = (d['src_seq'].to(dev), d['src_pos'].to(dev))
+    with torch.no_grad():
+        logits, enc, enc_attns, dec2 = m(src, adj, None, None, return_attns=True)
+        plain, enc_plain, _ = m(src, None, None, None)
+        with_adj, _, _ = m(src, adj, None, None)
+    assert max_abs_diff(logits, d['logits']) < 1e-4 and max_abs_diff(enc, d['enc_output']) < 5e-5
+    for i in range(2):
+        assert max_abs_diff(enc_attns[0][i], d['attn_enc_%d' % i]) < 1e-5
+    assert max_abs_diff(dec2[0][1], d['attn_dec_slf_1']) < 1e-5 and max_abs_diff(dec2[1][1], d['attn_dec_enc_1']) < 1e-5
+    assert torch.equal(with_adj, plain) and max_abs_diff(logits, plain) < 1e-6
+
+
+@pytest.mark.gpu
 def test_rnn_baseline_runs_on_the_device():
     d, sd = load_golden('baseline_rnn')
     dev = torch.device('cuda:0')
