@@ -295,6 +295,11 @@ def main():
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
+    # ONE JSON line on stdout, whatever the libraries underneath print (gloo and RCCL write banners to fd 1): everything
+    # but the result line is sent to stderr from here on
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -464,7 +469,8 @@ def main():
         cb = cpu_baseline(w, m['sd'], m['adj'], m['seq'], m['pos'], args.cpu_budget)
         result['cpu_baseline'] = cb
         result['speedup_vs_cpu_as_written'] = value / cb['value']
-    print(json.dumps(result), flush=True)
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(result) + '\n').encode())
     ok = n_gpus == args.gpus
     if dist is not None:
         dist.barrier()

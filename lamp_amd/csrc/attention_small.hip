@@ -51,6 +51,10 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int qb = wave / KSPLIT, ks = wave % KSPLIT;
+#ifdef LAMP_TUNING
+    const unsigned long long t_entry = p.trace ? wall_clock64() : 0ull;
+    unsigned long long t_loop = 0, t_merge = 0;
+#endif
     const int nqg = (p.lq + 16 * QB - 1) / (16 * QB);
     const int item = xcd_remap(blockIdx.x, gridDim.x);  // the query groups of one (sample, head) stay on one XCD
     const int qgrp = item % nqg;
@@ -181,6 +185,9 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     float m_run = -INFINITY, l_part = 0.f;   // m_run: this query's running maximum (equal in its 4 lane groups)
     constexpr float RESCALE_THR = 32.0f;
 
+#ifdef LAMP_TUNING
+    if (p.trace) t_loop = wall_clock64();
+#endif
     if (wave_active && ks < nt) {
         int kt = ks;
         load_k(kt);
@@ -228,6 +235,9 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
         }
     }
 
+#ifdef LAMP_TUNING
+    if (p.trace) t_merge = wall_clock64();
+#endif
     if constexpr (KSPLIT > 1) {
         // ---- merge the KSPLIT partial results of each query block (lane-local positions, fixed order) ----
         constexpr int CW = (DV8 * 4 + 4) * 64;  // floats per wave: o blocks as float4 per lane, then (m, l, -, -) per lane
@@ -297,6 +307,16 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
             }
         }
     }
+#ifdef LAMP_TUNING
+    if (p.trace && tid == 0) {   // wave 0 (key share 0 of the first query block): entry, loop start, loop end, exit
+        unsigned long long* t = p.trace + size_t(blockIdx.x) * 8;
+        t[0] = t_entry; t[1] = t_loop; t[2] = t_merge; t[3] = wall_clock64();
+        t[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        t[6] = unsigned(item);
+        t[7] = 0;
+    }
+#endif
 }
 
 template <int DP, int QB, int KSPLIT, int PM, int MK>
@@ -357,8 +377,18 @@ bool attn_small_applies(const AttnParams& p) {
     return p.lq <= 256 && p.V && p.O && (!p.P || p.lse) && dmax <= 128 && (dmax <= 64 || (p.dv & 7) == 0);
 }
 
+#ifdef LAMP_TUNING
+static unsigned long long* g_attn_trace = nullptr;   // 8 words per workgroup of the NEXT small-shape launch(es)
+extern "C" void lamp_debug_set_attn_trace(unsigned long long* buf) { g_attn_trace = buf; }
+#endif
+
 // force: 0 = heuristic; else (tuning build) key shares in bits 0-2, query blocks per workgroup in bits 4-6.
-int launch_attn_small(const AttnParams& p, int force, hipStream_t s) {
+int launch_attn_small(const AttnParams& p_in, int force, hipStream_t s) {
+    AttnParams p = p_in;
+    p.trace = nullptr;
+#ifdef LAMP_TUNING
+    p.trace = g_attn_trace;
+#endif
     const int nt = (p.lk + 15) / 16;
     const int nqb = (p.lq + 15) / 16;
     // Key shares (measured, profiles/r02_attn_variants.txt): four from 12 sixteen-key tiles on (reuters enc-dec: 19), two

@@ -53,6 +53,7 @@ struct AttnParams {
     int64_t m_sb, m_sq;
     const int* tiles;      // optional per-32-query-block active key-tile lists (shared masks), or nullptr
     int64_t tiles_stride;
+    unsigned long long* trace;  // tuning build only: per-workgroup timeline of attention_small.hip; NULL in production
 };
 
 int launch_gemm(const GemmParams& p, hipStream_t s);

@@ -233,6 +233,46 @@ def ln():
         print('layernorm %6d x %4d  %7.2f us  %7.1f GB/s' % (M, d, us, 8.0 * M * d / us / 1e3))
 
 
+def attn_trace():
+    """Per-workgroup timeline of the small-shape attention kernel (stamps of wave 0 of each workgroup: entry, Q block
+    staged, key loop done, exit) for the reuters / bibtex shapes, heuristic variant."""
+    dev = torch.device('cuda:0')
+    hook = N.lib().lamp_debug_set_attn_trace
+    hook.argtypes = [ctypes.c_void_p]
+    hook.restype = None
+    print('%-18s %6s %8s | %-22s | %-16s %-16s %-16s' % ('shape', 'WGs', 'span', 'start p50 p90 max', 'stage Q p50 max',
+                                                      'key loop p50 max', 'merge+store p50 max'))
+    for name, B, H, lq, lk, dk in (('reuters enc-attn', 32, 4, 90, 302, 128), ('reuters self', 32, 4, 90, 90, 128),
+                                   ('bibtex enc-attn', 32, 4, 159, 100, 128), ('bibtex self', 32, 4, 159, 159, 128)):
+        q = torch.randn(B, lq, H * dk, device=dev)
+        k = torch.randn(B, lk, H * dk, device=dev)
+        v = torch.randn(B, lk, H * dk, device=dev)
+        o = torch.empty(B, lq, H * dk, device=dev)
+        lay = N.AttnLayout(lq * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lq * H * dk, dk, H * dk)
+        buf = torch.zeros(8 * 8192, dtype=torch.int64, device=dev)
+
+        def fn():
+            N.check(N.lib().lamp_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), None, B, H, lq, lk, dk, dk,
+                                          dk ** -0.5, None, ctypes.byref(lay), N.stream()), 'sdpa')
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        hook(buf.data_ptr())
+        fn()
+        torch.cuda.synchronize()
+        hook(None)
+        t = buf.cpu().view(-1, 8)
+        rows = t[t[:, 3] != 0]
+        t0 = rows[:, 0].min().item()
+        us = lambda x: (x - t0) * 0.01  # noqa: E731  (10 ns ticks)
+        start = sorted(us(x) for x in rows[:, 0].tolist())
+        ph = [sorted(((rows[:, j + 1] - rows[:, j]).double() * 0.01).tolist()) for j in range(3)]
+        qf = lambda a, f: a[min(len(a) - 1, int(f * len(a)))]  # noqa: E731
+        print('%-18s %6d %8.2f | %6.2f %6.2f %6.2f   | %7.2f %7.2f  %7.2f %7.2f  %7.2f %7.2f' %
+              (name, len(start), us(rows[:, 3].max().item()), qf(start, 0.5), qf(start, 0.9), start[-1],
+               qf(ph[0], 0.5), ph[0][-1], qf(ph[1], 0.5), ph[1][-1], qf(ph[2], 0.5), ph[2][-1]))
+
+
 def gemm_trace():
     """Per-workgroup timeline of the GEMM launches of ONE reuters forward (in situ: every launch runs behind its real
     predecessor), from the wall_clock64 stamps the tuning build records at kernel entry, after the prologue (first
@@ -289,4 +329,4 @@ def gemm_trace():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
     {'gemm': gemm, 'gemm_ab': gemm_ab, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
-     'gemm_trace': gemm_trace, 'ln': ln}[which]()
+     'gemm_trace': gemm_trace, 'ln': ln, 'attn_trace': attn_trace}[which]()
