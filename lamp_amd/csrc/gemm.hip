@@ -301,14 +301,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
 #endif
 }
 
+#ifdef LAMP_TUNING
+static size_t g_extra_lds = 0;
+extern "C" void lamp_debug_set_gemm_extra_lds(int bytes) { g_extra_lds = size_t(bytes); }
+#endif
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF>
 static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
     constexpr bool RPRE = T::MI * T::NI * (MF == 32 ? 16 : 4) <= 16;
     auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE>;
-    constexpr size_t LDS = T::LDS_BYTES;
+    size_t LDS = T::LDS_BYTES;
     static AttrOnce once;
+#ifdef LAMP_TUNING
+    LDS += g_extra_lds;   // residency experiments: more LDS per workgroup = fewer workgroups per CU
+    if (int e = once.set(reinterpret_cast<const void*>(kern), 160 * 1024)) return e;
+#else
     if (int e = once.set(reinterpret_cast<const void*>(kern), LDS)) return e;
+#endif
     // 32-bit in-tile byte offsets
     const int64_t ldmax = p.lda > p.ldw ? (p.lda > p.ldc ? p.lda : p.ldc) : (p.ldw > p.ldc ? p.ldw : p.ldc);
     if (ldmax * (BM > BN ? BM : BN) * 4 >= 0x7fffffffLL || (p.R && p.ldr * BM * 4 >= 0x7fffffffLL))

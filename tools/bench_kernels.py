@@ -219,6 +219,39 @@ def attn():
             print('%-20s mode=%02x mask=%-10s %9.1f us  %6.1f TFLOP/s' % (name, mode, mname, us, fl / us / 1e6))
 
 
+def residency():
+    """Forward-GEMM shapes with the workgroups per CU limited by extra LDS (tuning build): does a launch whose tiles no
+    longer fit one round -- phases out of lockstep -- beat the all-resident one?"""
+    lib = N.lib()
+    hook = lib.lamp_debug_set_gemm_extra_lds
+    hook.argtypes = [ctypes.c_int]
+    hook.restype = None
+    dev = torch.device('cuda:0')
+    shapes = [('encFFN 9664x512x512', 9664, 512, 512), ('dec 2880x512x512', 2880, 512, 512),
+              ('decQKV 2880x1536x512', 2880, 1536, 512), ('encKVx2 9664x2048x512', 9664, 2048, 512)]
+    extras = (0, 12, 20, 32, 44, 60)
+    print('%-26s' % 'extra LDS KiB ->' + ''.join('%14d' % e for e in extras))
+    for name, M, Nn, K in shapes:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(Nn, K, device=dev) / K ** 0.5
+        b = torch.randn(Nn, device=dev)
+        r = torch.randn(M, Nn, device=dev)
+        out = torch.empty(M, Nn, device=dev)
+
+        def fn():
+            N.check(lib.lamp_linear_fwd(x.data_ptr(), M, K, K, w.data_ptr(), Nn, K, b.data_ptr(), r.data_ptr(), Nn, 1,
+                                        out.data_ptr(), Nn, N.stream()), 'linear')
+        row = '%-26s' % name
+        import statistics
+        samples = {e: [] for e in extras}
+        for _ in range(5):
+            for e in extras:
+                hook(e * 1024)
+                samples[e].append(time_fn(fn, iters=20, warm=3))
+        hook(0)
+        print(row + ''.join('%9.1f us   ' % statistics.median(samples[e]) for e in extras))
+
+
 def ln():
     """Stand-alone LayerNorm launches at the shapes of one forward."""
     dev = torch.device('cuda:0')
@@ -329,4 +362,4 @@ def gemm_trace():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
     {'gemm': gemm, 'gemm_ab': gemm_ab, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
-     'gemm_trace': gemm_trace, 'ln': ln, 'attn_trace': attn_trace}[which]()
+     'gemm_trace': gemm_trace, 'ln': ln, 'attn_trace': attn_trace, 'residency': residency}[which]()
