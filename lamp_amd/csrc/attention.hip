@@ -466,7 +466,8 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     if (ksplit != 1 && ksplit != 2 && ksplit != 4) ksplit = (p.lq <= 128 && nt >= 3) ? 2 : 1;
     if (ksplit == 4 && p.lse) ksplit = 2;
     int rc;
-    if (attn_small_applies(p))   // at most 256 queries: 16-query blocks on 16x16x4 (attention_small.hip)
+    // at most 256 queries: 16-query blocks on 16x16x4 (attention_small.hip); bit 7 of the tuning hook lifts the limit
+    if (attn_small_applies(p, (g_force_attn & 0x80) != 0))
         rc = launch_attn_small(p, g_force_attn, s);
     else if (dmax <= 32)
         rc = launch_attn_dp<32>(p, ksplit, s);

@@ -371,10 +371,10 @@ static int launch_small_dp(const AttnParams& p, int qb, int ksplit, hipStream_t 
 
 // The shapes this kernel takes (a function of the per-sample shape ONLY): at most 256 queries, with V and O given and
 // either no maps or the single-pass map write-out.  The exact two-pass maps and map-only calls stay in attention.hip.
-bool attn_small_applies(const AttnParams& p) {
+bool attn_small_applies(const AttnParams& p, bool any_lq) {
     const int dmax = p.dk > p.dv ? p.dk : p.dv;
     // a lane reads DP/16 consecutive floats of a V row: d_v must be a whole number of them (8 for 64 < d <= 128)
-    return p.lq <= 256 && p.V && p.O && (!p.P || p.lse) && dmax <= 128 && (dmax <= 64 || (p.dv & 7) == 0);
+    return (p.lq <= 256 || any_lq) && p.V && p.O && (!p.P || p.lse) && dmax <= 128 && (dmax <= 64 || (p.dv & 7) == 0);
 }
 
 #ifdef LAMP_TUNING
