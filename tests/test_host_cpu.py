@@ -192,3 +192,16 @@ def test_dropin_package_aliases_reference_import_paths():
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, 'dropin'), ROOT]))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd='/tmp')
     assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
+def test_bench_refuses_to_run_without_a_gpu_and_its_spawner_does_not_hang():
+    """bench.py has no CPU path; started with --gpus 2 on a GPU-less host the self-spawned ranks fail and the parent
+    returns their error instead of waiting for a rendezvous (SURVEY.md 8e entry point)."""
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip('GPU box: covered by tests/test_gpu_multi.py')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    for extra in ([], ['--gpus', '2']):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1'] + extra, capture_output=True,
+                           text=True, env=env, timeout=300)
+        assert r.returncode != 0 and 'needs an MI355X' in r.stderr and r.stdout.strip() == ''
