@@ -313,19 +313,24 @@ def main():
     # "nccl" is RCCL on ROCm.  LAMP_BENCH_BACKEND=gloo lets two ranks share one GPU to smoke-test this path.
     backend = os.environ.get('LAMP_BENCH_BACKEND', 'nccl')
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device,
+                                    timeout=datetime.timedelta(seconds=600))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
     if world != args.gpus and rank == 0:
         print('error: --gpus %d but %d rank(s) were launched' % (args.gpus, world), file=sys.stderr)
     comm_dev = device if backend == 'nccl' else torch.device('cpu')
 
     def sync():
         if dist is not None:
-            dist.barrier()
+            if backend == 'nccl':
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
 
     from lamp_amd import _native as N
     N.lib()
@@ -393,7 +398,7 @@ def main():
 
     if rank != 0:
         if dist is not None:
-            dist.barrier()
+            sync()
             dist.destroy_process_group()
         return
 
@@ -473,7 +478,7 @@ def main():
     os.write(result_fd, (json.dumps(result) + '\n').encode())
     ok = n_gpus == args.gpus
     if dist is not None:
-        dist.barrier()
+        sync()
         dist.destroy_process_group()
     if not ok:
         sys.exit(3)

@@ -71,6 +71,14 @@ def test_bench_spawns_its_own_ranks(dev):
     assert r4.returncode != 0
 
 
+def test_rccl_control_plane_calls_work(dev):
+    """bench.py's "nccl" (= RCCL) control plane -- init with device_id, barrier(device_ids), all_gather of a float64 device
+    tensor -- as a one-rank group (RCCL refuses two ranks on one device, so the 2-rank tests above run on gloo)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_rccl_control_plane.py')], capture_output=True,
+                       text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0 and 'rccl control plane ok' in r.stdout, r.stderr[-2000:]
+
+
 def test_run_eval_sharded_over_two_ranks_equals_one(dev, tmp_path):
     """Two processes (gloo, sharing this box's GPU) each run the HIP forward on their share of the test batches;
     the gathered result must equal the one-process run: same BCE, same metrics."""
