@@ -154,6 +154,27 @@ def test_sdpa_every_kernel_variant(dev, tuning, mode, lq, lk, dk):
     assert max_abs_diff(o2, ref_o) < 2e-5 and max_abs_diff(a2, ref_a) < 5e-6
 
 
+@pytest.mark.parametrize('lq,lk,dk,dv', [(256, 40, 128, 128), (257, 40, 128, 128), (16, 16, 128, 128), (17, 191, 128, 72),
+                                         (90, 302, 128, 100), (90, 302, 64, 128), (255, 3, 36, 20), (1, 500, 8, 8)])
+def test_sdpa_kernel_choice_boundaries(dev, lq, lk, dk, dv):
+    """Either side of the 256-query rule, d_v != d_k, a d_v that is a multiple of 4 but not of 8 (must stay off the
+    16-query kernel at widths beyond 64), one-tile and many-tile key ranges: out and maps against the oracle."""
+    from lamp_amd import _native as N
+    g = torch.Generator().manual_seed(lq * 7 + lk + dv)
+    n = 3
+    q, k = torch.randn(n, lq, dk, generator=g), torch.randn(n, lk, dk, generator=g)
+    v = torch.randn(n, lk, dv, generator=g)
+    mask = torch.rand(n, lq, lk, generator=g) < 0.35
+    mask[:, :, 0] = False
+    mask[2, lq // 2, :] = True
+    ref_o, ref_a = R.sdpa(q.double(), k.double(), v.double(), mask)
+    o, _ = N.sdpa(q.to(dev), k.to(dev), v.to(dev), mask.to(dev), 1.0 / dk ** 0.5, need_attn=False)
+    o2, a2 = N.sdpa(q.to(dev), k.to(dev), v.to(dev), mask.to(dev), 1.0 / dk ** 0.5, need_attn=True)
+    assert max_abs_diff(o, ref_o) < 2e-5 and max_abs_diff(o2, ref_o) < 2e-5 and max_abs_diff(a2, ref_a) < 5e-6
+    o3, _ = N.sdpa(q.to(dev), k.to(dev), v.to(dev), None, 1.0 / dk ** 0.5, need_attn=False)
+    assert max_abs_diff(o3, R.sdpa(q.double(), k.double(), v.double(), None)[0]) < 2e-5
+
+
 def test_sdpa_online_rescale_is_forced(dev):
     """A key in a LATE tile dominates every earlier one, so the running max jumps and the online
     rescale branch really runs (guide rule: a rare data-dependent branch needs its own test)."""
