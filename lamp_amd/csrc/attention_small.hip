@@ -85,6 +85,10 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
 
     // ---- Q block -> LDS (pre-scaled); the KSPLIT waves of a block share the copy work ----
     float* Qs = smem + qb * 16 * QS;
+    // this wave's K tile (16 keys x d_k), staged through a wave-private LDS block: the tile is fetched with COALESCED loads
+    // (whole 512-byte rows per instruction) and re-read as MFMA fragments; fragment-shaped global loads (16 rows x 64 B per
+    // instruction) run at about a quarter of the rate (profiles/r02_rejected_experiments.txt #9)
+    float* Ks = smem + (QB + wave) * 16 * QS;
     {
         constexpr int C4 = DP / 4;
         constexpr int PER_WAVE = 16 * C4 / KSPLIT;  // float4 per wave
@@ -103,15 +107,23 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     __syncthreads();
 
     const int nt = (p.lk + 15) / 16;
-    float4 kf[DKC];
+    float4 kg[DKC];        // the NEXT tile's K rows in flight (coalesced layout: row = i * RPI + lane / C4K, float4 lane % C4K)
+    constexpr int C4K = DP / 4, RPI = 64 / C4K;   // float4 per K row; rows per load instruction
     float vf[4][DV8];      // V[kt*16 + 4g + r][DV8*l15 + e]: block e of O^T holds the dv columns {DV8*i + e}
     unsigned mbits = 0;    // bit r = key (kt*16 + 4g + r) is blocked for this lane's query (one tile ahead)
 
     auto load_k = [&](int kt) {
-        const unsigned base = unsigned((kt * 16 + l15) * k_r + 4 * g) * 4u;
+        const int c = (lane % C4K) * 4;
 #pragma unroll
-        for (int c = 0; c < DKC; ++c)
-            kf[c] = bload4(rsK, (kt < nt && 16 * c + 4 * g < p.dk) ? base + unsigned(c) * 64u : OOB, 0);
+        for (int i = 0; i < DKC; ++i) {
+            const int row = i * RPI + lane / C4K;
+            kg[i] = bload4(rsK, (kt < nt && c < p.dk) ? unsigned((kt * 16 + row) * k_r + c) * 4u : OOB, 0);
+        }
+    };
+    auto stage_k = [&]() {   // registers -> this wave's LDS block (its reads of the previous tile are behind us: in order)
+        const int c = (lane % C4K) * 4;
+#pragma unroll
+        for (int i = 0; i < DKC; ++i) *reinterpret_cast<float4*>(Ks + (i * RPI + lane / C4K) * QS + c) = kg[i];
     };
     auto load_v = [&](int kt) {
         const bool col_ok = kt < nt && DV8 * l15 < p.dv;  // d_v is a multiple of DV8 (attn_small_applies): all-or-nothing
@@ -157,18 +169,21 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     auto scores = [&](int kt, f32x4& s) {
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
         const float* qp = Qs + l15 * QS + 4 * g;   // lane (query l15, group g): Q[q][16c + 4g + j]
+        const float* kp = Ks + l15 * QS + 4 * g;   // lane (key   l15, group g): K[k][16c + 4g + j]
 #pragma unroll
         for (int c = 0; c < DKC; c += 2) {
             const float4 qa = *reinterpret_cast<const float4*>(qp + 16 * c);
             const float4 qb2 = *reinterpret_cast<const float4*>(qp + 16 * c + 16);
-            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].x, qa.x, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].x, qb2.x, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].y, qa.y, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].y, qb2.y, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].z, qa.z, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].z, qb2.z, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].w, qa.w, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c + 1].w, qb2.w, s1, 0, 0, 0);
+            const float4 ka = *reinterpret_cast<const float4*>(kp + 16 * c);
+            const float4 kb = *reinterpret_cast<const float4*>(kp + 16 * c + 16);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qa.x, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.x, qb2.x, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qa.y, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.y, qb2.y, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.z, qa.z, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.z, qb2.z, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.w, qa.w, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.w, qb2.w, s1, 0, 0, 0);
         }
         const int kbase = kt * 16 + 4 * g;
 #pragma unroll
@@ -196,6 +211,7 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
         for (; kt < nt; kt += KSPLIT) {
             const int kn = kt + KSPLIT;   // past the end: range-checked zeros
             f32x4 s;
+            stage_k();       // the tile requested one iteration ago: registers -> LDS, read back as fragments by scores()
             scores(kt, s);
             // pin the order "MFMAs of this tile, THEN the next tile's loads into the registers they just freed": hoisted
             // above the MFMAs the loads need a second register set (K and V double-buffered = +64 VGPRs, spills at 3 waves)
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
 template <int DP, int QB, int KSPLIT, int PM, int MK>
 static int launch_small_mk(const AttnParams& p, hipStream_t s) {
     constexpr int NW = QB * KSPLIT;
-    constexpr size_t lds_q = size_t(QB) * 16 * (DP + 4) * sizeof(float);
+    constexpr size_t lds_q = size_t(QB + NW) * 16 * (DP + 4) * sizeof(float);   // Q blocks + one K tile per wave
     constexpr size_t lds_c = KSPLIT > 1 ? size_t(NW) * (DP / 16 * 4 + 4) * 64 * sizeof(float) : 0;
     constexpr size_t lds = lds_q > lds_c ? lds_q : lds_c;
     auto kern = attn16_kernel<DP, QB, KSPLIT, PM, MK>;
