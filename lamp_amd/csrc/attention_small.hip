@@ -109,7 +109,7 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     const int nt = (p.lk + 15) / 16;
     float4 kg[DKC];        // the NEXT tile's K rows in flight (coalesced layout: row = i * RPI + lane / C4K, float4 lane % C4K)
     constexpr int C4K = DP / 4, RPI = 64 / C4K;   // float4 per K row; rows per load instruction
-    float vf[4][DV8];      // V[kt*16 + 4g + r][DV8*l15 + e]: block e of O^T holds the dv columns {DV8*i + e}
+    float vf[4][DV8];      // V[kt*16 + 4g + r][.]: block e of O^T holds the d_v columns given at load_v below
     unsigned mbits = 0;    // bit r = key (kt*16 + 4g + r) is blocked for this lane's query (one tile ahead)
 
     auto load_k = [&](int kt) {
@@ -125,14 +125,20 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
 #pragma unroll
         for (int i = 0; i < DKC; ++i) *reinterpret_cast<float4*>(Ks + (i * RPI + lane / C4K) * QS + c) = kg[i];
     };
+    // V columns of a lane: DVW consecutive floats per load, the 16 lanes of a group side by side (whole cache lines per
+    // row and instruction).  d = 128 takes two such loads 64 columns apart: block e of O^T then holds the d_v columns
+    // {4 i + e} (e < 4) and {64 + 4 i + e - 4} (e >= 4), i = the block's row index -- see the store at the end.
+    constexpr int DVW = DV8 == 8 ? 4 : DV8;
     auto load_v = [&](int kt) {
-        const bool col_ok = kt < nt && DV8 * l15 < p.dv;  // d_v is a multiple of DV8 (attn_small_applies): all-or-nothing
-        const unsigned base = unsigned((kt * 16 + 4 * g) * v_r + DV8 * l15) * 4u;
+        const bool col_ok = kt < nt && DVW * l15 < p.dv;         // d_v is a multiple of 4: all-or-nothing per load
+        const bool col_ok2 = kt < nt && 64 + DVW * l15 < p.dv;   // second half (d = 128 only)
+        const unsigned base = unsigned((kt * 16 + 4 * g) * v_r + DVW * l15) * 4u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const unsigned off = col_ok ? base + unsigned(r * v_r) * 4u : OOB;
             if constexpr (DV8 == 8) {
-                const float4 a = bload4(rsV, off, 0), c2 = bload4(rsV, off == OOB ? OOB : off + 16u, 0);
+                const float4 a = bload4(rsV, off, 0);
+                const float4 c2 = bload4(rsV, col_ok2 ? base + unsigned(r * v_r) * 4u + 256u : OOB, 0);
                 vf[r][0] = a.x; vf[r][1] = a.y; vf[r][2] = a.z; vf[r][3] = a.w;
                 vf[r][4] = c2.x; vf[r][5] = c2.y; vf[r][6] = c2.z; vf[r][7] = c2.w;
             } else if constexpr (DV8 == 4) {
@@ -303,23 +309,24 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     }
     const float inv_l = 1.0f / l_run;   // l = 0 (fully blocked row): 0 * inf = NaN, like torch
 
-    // ---- store: lane (query, g), register r, block e  <->  O[query][DV8*(4g + r) + e] ----
+    // ---- store: lane (query, g), register r, block e  <->  O[query][DVW*(4g + r) + (e % DVW) + 64*(e / DVW)] ----
     if (qi < p.lq) {
         float* Orow = p.O + int64_t(b) * p.lay.o_b + int64_t(h) * p.lay.o_h + int64_t(qi) * p.lay.o_r;
         const bool vec = ((p.lay.o_b | p.lay.o_h | p.lay.o_r) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.O) & 15u) == 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int col = DV8 * (4 * g + r);
-            if (col >= p.dv) continue;
-            if (DV8 >= 4 && vec) {
 #pragma unroll
-                for (int e = 0; e < DV8; e += 4)
-                    *reinterpret_cast<float4*>(Orow + col + e) =
-                        make_float4(o[e][r] * inv_l, o[e + 1 < DV8 ? e + 1 : e][r] * inv_l,
-                                    o[e + 2 < DV8 ? e + 2 : e][r] * inv_l, o[e + 3 < DV8 ? e + 3 : e][r] * inv_l);
-            } else {
+            for (int e0 = 0; e0 < DV8; e0 += DVW) {
+                const int col = DVW * (4 * g + r) + 64 * (e0 / DVW);
+                if (col >= p.dv) continue;
+                if (DVW == 4 && vec) {
+                    *reinterpret_cast<float4*>(Orow + col) =
+                        make_float4(o[e0][r] * inv_l, o[e0 + (DVW > 1 ? 1 : 0)][r] * inv_l,
+                                    o[e0 + (DVW > 2 ? 2 : 0)][r] * inv_l, o[e0 + (DVW > 3 ? 3 : 0)][r] * inv_l);
+                } else {
 #pragma unroll
-                for (int e = 0; e < DV8; ++e) Orow[col + e] = o[e][r] * inv_l;
+                    for (int e = 0; e < DVW; ++e) Orow[col + e] = o[e0 + e][r] * inv_l;
+                }
             }
         }
     }
@@ -389,8 +396,8 @@ static int launch_small_dp(const AttnParams& p, int qb, int ksplit, hipStream_t 
 // either no maps or the single-pass map write-out.  The exact two-pass maps and map-only calls stay in attention.hip.
 bool attn_small_applies(const AttnParams& p, bool any_lq) {
     const int dmax = p.dk > p.dv ? p.dk : p.dv;
-    // a lane reads DP/16 consecutive floats of a V row: d_v must be a whole number of them (8 for 64 < d <= 128)
-    return (p.lq <= 256 || any_lq) && p.V && p.O && (!p.P || p.lse) && dmax <= 128 && (dmax <= 64 || (p.dv & 7) == 0);
+    (void)dmax;
+    return (p.lq <= 256 || any_lq) && p.V && p.O && (!p.P || p.lse) && p.dk <= 128 && p.dv <= 128;
 }
 
 #ifdef LAMP_TUNING
