@@ -53,7 +53,8 @@ struct GemmTile {
 // round trip over 8-16x more matrix work per wave and keep the registers for occupancy.
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
-                                                                          int tiles_n, int tiles_m) {
+                                                                          int tiles_n, int tiles_m,
+                                                                          int panel_split) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
     // lane -> (row within an MFMA block, which group of 4 consecutive k this lane's b128 read covers)
     constexpr int KQ = 64 / MF;             // 2 for 32x32x2, 4 for 16x16x4
@@ -82,13 +83,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     // per group -- instead of the whole W once per ROW-PANEL, which is what the plain row-major walk cost as soon as W
     // alone filled the L2 (K/V projection of reuters: 291 MB fetched for 24 MB of compulsory traffic, round 1).
     // Placement only: every output element is computed by exactly one tile with a k-order fixed by (K, BK).
+    // (3) panel_split: the launch gave every XCD WHOLE row-panels (all their column tiles; workgroups past an XCD's
+    // share exit), so a row of C is written by one XCD only -- the LayerNorm / attention / GEMM that reads it next
+    // walks rows in the same XCD order and finds it in its own L2.  Used when it costs no extra round of tiles.
     constexpr int GROUP_M = 8;
-    const int item = xcd_remap(blockIdx.x, gridDim.x);
+    int item, pan0, pan1;
+    if (panel_split) {
+        const int q = tiles_m >> 3, r = tiles_m & 7, xcd = blockIdx.x & 7;
+        pan0 = xcd * q + (xcd < r ? xcd : r);
+        pan1 = pan0 + q + (xcd < r ? 1 : 0);
+        item = blockIdx.x >> 3;
+        if (item >= (pan1 - pan0) * tiles_n) return;
+    } else {
+        item = xcd_remap(blockIdx.x, gridDim.x);
+        pan0 = 0;
+        pan1 = tiles_m;
+    }
     const int group_sz = GROUP_M * tiles_n;
     const int grp = item / group_sz;
     const int in_grp = item - grp * group_sz;
-    const int first_m = grp * GROUP_M;
-    const int gm = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+    const int first_m = pan0 + grp * GROUP_M;
+    const int gm = pan1 - first_m < GROUP_M ? pan1 - first_m : GROUP_M;
     const int tn_all = in_grp / gm;
     const int tm = first_m + (in_grp - tn_all * gm);
     const int seg = tn_all / tiles_n_seg;
@@ -326,9 +341,14 @@ static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     const int64_t tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n_seg = (p.N + BN - 1) / BN;
     const int tiles_n = tiles_n_seg * p.nseg;
-    const int64_t nwg = tiles_m * tiles_n;
+    int64_t nwg = tiles_m * tiles_n;
     if (nwg > 0x7fffffffLL) return LAMP_E_DIMS;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(T::NT), LDS, s, p, tiles_n_seg, tiles_n, int(tiles_m));
+    // whole row-panels per XCD when the fullest XCD then needs no more rounds of tiles (32 CUs each) than an even split
+    const int64_t pan_xcd = (tiles_m + 7) / 8;
+    const int panel_split = tiles_m >= 16 && (pan_xcd * tiles_n + 31) / 32 <= ((nwg + 7) / 8 + 31) / 32;
+    if (panel_split) nwg = 8 * pan_xcd * tiles_n;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(T::NT), LDS, s, p, tiles_n_seg, tiles_n, int(tiles_m),
+                       panel_split);
     return int(hipGetLastError());
 }
 

@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
                                                     const float* __restrict__ pos_table, int n_position,
                                                     int d, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
-    const int64_t t = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int64_t t = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);  // XCD order of the next GEMM
     if (t >= n_tok) return;
     const int64_t tok = seq[t];
     const int64_t ps = pos_table ? pos[t] : 0;
@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ w_out, int n_labels,
                                                         float* __restrict__ logits, DropoutSpec drop) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    // rows in the XCD-contiguous order of the GEMM that produced x (and of the one that reads y): most of a row's
+    // cache lines are then still in THIS XCD's L2 instead of a round trip to the Infinity Cache away
+    const int64_t row = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float4* xr = reinterpret_cast<const float4*>(x + row * d);
     const float4* rr = res ? reinterpret_cast<const float4*>(res + (r_mod > 0 ? row % r_mod : row) * d) : nullptr;
