@@ -36,7 +36,9 @@ def tuning():
 
 # ------------------------------------------------------------------ building blocks
 @pytest.mark.parametrize('M,K,N_', [(1, 4, 1), (7, 36, 5), (64, 64, 64), (90, 512, 512), (200, 128, 96),
-                                    (2880, 512, 512), (9664, 512, 512), (333, 1024, 2048)])
+                                    (2880, 512, 512), (9664, 512, 512), (333, 1024, 2048),
+                                    # row-panel counts around the whole-panels-per-XCD placement (gemm.hip: panel_split)
+                                    (513, 64, 70), (1024, 512, 64), (4100, 36, 200), (545, 128, 1536)])
 def test_linear_vs_torch_fp64(dev, M, K, N_):
     from lamp_amd import _native as N
     g = torch.Generator().manual_seed(M * 7 + K)
