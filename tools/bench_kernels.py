@@ -219,6 +219,29 @@ def attn():
             print('%-20s mode=%02x mask=%-10s %9.1f us  %6.1f TFLOP/s' % (name, mode, mname, us, fl / us / 1e6))
 
 
+def attn_one():
+    """One attention shape, heuristic variant, bit-packed shared mask, a handful of launches: small enough for a
+    rocprofv3 --pmc pass (tools/pmc_ta.sh).  argv[2] = case name prefix (default 'synthetic self')."""
+    dev = torch.device('cuda:0')
+    want = sys.argv[2] if len(sys.argv) > 2 else 'synthetic self'
+    cases = {'reuters enc-attn': (32, 4, 90, 302, 128), 'reuters self': (32, 4, 90, 90, 128),
+             'delicious self': (32, 8, 983, 983, 128), 'synthetic self': (4, 8, 4096, 4096, 128)}
+    B, H, lq, lk, dk = cases[want]
+    q, k, v = (torch.randn(B, l, H * dk, device=dev) for l in (lq, lk, lk))
+    o = torch.empty(B, lq, H * dk, device=dev)
+    mask = (torch.rand(lq, lk, device=dev) < 0.9).to(torch.uint8)
+    mask[:, 0] = 0
+    bits = N.pack_mask_bits(mask).to(dev)
+    ms = N.Mask(N.LAMP_MASK_BITS_U32, 0, bits.data_ptr(), 0, bits.size(1))
+    lay = N.AttnLayout(lq * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lq * H * dk, dk, H * dk)
+
+    def fn():
+        N.check(N.lib().lamp_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), None, B, H, lq, lk, dk, dk,
+                                      dk ** -0.5, ctypes.byref(ms), ctypes.byref(lay), N.stream()), 'sdpa')
+    us = time_fn(fn, iters=4, warm=2)
+    print('%-20s %9.1f us  %6.1f TFLOP/s' % (want, us, 4.0 * B * H * lq * lk * dk / us / 1e6))
+
+
 def residency():
     """Forward-GEMM shapes with the workgroups per CU limited by extra LDS (tuning build): does a launch whose tiles no
     longer fit one round -- phases out of lockstep -- beat the all-resident one?"""
@@ -362,4 +385,4 @@ def gemm_trace():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
     {'gemm': gemm, 'gemm_ab': gemm_ab, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
-     'gemm_trace': gemm_trace, 'ln': ln, 'attn_trace': attn_trace, 'residency': residency}[which]()
+     'gemm_trace': gemm_trace, 'ln': ln, 'attn_one': attn_one, 'attn_trace': attn_trace, 'residency': residency}[which]()
