@@ -45,7 +45,7 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // the single-pass kernel at full speed; softmax_from_scores_kernel then turns the scores into probabilities in
 // place (training forward: the maps are needed for the backward pass).
 template <int DP, int KSPLIT, int PM, int MK>
-__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     constexpr bool WRITE_P = PM == 1;
     static_assert(!WRITE_P || KSPLIT == 1, "probability write-out uses unsplit keys");
     constexpr int DKC = DP / 8, DVB = DP / 32, QB = 4 / KSPLIT, QS = DP + 4;
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                 const int kn = tile_at(idx + KSPLIT);  // next tile of this wave (past-the-end: range-checked zeros)
                 f32x16 s;
                 scores(kt, s);
+                __builtin_amdgcn_sched_barrier(0);
                 load_k(kn);     // unconditional prefetch, flies under softmax + PV
                 load_mask(kn);
                 if constexpr (PM == 2) {
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                 psum += xor32(psum);
                 l_run += psum;
                 pv(s, o);
+                __builtin_amdgcn_sched_barrier(0);
                 load_v(kn);  // flies under the next QK^T
                 kt = kn;
             }
