@@ -45,7 +45,7 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // the single-pass kernel at full speed; softmax_from_scores_kernel then turns the scores into probabilities in
 // place (training forward: the maps are needed for the backward pass).
 template <int DP, int KSPLIT, int PM, int MK>
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, PM == 0 ? 2 : 1) void attn_kernel(AttnParams p) {
     constexpr bool WRITE_P = PM == 1;
     static_assert(!WRITE_P || KSPLIT == 1, "probability write-out uses unsplit keys");
     constexpr int DKC = DP / 8, DVB = DP / 32, QB = 4 / KSPLIT, QS = DP + 4;

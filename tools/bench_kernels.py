@@ -242,6 +242,25 @@ def attn_one():
     print('%-20s %9.1f us  %6.1f TFLOP/s' % (want, us, 4.0 * B * H * lq * lk * dk / us / 1e6))
 
 
+def attn_maps():
+    """The map-writing variants of the large-shape kernel (PM = 1 exact two-pass / PM = 2 single pass + scores), us."""
+    dev = torch.device('cuda:0')
+    for name, B, H, lq, lk, dk in (('delicious self', 8, 8, 983, 983, 128), ('synthetic self', 1, 8, 4096, 4096, 128),
+                                   ('reuters enc self-attn maps', 32, 4, 302, 302, 128)):
+        q, k, v = (torch.randn(B, l, H * dk, device=dev) for l in (lq, lk, lk))
+        mask = (torch.rand(lq, lk, device=dev) < 0.9).to(torch.uint8)
+        mask[:, 0] = 0
+        bits = N.pack_mask_bits(mask).to(dev)
+        toks = (torch.rand(B, lk, device=dev) < 0.9).long()
+        toks[:, 0] = 1
+        for mname, ms in (('shared-bits', N.Mask(N.LAMP_MASK_BITS_U32, 0, bits.data_ptr(), 0, bits.size(1))),
+                          ('key-tokens', N.Mask(N.LAMP_MASK_KEY_TOKENS_I64, 0, toks.data_ptr(), lk, 0))):
+            t0 = time_fn(lambda: N.sdpa_fused(q, k, v, H, ms, dk ** -0.5, need_attn=False), iters=5, warm=2)
+            t1 = time_fn(lambda: N.sdpa_fused(q, k, v, H, ms, dk ** -0.5, need_attn=True), iters=5, warm=2)
+            t2 = time_fn(lambda: N.sdpa_fused(q, k, v, H, ms, dk ** -0.5, need_attn=True, fast_maps=True), iters=5, warm=2)
+            print('%-28s %-12s no maps %9.1f   exact two-pass maps %9.1f   single-pass maps %9.1f' % (name, mname, t0, t1, t2))
+
+
 def residency():
     """Forward-GEMM shapes with the workgroups per CU limited by extra LDS (tuning build): does a launch whose tiles no
     longer fit one round -- phases out of lockstep -- beat the all-resident one?"""
@@ -385,4 +404,4 @@ def gemm_trace():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
     {'gemm': gemm, 'gemm_ab': gemm_ab, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
-     'gemm_trace': gemm_trace, 'ln': ln, 'attn_one': attn_one, 'attn_trace': attn_trace, 'residency': residency}[which]()
+     'gemm_trace': gemm_trace, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency}[which]()
