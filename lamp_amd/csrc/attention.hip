@@ -30,6 +30,13 @@
 // for the mask bytes -- and with it for the whole V prefetch -- in front of the QK^T MFMAs; hence the
 // one-tile-ahead mask registers.
 //
+// Occupancy: the loop is written with ONE K tile and ONE V tile in registers (64 + 64 beside the 64 accumulators), but
+// with 512 registers on offer hipcc hoists the next tile's loads above the MFMAs and double-buffers both by itself
+// (370-430 registers, one wave per SIMD, whose softmax VALU work then serialises with its own MFMAs).  The two
+// sched_barrier(0) in the loop pin the written order; the variants without map output (PM == 0) then fit 240 registers and
+// run two waves per SIMD: 118 -> 128 TFLOP/s at L = 4096 (profiles/r02_attn_variants.txt).  The map-writing variants
+// spill at 256 registers and stay at one wave (measured both ways, profiles/r02_attn_maps.txt).
+//
 // Masking follows the reference: blocked scores become -inf BEFORE the softmax; a fully blocked
 // row therefore has zero row-sum and comes out NaN (0 * inf), exactly like torch's
 // softmax(-inf, ..., -inf) -- lamp/SubLayers.py:31-39, SURVEY.md G10.
