@@ -18,7 +18,8 @@ for line in r.stderr.splitlines():
     m = re.search(r'Function Name: (\S+)', line) or re.search(r' Name: (\S+)', line)
     if m:
         name = subprocess.run(['c++filt', m.group(1)], capture_output=True, text=True).stdout.strip()
-        cur = {'name': name.split('(')[0].replace('void lamp::', '')}
+        name = name.replace('(anonymous namespace)::', '')
+        cur = {'name': name.split('(')[0].replace('void lamp::', '').replace('lamp::', '')}
         rows.append(cur)
         continue
     for key, pat in (('sgpr', r'TotalSGPRs: (\d+)'), ('vgpr', r' VGPRs: (\d+)'), ('agpr', r'AGPRs: (\d+)'),
