@@ -33,6 +33,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY dynamic symbols. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define LAMP_HIP_ABI_VERSION 2
 
@@ -347,6 +351,9 @@ int lamp_prof_reset(void);
 int lamp_prof_read(int32_t kernel_class, int64_t* launches, double* total_ms, double* flops,
                    double* bytes);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

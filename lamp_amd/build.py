@@ -24,7 +24,7 @@ SOURCES = ['gemm.hip', 'gemm_gen.hip', 'attention.hip', 'attention_small.hip', '
            'backward.hip', 'api.hip']
 TUNING_SOURCES = {'gemm.hip', 'attention.hip', 'attention_small.hip'}   # the units that contain LAMP_TUNING code
 HEADERS = [os.path.join(CSRC, 'lamp_kernels.h'), os.path.join(HERE, '..', 'include', 'lamp_hip.h')]
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-fvisibility-inlines-hidden', '-Wno-unused-result']
 
 
 def _hipcc():

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void softmax_from_scores_kernel(float* __restr
 // Tuning build only (liblamp_hip_tuning.so): 0 = heuristic; bits 0-2: force that key split (1/2/4); bits 4-6: query
 // blocks per workgroup of the small-shape kernel (attention_small.hip).
 static int g_force_attn = 0;
-extern "C" void lamp_debug_force_attn(int v) { g_force_attn = v; }
+extern "C" __attribute__((visibility("default"))) void lamp_debug_force_attn(int v) { g_force_attn = v; }
 #else
 constexpr int g_force_attn = 0;
 #endif

@@ -402,7 +402,7 @@ bool attn_small_applies(const AttnParams& p, bool any_lq) {
 
 #ifdef LAMP_TUNING
 static unsigned long long* g_attn_trace = nullptr;   // 8 words per workgroup of the NEXT small-shape launch(es)
-extern "C" void lamp_debug_set_attn_trace(unsigned long long* buf) { g_attn_trace = buf; }
+extern "C" __attribute__((visibility("default"))) void lamp_debug_set_attn_trace(unsigned long long* buf) { g_attn_trace = buf; }
 #endif
 
 // force: 0 = heuristic; else (tuning build) key shares in bits 0-2, query blocks per workgroup in bits 4-6.

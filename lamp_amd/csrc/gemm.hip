@@ -318,7 +318,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
 
 #ifdef LAMP_TUNING
 static size_t g_extra_lds = 0;
-extern "C" void lamp_debug_set_gemm_extra_lds(int bytes) { g_extra_lds = size_t(bytes); }
+extern "C" __attribute__((visibility("default"))) void lamp_debug_set_gemm_extra_lds(int bytes) { g_extra_lds = size_t(bytes); }
 #endif
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF>
@@ -365,8 +365,8 @@ static int g_force_tile = 0;
 static unsigned long long* g_gemm_trace = nullptr;  // n_slabs slabs of slab_words u64: launch i records into slab i % n_slabs,
 static long long g_trace_slab = 0;                  // 8 words per workgroup (entry, loop start, loop end, exit: wall_clock64
 static int g_trace_slabs = 0, g_trace_count = 0;    // ticks; HW_ID; XCC_ID; work item; -)
-extern "C" void lamp_debug_force_gemm_tile(int cfg) { g_force_tile = cfg; }
-extern "C" void lamp_debug_set_gemm_trace(unsigned long long* buf, long long slab_words, int n_slabs) {
+extern "C" __attribute__((visibility("default"))) void lamp_debug_force_gemm_tile(int cfg) { g_force_tile = cfg; }
+extern "C" __attribute__((visibility("default"))) void lamp_debug_set_gemm_trace(unsigned long long* buf, long long slab_words, int n_slabs) {
     g_gemm_trace = buf;
     g_trace_slab = slab_words;
     g_trace_slabs = n_slabs;
