@@ -392,12 +392,12 @@ static int launch_small_dp(const AttnParams& p, int qb, int ksplit, hipStream_t 
     }
 }
 
-// The shapes this kernel takes (a function of the per-sample shape ONLY): at most 256 queries, with V and O given and
-// either no maps or the single-pass map write-out.  The exact two-pass maps and map-only calls stay in attention.hip.
+// The shapes this kernel takes (a function of the per-sample shape ONLY): at most 256 queries -- or any number of queries
+// over at most 64 keys (delicious' 983 labels x 40 tokens: 135 -> 121 us; 300 x 100 would be 52 -> 35, but 983 x 100 is a
+// tie and the self-attention shapes beyond 256 belong to attention.hip) -- with V and O given and either no maps or the
+// single-pass map write-out.  The exact two-pass maps and map-only calls stay in attention.hip.
 bool attn_small_applies(const AttnParams& p, bool any_lq) {
-    const int dmax = p.dk > p.dv ? p.dk : p.dv;
-    (void)dmax;
-    return (p.lq <= 256 || any_lq) && p.V && p.O && (!p.P || p.lse) && p.dk <= 128 && p.dv <= 128;
+    return (p.lq <= 256 || p.lk <= 64 || any_lq) && p.V && p.O && (!p.P || p.lse) && p.dk <= 128 && p.dv <= 128;
 }
 
 #ifdef LAMP_TUNING

@@ -59,7 +59,7 @@ struct AttnParams {
 int launch_gemm(const GemmParams& p, hipStream_t s);
 int launch_attn(const AttnParams& p, hipStream_t s);
 int launch_attn_general(const AttnParams& p, hipStream_t s);  // any d_k / d_v: scores through memory
-bool attn_small_applies(const AttnParams& p, bool any_lq = false);  // attention_small.hip: lq <= 256 (shape-only rule)
+bool attn_small_applies(const AttnParams& p, bool any_lq = false);  // attention_small.hip: lq <= 256 or lk <= 64 (shape-only rule)
 int launch_attn_small(const AttnParams& p, int force_ksplit, hipStream_t s);
 size_t gemm_gen_workspace_bytes(int M, int N, int K, int batch);
 int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStream_t s);

@@ -133,9 +133,9 @@ def test_sdpa_vs_oracle_shapes(dev, lq, lk, dk):
 
 
 @pytest.mark.parametrize('mode', [1, 2, 4, 0x12, 0x22, 0x32, 0x42, 0x14, 0x24, 0x34, 0x41])
-@pytest.mark.parametrize('lq,lk,dk', [(90, 302, 128), (70, 33, 64), (200, 513, 32), (5, 1, 16), (300, 130, 128), (260, 40, 24)])
+@pytest.mark.parametrize('lq,lk,dk', [(90, 302, 128), (70, 33, 64), (200, 513, 32), (5, 1, 16), (300, 130, 128), (260, 70, 24), (260, 40, 24)])
 def test_sdpa_every_kernel_variant(dev, tuning, mode, lq, lk, dk):
-    """The attention kernels (16-query blocks up to 256 queries, 32-query blocks beyond and for exact maps) with
+    """The attention kernels (16-query blocks up to 256 queries or 64 keys, 32-query blocks beyond and for exact maps) with
     1/2/4-way key split must agree with the oracle in every variant, masks and dead rows included."""
     from lamp_amd import _native as N
     force = tuning.lamp_debug_force_attn
@@ -157,9 +157,10 @@ def test_sdpa_every_kernel_variant(dev, tuning, mode, lq, lk, dk):
 
 
 @pytest.mark.parametrize('lq,lk,dk,dv', [(256, 40, 128, 128), (257, 40, 128, 128), (16, 16, 128, 128), (17, 191, 128, 72),
-                                         (90, 302, 128, 100), (90, 302, 64, 128), (255, 3, 36, 20), (1, 500, 8, 8)])
+                                         (90, 302, 128, 100), (90, 302, 64, 128), (255, 3, 36, 20), (1, 500, 8, 8),
+                                         (257, 64, 128, 128), (257, 65, 128, 128), (983, 40, 128, 128), (300, 100, 64, 64)])
 def test_sdpa_kernel_choice_boundaries(dev, lq, lk, dk, dv):
-    """Either side of the 256-query rule, d_v != d_k, a d_v that is a multiple of 4 but not of 8 (must stay off the
+    """Either side of the 256-query / 64-key rule, d_v != d_k, a d_v that is a multiple of 4 but not of 8 (must stay off the
     16-query kernel at widths beyond 64), one-tile and many-tile key ranges: out and maps against the oracle."""
     from lamp_amd import _native as N
     g = torch.Generator().manual_seed(lq * 7 + lk + dv)
