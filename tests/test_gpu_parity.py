@@ -88,11 +88,12 @@ def test_linear_detects_transposed_or_shifted_tiles(dev):
     assert max_abs_diff(N.linear(x.to(dev), w.to(dev)), ref) < 1e-4
 
 
-@pytest.mark.parametrize('d', [4, 64, 512, 1024, 2048])
-def test_layernorm(dev, d):
+@pytest.mark.parametrize('d,M', [(4, 37), (64, 37), (512, 37), (1024, 37), (2048, 37), (512, 1), (512, 5), (512, 1025),
+                                 (512, 2883)])   # row counts around the XCD-contiguous row order (4 rows per workgroup)
+def test_layernorm(dev, d, M):
     from lamp_amd import _native as N
-    g = torch.Generator().manual_seed(d)
-    x = torch.randn(37, d, generator=g) * 3 + 1
+    g = torch.Generator().manual_seed(d + M)
+    x = torch.randn(M, d, generator=g) * 3 + 1
     gm, bt = torch.randn(d, generator=g), torch.randn(d, generator=g)
     ref = torch.nn.functional.layer_norm(x.double(), (d,), gm.double(), bt.double(), 1e-5)
     assert max_abs_diff(N.layernorm(x.to(dev), gm.to(dev), bt.to(dev)), ref) < 2e-5
