@@ -9,7 +9,6 @@ the device as uint8 and broadcast over batch and heads by the kernel, instead of
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import Constants, utils
 from . import _native as N
@@ -100,95 +99,87 @@ class GraphDecoder(nn.Module):
 
 
 class MLPDecoder(nn.Module):
-    """Binary-relevance baseline (lamp/Decoders.py:76-93): Linear -> ReLU -> Dropout -> Linear over the encoder's
-    vector; returns ((B, 1, n_tgt_vocab),).  Plain PyTorch, parameter names as in the reference."""
+    """Binary-relevance baseline: a two-layer perceptron (hidden width d_model, ReLU, dropout) scoring every label from
+    the encoder's single vector per sample; output ``((B, 1, n_tgt_vocab),)``.  Behaviour of lamp/Decoders.py:76-93;
+    only the attribute names ``linear1`` / ``linear4`` / ``dropout`` are kept, for checkpoint compatibility.  Plain
+    PyTorch: not on the hot path."""
 
     def __init__(self, n_tgt_vocab, n_max_seq_e, n_max_seq_d, n_layers=6, n_head=8, d_k=64, d_v=64, d_word_vec=512,
                  d_model=512, d_inner_hid=1024, dropout=0.1, enc_transform='mean'):
         super().__init__()
-        self.n_max_seq = n_max_seq_e
-        self.d_model = d_model
-        self.dropout = nn.Dropout(dropout)
-        self.enc_transform = enc_transform
-        if enc_transform in ['flatten']:
-            raise NotImplementedError
+        if enc_transform == 'flatten':
+            raise NotImplementedError("the mlp decoder takes one d_model vector per sample, not a flattened sequence")
+        self.n_max_seq, self.d_model, self.enc_transform = n_max_seq_e, d_model, enc_transform
         self.linear1 = nn.Linear(d_model, d_model)
+        self.dropout = nn.Dropout(dropout)
         self.linear4 = nn.Linear(d_model, n_tgt_vocab)
 
     def forward(self, tgt_seq, src_seq, enc_output, return_attns=False, int_preds=False):
-        batch_size = src_seq.size(0)
-        out1 = self.dropout(F.relu(self.linear1(enc_output.float())))
-        return self.linear4(out1).view(batch_size, 1, -1),
+        scorer = nn.Sequential(self.linear1, nn.ReLU(), self.dropout, self.linear4)
+        return (scorer(enc_output.to(torch.float32)).reshape(src_seq.size(0), 1, -1),)
 
 
-def _dot_attention(q, k, v, temperature, blocked):
-    """lamp/SubLayers.py:27-43 in plain PyTorch (eval-mode dropout = identity is applied by the caller's module):
-    the RNN decoder's one-query attention over the encoder states."""
-    attn = torch.bmm(q, k.transpose(1, 2)) / temperature
-    if blocked is not None:
-        attn = attn.masked_fill(blocked.bool(), float('-inf'))
-    attn = torch.softmax(attn, dim=2)
-    return attn
-
-
-class _PlainAttention(nn.Module):
-    """ScaledDotProductAttention as the RNN decoder holds it (no parameters; temperature = d_model as the reference
-    passes it, lamp/Decoders.py:30), differentiable PyTorch so that train.py works for the baseline too."""
+class _MemoryReader(nn.Module):
+    """What the reference's parameter-free ScaledDotProductAttention does for the RNN decoder (lamp/SubLayers.py:27-43
+    with one query row): a softmax-weighted summary of the encoder states.  Scores are divided by ``temperature``
+    (the reference passes d_model itself, lamp/Decoders.py:30), blocked keys get -inf, dropout acts on the weights."""
 
     def __init__(self, temperature, dropout=0.1):
         super().__init__()
         self.temperature = temperature
         self.dropout = nn.Dropout(dropout)
-        self.attn_type = nn.Softmax(dim=2)
 
-    def forward(self, q, k, v, attn_mask=None, stop_sig=False):
-        attn = self.dropout(_dot_attention(q, k, v, self.temperature, attn_mask))
-        return torch.bmm(attn, v), attn
+    def forward(self, query, memory, blocked=None):
+        """query (B, d), memory (B, T, d), blocked (B, T) bool or None -> summary (B, d), weights (B, T)."""
+        weights = (memory @ query.unsqueeze(2)).squeeze(2) / self.temperature
+        if blocked is not None:
+            weights = weights.masked_fill(blocked.reshape(weights.shape).bool(), float('-inf'))
+        weights = self.dropout(torch.softmax(weights, dim=1))
+        return (weights.unsqueeze(1) @ memory).squeeze(1), weights
 
 
 class RNNDecoder(nn.Module):
-    """Autoregressive GRU baseline with attention over the encoder states (lamp/Decoders.py:16-72): every step feeds
-    the arg-max label of the previous one; returns ((B, len, n_tgt_vocab),).  Plain PyTorch."""
+    """Autoregressive GRU baseline (behaviour of lamp/Decoders.py:16-72): the recurrent state starts at the mean
+    encoder state; every step embeds the previous label, lets each layer read the encoder states with the current
+    state as the query, feeds [input, summary] through that layer's one-step GRU, and scores the labels as
+    U(state) + V(top layer output) + C(last summary).  The next input is the arg-max label (no teacher forcing).
+    Returns ``((B, len, n_tgt_vocab),)``.  Attribute names follow the reference's state_dict; plain PyTorch."""
 
     def __init__(self, n_tgt_vocab, n_max_seq, n_layers=6, n_head=8, d_k=64, d_v=64, d_word_vec=512, d_model=512,
                  d_inner_hid=1024, dropout=0.1):
         super().__init__()
-        self.n_max_seq = n_max_seq
-        self.d_model = d_model
-        self.n_tgt_vocab = n_tgt_vocab
+        self.n_max_seq, self.d_model, self.n_tgt_vocab = n_max_seq, d_model, n_tgt_vocab
         self.tgt_word_emb = nn.Embedding(n_tgt_vocab, d_word_vec, padding_idx=Constants.PAD)
         self.dropout = nn.Dropout(dropout)
-        self.attention_stack = nn.ModuleList([_PlainAttention(d_model, dropout=dropout) for _ in range(n_layers)])
+        self.attention_stack = nn.ModuleList(_MemoryReader(d_model, dropout) for _ in range(n_layers))
         self.rnn_layer_stack = nn.ModuleList(
-            [nn.GRU(d_model + d_word_vec, d_model, batch_first=True, dropout=dropout) for _ in range(n_layers)])
-        self.U = nn.Linear(self.d_model, self.n_tgt_vocab)
-        self.V = nn.Linear(self.d_model, self.n_tgt_vocab)
-        self.C = nn.Linear(self.d_model, self.n_tgt_vocab)
+            nn.GRU(d_model + d_word_vec, d_model, batch_first=True, dropout=dropout) for _ in range(n_layers))
+        self.U, self.V, self.C = (nn.Linear(d_model, n_tgt_vocab) for _ in range(3))
 
-    def forward_step(self, input_var, decoder_hidden, encoder_outputs, dec_enc_attn_pad_mask=None):
-        batch_size = input_var.size(0)
-        embedded = self.tgt_word_emb(input_var)
-        decoder_hidden = decoder_hidden.view(batch_size, 1, -1)
-        if encoder_outputs.size(1) == 1:
-            dec_enc_attn_pad_mask = None
-        for idx, dec_layer in enumerate(self.rnn_layer_stack):
-            context, attn = self.attention_stack[idx](decoder_hidden.view(batch_size, 1, -1), encoder_outputs,
-                                                      encoder_outputs, dec_enc_attn_pad_mask)
-            rnn_input = torch.cat((embedded, context), 2)
-            embedded, decoder_hidden = dec_layer(rnn_input, decoder_hidden.view(1, batch_size, -1).contiguous())
-        output = self.U(decoder_hidden)
-        output = output + self.V(embedded.view(batch_size, -1))
-        output = output + self.C(context.view(batch_size, -1))
-        return output, decoder_hidden, attn
+    def step(self, token, state, memory, pad=None):
+        """One decoding step.  token (B,) int64, state (B, d), memory (B, T, d), pad (B, T) True on PAD keys
+        -> label scores (B, n_tgt_vocab), new state (B, d), the last layer's read weights (B, T)."""
+        if memory.size(1) == 1:      # a vector encoder hands over one state per sample: nothing to mask
+            pad = None
+        feed = self.tgt_word_emb(token.reshape(-1))
+        for read, cell in zip(self.attention_stack, self.rnn_layer_stack):
+            summary, weights = read(state, memory, pad)
+            y, h = cell(torch.cat([feed, summary], dim=1).unsqueeze(1), state.unsqueeze(0).contiguous())
+            feed, state = y[:, 0], h[0]
+        return self.U(state) + self.V(feed) + self.C(summary), state, weights
+
+    def forward_step(self, token, state, memory, pad=None):
+        """The reference's calling convention for ``step`` (its Translator uses it): scores and state come back with
+        a leading length-1 axis."""
+        scores, state, weights = self.step(token, state.reshape(token.size(0), -1), memory, pad)
+        return scores.unsqueeze(0), state.unsqueeze(0), weights.unsqueeze(1)
 
     def forward(self, tgt_seq, src_seq, enc_output, return_attns=False, int_preds=False):
-        batch_size = enc_output.size(0)
-        pad_mask = utils.get_attn_padding_mask(tgt_seq, src_seq, unsqueeze=False)
-        dec_output = torch.zeros(tgt_seq.size(0), tgt_seq.size(1), self.n_tgt_vocab, device=enc_output.device)
-        dec_input = tgt_seq[:, 0].unsqueeze(1)
-        decoder_hidden = enc_output.mean(1)
-        for di in range(tgt_seq.size(1)):
-            decoder_output, decoder_hidden, _ = self.forward_step(dec_input, decoder_hidden, enc_output, pad_mask)
-            dec_output[:, di, :] = decoder_output
-            dec_input = F.log_softmax(decoder_output.view(batch_size, -1), dim=1).topk(1)[1].view(batch_size, -1)
-        return dec_output,
+        pad = src_seq.eq(Constants.PAD)
+        token, state = tgt_seq[:, 0], enc_output.mean(dim=1)
+        per_step = []
+        for _ in range(tgt_seq.size(1)):
+            scores, state, _ = self.step(token, state, enc_output, pad)
+            per_step.append(scores)
+            token = scores.argmax(dim=1)
+        return (torch.stack(per_step, dim=1),)

@@ -89,13 +89,12 @@ class MLPEncoder(nn.Module):
     def __init__(self, n_src_vocab, n_max_seq, n_layers=6, n_head=8, d_k=64, d_v=64, d_word_vec=512, d_model=512,
                  d_inner_hid=1024, onehot=False, dropout=0.1):
         super().__init__()
-        self.n_max_seq = n_max_seq
-        self.d_model = d_model
+        self.n_max_seq, self.d_model = n_max_seq, d_model
         self.linear1 = nn.Linear(n_src_vocab, d_model)
 
     def forward(self, src_seq, adj, src_pos, return_attns=False):
-        enc_output = self.linear1(src_seq)
-        return enc_output.view(src_seq.size(0), 1, -1), None
+        # one "token" per sample: the projected feature row
+        return self.linear1(src_seq).unsqueeze(1), None
 
 
 class RNNEncoder(nn.Module):
@@ -112,6 +111,5 @@ class RNNEncoder(nn.Module):
         self.U = nn.Linear(d_model * 2, d_model)
 
     def forward(self, src_seq, adj, src_pos, return_attns=False):
-        enc_input = self.src_word_emb(src_seq)
-        enc_output, _ = self.brnn(enc_input)
-        return self.U(enc_output), None
+        both_directions = self.brnn(self.src_word_emb(src_seq))[0]   # (B, T, 2 d_model)
+        return self.U(both_directions), None

@@ -12,14 +12,6 @@ from . import Constants
 from .Beam import Beam
 
 
-def get_attn_padding_mask(seq_q, seq_k, unsqueeze=True):
-    """(B, 1 or len_q, len_k) bool, True where the key is PAD (lamp/Translator.py:12-20)."""
-    if seq_q.dim() != 2 or seq_k.dim() != 2:
-        raise ValueError('expected 2-D index tensors')
-    mask = seq_k.eq(Constants.PAD).unsqueeze(1)
-    return mask.expand(seq_k.size(0), seq_q.size(1), seq_k.size(1)) if unsqueeze else mask
-
-
 def translate(model, opt, src_batch, adj):
     src_seq, src_pos = src_batch
     device = src_seq.device
@@ -44,10 +36,8 @@ def translate(model, opt, src_batch, adj):
     for i in range(opt.max_token_seq_len_d):
         partial = torch.stack([b.get_current_state() for b in beams if not b.done]).view(-1, i + 1).to(device)
         if opt.decoder == 'rnn_m':
-            pad_mask = get_attn_padding_mask(partial, src_seq, unsqueeze=False)
-            dec_output, decoder_hidden, _ = model.decoder.forward_step(partial[:, -1].unsqueeze(1), decoder_hidden.squeeze(),
-                                                                       enc_output, dec_enc_attn_pad_mask=pad_mask)
-            dec_output = dec_output[-1, :, :]
+            dec_output, decoder_hidden, _ = model.decoder.step(partial[:, -1], decoder_hidden, enc_output,
+                                                               src_seq.eq(Constants.PAD))
         else:
             dec_output, *_ = model.decoder(partial, src_seq, enc_output)
             dec_output = model.tgt_word_proj(dec_output[:, -1, :])
@@ -62,7 +52,7 @@ def translate(model, opt, src_batch, adj):
         src_seq = keep_active(src_seq, idx)
         enc_output = keep_active(enc_output, idx)
         if decoder_hidden is not None:
-            decoder_hidden = keep_active(decoder_hidden.transpose(0, 1), idx).transpose(0, 1)
+            decoder_hidden = keep_active(decoder_hidden, idx)
         slot_of = {b: s for s, b in enumerate(still)}
         n_active = len(still)
 
