@@ -21,6 +21,10 @@ BASELINE.json configs[4] (4096 labels x 512 tokens, d_model 1024, batch 8192 ove
 
 Rank 0 prints ONE JSON line with, besides the contract fields,
   ranks_seen / per_rank   which ranks reported and each one's own samples/s,
+  cross_rank_check        SURVEY.md 8e's contract, checked across real devices: every rank holds the SAME weights and
+                          its OWN batch; after the timed region rank 0 re-runs the first samples of every other rank's
+                          batch on its own device and compares the logits that rank computed bit for bit (exit 4 on a
+                          mismatch).  Under "nccl" rank 0 also requires one physical device per rank (exit 5),
   roofline      the dominant kernel class (fp32-MFMA GEMM): algorithmic FLOPs of its launches divided
                 by their HIP-event durations (events recorded by liblamp_hip.so on the launch stream,
                 in an instrumented replay of the same K steps right after the timed region); `traffic`
@@ -49,6 +53,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
 DEVICE_WARMUP_S = 0.5           # fixed device warm-up before every timed region (clock ramp), stated in `config`
+PIPELINED_WINDOW_S = 0.4        # the batches-in-flight rates are measured over at least this much device time
 
 RAGGED = {'reuters': (20, 302), 'bibtex': (10, 150), 'delicious': (5, 60)}  # SURVEY.md 8d length variant (ii)
 WORKLOADS = {
@@ -69,12 +74,14 @@ def f_live(w, n_enc=2, n_dec=2):
             n_dec * (8 * L * d * d + 4 * L * L * d) + n_dec * 8 * L * d * dff + 2 * L * d)
 
 
-def build(w, batch, device, seed=0, lengths=None):
+def build(w, batch, device, seed=0, lengths=None, n_max=None):
+    """Model + one batch.  The weights and the label graph are the same on every rank (seed 0: what replicating a
+    checkpoint gives); `seed` only draws the batch, so that ranks work on different samples."""
     from lamp_amd import synthetic as R
     from lamp_amd.Models import LAMP
-    n_max = max([w['T']] + list(lengths or []))
-    sd = R.make_state_dict(w['V'], w['L'], n_max, w['d'], w['dff'], w['h'], 2, 2, pos_emb=w['pos'], seed=seed)
-    adj = R.make_adjacency(w['L'], w['p'], seed) if w['mask'] == 'prior' else None
+    n_max = n_max or max([w['T']] + list(lengths or []))
+    sd = R.make_state_dict(w['V'], w['L'], n_max, w['d'], w['dff'], w['h'], 2, 2, pos_emb=w['pos'], seed=0)
+    adj = R.make_adjacency(w['L'], w['p'], 0) if w['mask'] == 'prior' else None
     seq, pos = R.make_batch(batch, w['V'], w['T'], lengths=lengths, seed=seed)
     h, d = w['h'], w['d']
     model = LAMP(w['V'], w['L'], n_max, w['L'], n_layers_enc=2, n_layers_dec=2, n_head=h, n_head2=h,
@@ -147,10 +154,25 @@ def warm_device(step, seconds=DEVICE_WARMUP_S):
     return n
 
 
+def csrc_fingerprint():
+    """sha256 over the kernel sources (names and contents), first 16 hex digits: stamps a committed profile with the
+    kernels it was measured on (there is no .git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'lamp_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            with open(os.path.join(d, f), 'rb') as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(workload):
     """HBM-side bytes per GEMM launch measured by the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
     separate runs, FETCH_SIZE doubled per the MI355X guide's gfx950 calibration) -- or None when no profile of this
-    workload is committed.  Written by tools/summarize_profiles.py."""
+    workload is committed.  Written by tools/summarize_profiles.py together with the fingerprint of the kernel sources
+    the passes ran on: the bench line marks the figure stale when the sources have changed since."""
     path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     try:
         with open(path) as f:
@@ -196,21 +218,31 @@ def roofline_of(prof, n_steps, workload):
         'algorithmic_gflop_per_step': gemm['flops'] / n_steps / 1e9 if n_steps else None,
         'algorithmic_bytes_per_launch': gemm['bytes'] / gemm['launches'] if gemm['launches'] else None,
     }
+    out['timing'] = ('HIP events recorded by the library around every GEMM launch in an INSTRUMENTED replay of the timed '
+                     'steps (the event pairs perturb the stream: conservative); frac_kernel_only = the same FLOPs over '
+                     'the rocprofv3 --kernel-trace durations of the committed profile')
+    if tr and tr.get('gemm_kernel_only_us_per_step') and n_steps:
+        ko = gemm['flops'] / n_steps / (tr['gemm_kernel_only_us_per_step'] * 1e-6) / 1e12
+        out['achieved_kernel_only'] = ko
+        out['frac_kernel_only'] = ko / PEAK_FP32_MFMA_TFLOPS
     if tr and tr.get('gemm_launches'):
         out['traffic'] = (tr['gemm_fetch_bytes'] + tr['gemm_write_bytes']) / tr['gemm_launches']
+        out['traffic_stale'] = tr.get('csrc_fingerprint') != csrc_fingerprint()
         out['traffic_detail'] = {
             'unit': 'bytes per GEMM launch (HBM-side: L2 fabric requests incl. Infinity-Cache hits)',
             'fetch': tr['gemm_fetch_bytes'] / tr['gemm_launches'], 'write': tr['gemm_write_bytes'] / tr['gemm_launches'],
             'source': tr.get('source'), 'batch': tr.get('batch'),
+            'measured': 'NOT in this run: read from the committed PMC profile; traffic_stale says whether the kernel '
+                        'sources have changed since (fingerprint %s then)' % tr.get('csrc_fingerprint'),
         }
     else:
         out['traffic_detail'] = 'no committed PMC profile of this workload (profiles/hbm_traffic.json)'
     return out
 
 
-def measure(N, name, w, batch, steps, warmup, device, rank, sync, lengths=None, graph=False):
+def measure(N, name, w, batch, steps, warmup, device, rank, sync, lengths=None, graph=False, n_max=None):
     """Build one workload on `device`, warm up, time exactly `steps` steps between barriers.  -> dict."""
-    model, sd, adj, seq, pos = build(w, batch, device, seed=rank, lengths=lengths)
+    model, sd, adj, seq, pos = build(w, batch, device, seed=rank, lengths=lengths, n_max=n_max)
     src = (seq.to(device), pos.to(device))
 
     def step():
@@ -242,6 +274,120 @@ def measure(N, name, w, batch, steps, warmup, device, rank, sync, lengths=None, 
     assert torch.isfinite(logits).all(), 'non-finite logits'
     return dict(model=model, sd=sd, adj=adj, seq=seq, pos=pos, step=step, run=run, elapsed=elapsed,
                 device_warmup_steps=warm_n, graph=g)
+
+
+class ControlPlane:
+    """torch.distributed as a CONTROL plane only (the forward has no collective): barrier around the timed region, the
+    gather of per-rank reports, and the gather of a few logits for the cross-rank bitwise check.
+
+    The rendezvous and the default group are gloo (CPU, cannot fail on GPU topology); the barrier and the gathers run on a
+    "nccl" (= RCCL over xGMI on ROCm) group when it works -- first use is probed with one all_reduce, and every rank
+    agrees on the outcome through gloo -- so a node where RCCL cannot initialise still produces a line, with
+    `backend: "gloo"` and the reason in `config.backend_note`.  LAMP_BENCH_BACKEND=gloo skips RCCL (two ranks sharing
+    the one GPU of a test box)."""
+
+    def __init__(self, rank, world, device, want):
+        self.rank, self.world, self.device = rank, world, device
+        self.backend, self.note, self.group, self.dist = None, None, None, None
+        if world == 1 and not os.environ.get('LAMP_BENCH_FORCE_DIST'):   # the variable: tools/check_rccl_control_plane.py
+            return
+        import datetime
+        import torch.distributed as dist
+        self.dist = dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        self.backend = 'gloo'
+        if want != 'nccl':
+            return
+        ok, note = 1, None
+        try:
+            self.group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=300))
+            t = torch.ones(1, device=device)
+            dist.all_reduce(t, group=self.group)
+            torch.cuda.synchronize()
+            ok = int(t.item() == world)
+            if not ok:
+                note = 'RCCL all_reduce over %d ranks returned %r' % (world, t.item())
+        except Exception as e:  # noqa: BLE001 -- whatever RCCL raises here, the bench falls back to gloo and says so
+            ok, note = 0, '%s: %s' % (type(e).__name__, e)
+        flag = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        notes = [None] * world
+        dist.all_gather_object(notes, note)
+        if int(flag.item()) == 1:
+            self.backend = 'nccl'
+        else:
+            self.group = None
+            self.note = 'nccl (RCCL) control plane unavailable, gloo used: ' + '; '.join(
+                'rank %d: %s' % (r, n) for r, n in enumerate(notes) if n)
+
+    @property
+    def nccl(self):
+        return self.backend == 'nccl'
+
+    def barrier(self):
+        if self.dist is None:
+            return
+        if self.nccl:
+            self.dist.barrier(group=self.group, device_ids=[self.device.index])
+        else:
+            self.dist.barrier()
+
+    def ranks_in_group(self):
+        if self.dist is None:
+            return 1
+        return self.dist.get_world_size(group=self.group) if self.nccl else self.dist.get_world_size()
+
+    def gather(self, t):
+        """All ranks' copies of tensor `t` (same shape and dtype everywhere), as CPU tensors, rank order."""
+        if self.dist is None:
+            return [t.detach().cpu()]
+        src = t.detach().to(self.device if self.nccl else 'cpu').contiguous()
+        out = [torch.empty_like(src) for _ in range(self.world)]
+        self.dist.all_gather(out, src, group=self.group if self.nccl else None)
+        return [o.cpu() for o in out]
+
+    def gather_objects(self, obj):
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        if self.dist is not None:
+            self.barrier()
+            self.dist.destroy_process_group()
+
+
+def device_identity(index):
+    """A string that is the same for two ranks iff they sit on the same physical GPU, whatever HIP_VISIBLE_DEVICES says."""
+    p = torch.cuda.get_device_properties(index)
+    parts = [str(getattr(p, a, '')) for a in ('pci_domain_id', 'pci_bus_id', 'pci_device_id', 'uuid')]
+    return ':'.join(parts) if any(parts) else 'index-%d' % index
+
+
+def batch_of_rank(args, w_base, rank):
+    """The (workload dict, lengths) of rank `rank`'s batch -- every rank can rebuild every other rank's batch."""
+    w = dict(w_base)
+    lengths = None
+    if args.ragged:
+        lo, hi = RAGGED[args.workload]
+        g = torch.Generator().manual_seed(1000 + rank)
+        lengths = torch.randint(lo, hi + 1, (args.batch,), generator=g).tolist()
+        w['T'] = max(lengths)  # padded length of this batch: what F_live counts (the kernels skip the PAD positions)
+    return w, lengths
+
+
+def gemm_flops_per_step(w, batch, n_tok, n_enc=2, n_dec=2):
+    """Algorithmic FLOPs of the GEMM launches of one forward: what liblamp_hip.so's launchers count for a fixed-length
+    batch (n_tok = batch * T), evaluated for the real token count of a ragged one (the packed encoder and the K / V
+    projections run on n_tok rows; the launchers only know the padded upper bound).  Layer 0's hoisted query
+    projection is not counted, as in the library."""
+    L, d, dff = w['L'], w['d'], w['dff']
+    enc = n_enc * 4 * n_tok * d * dff + n_dec * 4 * n_tok * d * d
+    dec = batch * L * ((n_dec - 1) * 2 * d * d + n_dec * 2 * d * d + n_dec * 8 * d * d + n_dec * 8 * d * dff)
+    return float(enc + dec)
 
 
 def spawn_ranks(n):
@@ -309,55 +455,51 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()  # > 1 rank per GPU only happens in the 1-GPU smoke test
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-    dist = None
     # "nccl" is RCCL on ROCm.  LAMP_BENCH_BACKEND=gloo lets two ranks share one GPU to smoke-test this path.
-    backend = os.environ.get('LAMP_BENCH_BACKEND', 'nccl')
-    if world > 1:
-        import datetime
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device,
-                                    timeout=datetime.timedelta(seconds=600))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+    cp = ControlPlane(rank, world, device, os.environ.get('LAMP_BENCH_BACKEND', 'nccl'))
     if world != args.gpus and rank == 0:
         print('error: --gpus %d but %d rank(s) were launched' % (args.gpus, world), file=sys.stderr)
-    comm_dev = device if backend == 'nccl' else torch.device('cpu')
-
-    def sync():
-        if dist is not None:
-            if backend == 'nccl':
-                dist.barrier(device_ids=[dev_index])
-            else:
-                dist.barrier()
 
     from lamp_amd import _native as N
     N.lib()
-    w = dict(WORKLOADS[args.workload])
+    w_base = dict(WORKLOADS[args.workload])
     if args.mask:
-        w['mask'] = args.mask
-    lengths = None
-    if args.ragged:
-        lo, hi = RAGGED[args.workload]
-        g = torch.Generator().manual_seed(1000 + rank)
-        lengths = torch.randint(lo, hi + 1, (args.batch,), generator=g).tolist()
-        w['T'] = max(lengths)  # padded length of this batch: what the kernels process and what F_live counts
+        w_base['mask'] = args.mask
+    w, lengths = batch_of_rank(args, w_base, rank)
+    n_max = RAGGED[args.workload][1] if args.ragged else None   # one position table for every rank's batch
 
-    m = measure(N, args.workload, w, args.batch, args.steps, args.warmup, device, rank, sync, lengths=lengths,
-                graph=args.graph)
+    m = measure(N, args.workload, w, args.batch, args.steps, args.warmup, device, rank, cp.barrier, lengths=lengths,
+                graph=args.graph, n_max=n_max)
     model, step, run, my_elapsed = m['model'], m['step'], m['run'], m['elapsed']
 
-    # every rank reports (rank, device, elapsed, samples); rank 0 aggregates: total samples / max elapsed
-    mine = torch.tensor([float(rank), float(dev_index), my_elapsed, float(args.batch * args.steps)],
-                        dtype=torch.float64, device=comm_dev)
-    if dist is not None:
-        rows = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(rows, mine)
-        rows = [r.cpu().tolist() for r in rows]
-    else:
-        rows = [mine.cpu().tolist()]
+    # every rank reports (rank, device, elapsed, samples, tokens); rank 0 aggregates: total samples / max elapsed
+    n_tok = float(sum(lengths)) if lengths else float(args.batch * w['T'])
+    rows = [r.tolist() for r in cp.gather(torch.tensor(
+        [float(rank), float(dev_index), my_elapsed, float(args.batch * args.steps), n_tok, float(w['T'])],
+        dtype=torch.float64))]
+    identities = cp.gather_objects(device_identity(dev_index))
     elapsed = max(r[2] for r in rows)
+
+    # ---- SURVEY.md 8e across ranks: same weights, different batches; rank 0 recomputes the first samples of every other
+    # rank's batch on ITS device and compares with what that rank computed, bit for bit ----
+    n_chk = min(args.batch, 64)
+    own = step()[0][:n_chk].detach().clone()
+    torch.cuda.synchronize()
+    theirs = cp.gather(own)
+    cross = None
+    if rank == 0 and world > 1:
+        from lamp_amd import synthetic as S
+        bad, worst = [], 0.0
+        for r in range(1, world):
+            w_r, len_r = batch_of_rank(args, w_base, r)
+            seq_r, pos_r = S.make_batch(args.batch, w_r['V'], w_r['T'], lengths=len_r, seed=r)
+            mine = model((seq_r[:n_chk].to(device), pos_r[:n_chk].to(device)), None, None, None)[0].cpu()
+            if not torch.equal(mine, theirs[r]):
+                bad.append(r)
+                worst = max(worst, float((mine.double() - theirs[r].double()).abs().max()))
+        cross = {'weights': 'identical on every rank (seed 0)', 'batches': 'rank r draws its batch with seed r',
+                 'recomputed_on': 'rank 0', 'ranks_checked': list(range(1, world)), 'samples_per_rank': n_chk,
+                 'bitwise_equal': not bad, 'mismatching_ranks': bad, 'max_abs_diff': worst}
 
     # per-step latency with a device sync after every step (median and min), outside the timed region
     lat = []
@@ -370,26 +512,30 @@ def main():
     lat.sort()
 
     # ---- throughput mode (reported beside `value`, never as `value`): successive batches issued round-robin
-    # on two HIP streams, so that one forward's launch gaps / ramp / tail are filled by the other's kernels ----
+    # on two HIP streams, so that one forward's launch gaps / ramp / tail are filled by the other's kernels.  Measured
+    # over a FIXED window (>= PIPELINED_WINDOW_S of device time, at least --steps steps), not over --steps iterations:
+    # a 20-step run would otherwise time 16 ms, most of it the two streams' ramp ----
     pipelined = None
     if not args.graph and not args.no_pipelined:
-        pipelined = {'unit': 'samples/s per GPU',
+        n_pipe = max(args.steps, int(PIPELINED_WINDOW_S / max(my_elapsed / args.steps, 1e-6)) + 1)
+        pipelined = {'unit': 'samples/s per GPU', 'steps': n_pipe, 'window_s': PIPELINED_WINDOW_S,
                      'note': 'independent batches in flight on round-robin HIP streams (what evaluate.test_epoch(streams=n) '
                              'does); latency per batch is NOT reduced'}
         for depth in (2, 4):
             streams = [torch.cuda.Stream(device=device) for _ in range(depth)]
-            for st in streams:
-                with torch.cuda.stream(st):
-                    step()
+            for _ in range(2):
+                for st in streams:
+                    with torch.cuda.stream(st):
+                        step()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for i in range(args.steps):
+            for i in range(n_pipe):
                 with torch.cuda.stream(streams[i % depth]):
                     step()
             torch.cuda.synchronize()
             e2 = time.perf_counter() - t1
-            pipelined['depth_%d' % depth] = {'value': args.batch * args.steps / e2,
-                                              'ms_per_step_amortised': e2 / args.steps * 1e3}
+            pipelined['depth_%d' % depth] = {'value': args.batch * n_pipe / e2,
+                                              'ms_per_step_amortised': e2 / n_pipe * 1e3}
         pipelined['value'] = pipelined['depth_2']['value']
         pipelined['streams'] = 2
 
@@ -397,17 +543,25 @@ def main():
     prof, kernels = profile_steps(N, step, prof_steps)
 
     if rank != 0:
-        if dist is not None:
-            sync()
-            dist.destroy_process_group()
+        cp.close()
         return
 
     ranks_seen = sorted(int(r[0]) for r in rows)
     n_gpus = len(ranks_seen)
+    physical = len(set(identities))
     samples = sum(r[3] for r in rows)
     value = samples / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     fl = f_live(w)
+    plain = not (args.ragged or args.mask)
+    roof = roofline_of(prof, prof_steps, args.workload if plain else None)
+    if args.ragged and prof['gemm']['ms'] > 0:
+        # the launchers count the padded upper bound of the packed encoder's rows: use the real token count
+        gf = gemm_flops_per_step(w, args.batch, n_tok)
+        tf = gf * prof_steps / (prof['gemm']['ms'] * 1e-3) / 1e12
+        roof.update(achieved=tf, frac=tf / PEAK_FP32_MFMA_TFLOPS, algorithmic_gflop_per_step=gf / 1e9,
+                    flops_source='analytic, real token count %d of %d padded positions' % (n_tok, args.batch * w['T']))
+        kernels['gemm']['tflops'] = tf
     result = {
         'metric': 'forward samples/sec, reuters d512 2+2L 4h' if args.workload == 'reuters' else
                   'forward samples/sec, %s d%d 2+2L %dh' % (args.workload, w['d'], w['h']),
@@ -416,33 +570,40 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'ranks_seen': ranks_seen,
-        'per_rank': [{'rank': int(r[0]), 'device': int(r[1]), 'value': r[3] / r[2], 'ms_per_step': r[2] / args.steps * 1e3}
-                     for r in sorted(rows)],
-        'physical_devices': len({int(r[1]) for r in rows}),
+        'per_rank': [{'rank': int(r[0]), 'device': int(r[1]), 'device_identity': identities[int(r[0])],
+                      'value': r[3] / r[2], 'ms_per_step': r[2] / args.steps * 1e3, 'tokens_per_batch': int(r[4]),
+                      'padded_length': int(r[5])} for r in sorted(rows)],
+        'physical_devices': physical,
+        'backend': cp.backend, 'control_plane_ranks': cp.ranks_in_group(),
+        'cross_rank_check': cross,
         'config': {'workload': '%s: batch %d/GPU, T=%d %s, L=%d, d_model=%d, d_ff=%d, 2 enc + 2 dec graph layers, '
                                '%d heads, label_mask=%s, fp32' %
                                (args.workload, args.batch, w['T'],
-                                '(lengths U{%d..%d} padded to the batch maximum)' % RAGGED[args.workload] if args.ragged
+                                '(lengths U{%d..%d} padded to the batch maximum; %d real tokens)' %
+                                (RAGGED[args.workload] + (int(n_tok),)) if args.ragged
                                 else 'fixed', w['L'], w['d'], w['dff'], w['h'], w['mask']),
                    'batch_per_gpu': args.batch, 'parallelism': 'batch-sharded x%d, no collectives' % n_gpus,
                    'launch': 'hip-graph replay' if args.graph else 'eager (one lamp_forward call per step)',
                    'launcher': 'self-spawned ranks' if os.environ.get('LAMP_BENCH_SPAWNED') else
                                ('torch.distributed.run' if world > 1 else 'single process'),
-                   'backend': backend if world > 1 else None,
+                   'backend': cp.backend, 'backend_note': cp.note,
                    'device_warmup_s': DEVICE_WARMUP_S, 'device_warmup_steps': m['device_warmup_steps'],
                    },
-        'roofline': roofline_of(prof, prof_steps, args.workload if not (args.ragged or args.mask) else None),
+        'roofline': roof,
         'forward': {
             'f_live_gflop_per_sample': fl / 1e9,
             'achieved_tflops_per_gpu': value / n_gpus * fl / 1e12,
             'frac_of_fp32_mfma_peak': value / n_gpus * fl / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             'kernel_time_us_per_step': sum(k['us_per_step'] for k in kernels.values()),
+            'kernel_time_note': 'HIP-event durations of an INSTRUMENTED replay (an event pair around every launch adds '
+                                '~2-3 us per kernel): the sum may exceed ms_per_step; rocprofv3 kernel-only figures are '
+                                'under profiles/',
         },
         'kernels': kernels,
         'pipelined_batches_in_flight': pipelined,
     }
 
-    if n_gpus == 1 and not args.no_extra_workloads and args.workload == 'reuters' and not (args.ragged or args.mask):
+    if n_gpus == 1 and not args.no_extra_workloads and args.workload == 'reuters' and plain:
         # the other GPU configurations of BASELINE.json, bounded; the headline model is dropped first
         sd_h, adj_h, seq_h, pos_h = m['sd'], m['adj'], m['seq'], m['pos']
         del model, step, run
@@ -461,7 +622,8 @@ def main():
                 'ms_per_step': me['elapsed'] / steps * 1e3,
                 'config': 'T=%d fixed, L=%d, d_model=%d, d_ff=%d, %d heads, label_mask=%s' %
                           (we['T'], we['L'], we['d'], we['dff'], we['h'], we['mask']),
-                'roofline': {'achieved': rf['achieved'], 'frac': rf['frac'], 'unit': 'TFLOP/s', 'traffic': rf['traffic']},
+                'roofline': {'achieved': rf['achieved'], 'frac': rf['frac'], 'unit': 'TFLOP/s', 'traffic': rf['traffic'],
+                             'traffic_stale': rf.get('traffic_stale')},
                 'attention_tflops': ke.get('attention', {}).get('tflops'),
                 'forward_frac_of_fp32_mfma_peak': v * fe / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             }
@@ -476,12 +638,18 @@ def main():
         result['speedup_vs_cpu_as_written'] = value / cb['value']
     sys.stdout.flush()
     os.write(result_fd, (json.dumps(result) + '\n').encode())
-    ok = n_gpus == args.gpus
-    if dist is not None:
-        sync()
-        dist.destroy_process_group()
-    if not ok:
-        sys.exit(3)
+    rc = 0
+    if n_gpus != args.gpus:
+        rc = 3
+    elif cross is not None and not cross['bitwise_equal']:
+        print('error: cross-rank bitwise check failed on ranks %s' % cross['mismatching_ranks'], file=sys.stderr)
+        rc = 4
+    elif cp.nccl and physical != n_gpus:
+        print('error: %d ranks on %d physical device(s) under nccl' % (n_gpus, physical), file=sys.stderr)
+        rc = 5
+    cp.close()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == '__main__':

@@ -79,10 +79,11 @@ struct Carver {
 
 static int linear(const float* A, int64_t M, int K, int64_t lda, const float* const* W, int nseg, int N,
                   int64_t ldw, const float* const* bias, const float* R, int64_t ldr, int relu,
-                  float* const* C, int64_t ldc, hipStream_t s) {
+                  float* const* C, int64_t ldc, hipStream_t s, const int* m_dev = nullptr,
+                  const float* A_dense = nullptr) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.M = M; p.K = K; p.N = N; p.nseg = nseg; p.ldw = ldw; p.ldc = ldc;
-    p.R = R; p.ldr = ldr; p.relu = relu;
+    p.R = R; p.ldr = ldr; p.relu = relu; p.m_dev = m_dev; p.A_dense = A_dense;
     for (int i = 0; i < nseg; ++i) {
         p.W[i] = W[i];
         p.bias[i] = bias ? bias[i] : nullptr;
@@ -105,7 +106,10 @@ struct MhaScratch {
     float *Q, *K, *V, *A;
     float* S = nullptr;    // (h*B, lq, lk) score scratch, only for d_k or d_v > 128 (attention_general.hip)
     float* lse = nullptr;  // [h][B][lq] row log-sum-exp: lets requested attention maps come from the single-pass kernel
+    int* plan_ints = nullptr;  // 3 B + 3 ints: the SeqPlan of a key-token mask when the caller did not bring one
 };
+static inline size_t plan_int_count(int64_t B) { return size_t(3) * size_t(B) + 3; }
+static inline SeqPlan plan_from(int* ints, int64_t B) { return SeqPlan{ints, ints + B, ints + 2 * B, ints + 3 * B + 1}; }
 static inline bool wide_heads(int dk, int dv) { return dk > 128 || dv > 128; }
 
 // MultiHeadAttention.forward (lamp/SubLayers.py:77-121).  `xq_shared`: xq is ONE [lq, d] block used
@@ -115,7 +119,10 @@ static inline bool wide_heads(int dk, int dv) { return dk > 128 || dv > 128; }
 static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, int lq, int lk, int d, int dk,
                     int dv, const lamp_mha_weights& w, const lamp_mask* mask, float* out, float* attn,
                     const MhaScratch& sc, hipStream_t s, bool kv_ready = false,
-                    const float* q_ready = nullptr, int P_batch = 0, int P_b0 = 0) {
+                    const float* q_ready = nullptr, int P_batch = 0, int P_b0 = 0, const SeqPlan* keys = nullptr,
+                    bool keys_packed = false, const float* xkv_dense = nullptr) {
+    // keys: per-sample key extents of a key-token mask (ragged batches); keys_packed: xkv holds the packed token rows
+    // (keys->rows[0] of them, counted on the device) instead of [B, lk, d]
     const int h = w.n_head;
     if (h < 1 || dk < 1 || dv < 1) return LAMP_E_DIMS;
     if (!w.w_qs || !w.w_ks || !w.w_vs || (out && (!w.ln_g || !w.ln_b))) return LAMP_E_NULL;
@@ -137,22 +144,33 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
             float* C[1] = {sc.Q};
             LAMP_CK(linear(xq, Mq, d, d, W, 1, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
         }
+        const int* mk_dev = keys_packed ? keys->rows : nullptr;
+        const float* xd = keys_packed ? xkv_dense : nullptr;  // the padded rows, read instead when nothing was skipped
         if (kv_ready) {
             // sc.K / sc.V were projected earlier (every decoder layer's K/V in one launch, see forward_range)
         } else if (need_v && hdk == hdv) {
             const float* W[2] = {w.w_ks, w.w_vs};
             float* C[2] = {sc.K, sc.V};
-            LAMP_CK(linear(xkv, Mk, d, d, W, 2, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
+            LAMP_CK(linear(xkv, Mk, d, d, W, 2, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s, mk_dev, xd));
         } else {
             const float* Wk[1] = {w.w_ks};
             float* Ck[1] = {sc.K};
-            LAMP_CK(linear(xkv, Mk, d, d, Wk, 1, hdk, d, nullptr, nullptr, 0, 0, Ck, hdk, s));
+            LAMP_CK(linear(xkv, Mk, d, d, Wk, 1, hdk, d, nullptr, nullptr, 0, 0, Ck, hdk, s, mk_dev, xd));
             if (need_v) {
                 const float* Wv[1] = {w.w_vs};
                 float* Cv[1] = {sc.V};
-                LAMP_CK(linear(xkv, Mk, d, d, Wv, 1, hdv, d, nullptr, nullptr, 0, 0, Cv, hdv, s));
+                LAMP_CK(linear(xkv, Mk, d, d, Wv, 1, hdv, d, nullptr, nullptr, 0, 0, Cv, hdv, s, mk_dev, xd));
             }
         }
+    }
+
+    // A key-token mask without a plan (lamp_mha_fwd on its own): count each sample's keys here, padded layout, so that
+    // the module-by-module route takes the same per-sample key split as lamp_forward -- same bits.
+    SeqPlan local_plan{};
+    if (!keys && mask && mask->kind == LAMP_MASK_KEY_TOKENS_I64 && sc.plan_ints && !wide_heads(dk, dv)) {
+        local_plan = plan_from(sc.plan_ints, B);
+        LAMP_CK(launch_seq_plan(static_cast<const int64_t*>(mask->ptr), nullptr, B, lk, mask->stride_b, false, local_plan, s));
+        keys = &local_plan;
     }
 
     AttnParams a{};
@@ -173,6 +191,10 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     a.m_sq = mask ? mask->stride_q : 0;
     a.tiles = (mask && !attn) ? mask->tile_list : nullptr;
     a.tiles_stride = mask ? mask->tile_list_stride : 0;
+    if (keys && mask && mask->kind == LAMP_MASK_KEY_TOKENS_I64) {
+        a.kv_len = keys->klen;
+        a.kv_off = keys->off;
+    }
     LAMP_CK(launch_attn(a, s));
     if (!out) return 0;
 
@@ -194,25 +216,26 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
 
 // K and V projections of one attention block on their own (same launches mha_core would issue).
 static int project_kv(const float* xkv, int64_t Mk, int d, int dk, int dv, const lamp_mha_weights& w, float* K,
-                      float* V, hipStream_t s) {
+                      float* V, hipStream_t s, const int* m_dev = nullptr, const float* A_dense = nullptr) {
     const int hdk = w.n_head * dk, hdv = w.n_head * dv;
     if (hdk == hdv) {
         const float* W[2] = {w.w_ks, w.w_vs};
         float* C[2] = {K, V};
-        return linear(xkv, Mk, d, d, W, 2, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s);
+        return linear(xkv, Mk, d, d, W, 2, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s, m_dev, A_dense);
     }
     const float* Wk[1] = {w.w_ks};
     float* Ck[1] = {K};
-    LAMP_CK(linear(xkv, Mk, d, d, Wk, 1, hdk, d, nullptr, nullptr, 0, 0, Ck, hdk, s));
+    LAMP_CK(linear(xkv, Mk, d, d, Wk, 1, hdk, d, nullptr, nullptr, 0, 0, Ck, hdk, s, m_dev, A_dense));
     const float* Wv[1] = {w.w_vs};
     float* Cv[1] = {V};
-    return linear(xkv, Mk, d, d, Wv, 1, hdv, d, nullptr, nullptr, 0, 0, Cv, hdv, s);
+    return linear(xkv, Mk, d, d, Wv, 1, hdv, d, nullptr, nullptr, 0, 0, Cv, hdv, s, m_dev, A_dense);
 }
 
 // K and V projections of the first n decoder layers' enc-attention from the same encoder output: ONE launch when the
 // 2n weight matrices fit the GEMM's segment list (n <= 2) -- 4 x more tiles per launch than layer by layer.
 static int project_kv_layers(const float* x, int64_t Me, int d, int dk, int dv, const lamp_dec_layer* layers, int n,
-                             float* const* K, float* const* V, hipStream_t s) {
+                             float* const* K, float* const* V, hipStream_t s, const int* m_dev = nullptr,
+                             const float* A_dense = nullptr) {
     const int h = layers[0].enc_attn.n_head;
     bool uniform = 2 * n <= GEMM_MAX_SEG && h * dk == h * dv;
     for (int i = 1; i < n && uniform; ++i) uniform = layers[i].enc_attn.n_head == h;
@@ -226,29 +249,38 @@ static int project_kv_layers(const float* x, int64_t Me, int d, int dk, int dv, 
             C[2 * i] = K[i];
             C[2 * i + 1] = V[i];
         }
-        return linear(x, Me, d, d, W, 2 * n, h * dk, d, nullptr, nullptr, 0, 0, C, h * dk, s);
+        return linear(x, Me, d, d, W, 2 * n, h * dk, d, nullptr, nullptr, 0, 0, C, h * dk, s, m_dev, A_dense);
     }
-    for (int i = 0; i < n; ++i) LAMP_CK(project_kv(x, Me, d, dk, dv, layers[i].enc_attn, K[i], V[i], s));
+    for (int i = 0; i < n; ++i) LAMP_CK(project_kv(x, Me, d, dk, dv, layers[i].enc_attn, K[i], V[i], s, m_dev, A_dense));
     return 0;
 }
 
 // PositionwiseFeedForward.forward (lamp/SubLayers.py:133-142); out may alias x.
+// Packed encoder rows (ragged batches): `rows_dev` = the live row count in device memory (M is the upper bound the
+// launches are sized for); with `scatter` this is the LAST encoder layer, whose LayerNorm also writes the padded
+// [nb, T, d] encoder output `y_flat` (see layernorm_kernel<.., RG = 2>).
 static int ffn_core(const float* x, int64_t M, int d, int dff, const lamp_ffn_weights& w, float* out,
                     float* hidden, hipStream_t s, const float* w_out = nullptr, int n_labels = 0,
-                    float* logits = nullptr) {
+                    float* logits = nullptr, const int* rows_dev = nullptr, const SeqPlan* scatter = nullptr,
+                    int nb = 0, int T = 0, float* y_flat = nullptr) {
     if (!w.w1 || !w.b1 || !w.w2 || !w.b2 || !w.ln_g || !w.ln_b) return LAMP_E_NULL;
     {
         const float* W[1] = {w.w1};
         const float* b[1] = {w.b1};
         float* C[1] = {hidden};
-        LAMP_CK(linear(x, M, d, d, W, 1, dff, d, b, nullptr, 0, 1, C, dff, s));
+        LAMP_CK(linear(x, M, d, d, W, 1, dff, d, b, nullptr, 0, 1, C, dff, s, rows_dev));
     }
     {
         const float* W[1] = {w.w2};
         const float* b[1] = {w.b2};
         float* C[1] = {out};
-        LAMP_CK(linear(hidden, M, dff, dff, W, 1, d, dff, b, x, d, 0, C, d, s));
+        LAMP_CK(linear(hidden, M, dff, dff, W, 1, d, dff, b, x, d, 0, C, d, s, rows_dev));
     }
+    if (scatter)
+        return launch_layernorm(out, int64_t(nb) * T, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, out, s, nullptr, 0, nullptr,
+                                nullptr, nullptr, scatter, T, y_flat);
+    if (rows_dev)
+        return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, out, s, nullptr, 0, nullptr, nullptr, rows_dev);
     // with w_out: the final decoder LayerNorm also produces the logits and its output row is not stored
     return launch_layernorm(out, M, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, w_out ? nullptr : out, s, w_out, n_labels,
                             logits);
@@ -341,7 +373,8 @@ size_t lamp_mha_workspace_bytes(int32_t B, int32_t lq, int32_t lk, int32_t d_mod
     if (B <= 0 || lq <= 0 || lk <= 0 || n_head <= 0 || d_k <= 0 || d_v <= 0) return 0;
     return (mha_ws_floats(B, lq, lk, n_head * d_k, n_head * d_v,
                           wide_heads(d_k, d_v) ? int64_t(n_head) * B * lq * lk : 0) +
-            align_up(size_t(n_head) * B * lq * sizeof(float), 256) / sizeof(float)) * sizeof(float);
+            align_up(size_t(n_head) * B * lq * sizeof(float), 256) / sizeof(float) +
+            align_up(plan_int_count(B) * sizeof(int), 256) / sizeof(float)) * sizeof(float);
 }
 
 int lamp_mha_fwd(const float* xq, const float* xkv, int32_t B, int32_t lq, int32_t lk, int32_t d_model,
@@ -360,6 +393,7 @@ int lamp_mha_fwd(const float* xq, const float* xkv, int32_t B, int32_t lq, int32
     sc.A = c.take(size_t(B) * lq * hdv);
     if (wide_heads(d_k, d_v)) sc.S = c.take(size_t(w->n_head) * B * lq * lk);
     sc.lse = c.take(size_t(w->n_head) * B * lq);
+    sc.plan_ints = reinterpret_cast<int*>(c.take(plan_int_count(B)));
     if (!c.ok) return LAMP_E_WORKSPACE;
     return mha_core(xq, false, xkv, B, lq, lk, d_model, d_k, d_v, *w, mask, out, attn, sc, hipStream_t(stream));
 }
@@ -506,6 +540,10 @@ static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
     pl->per_sample_floats += pl->score_floats;
     pl->lse_floats = size_t(h) * Rq;  // row log-sum-exp of an attention whose maps are requested
     pl->per_sample_floats += pl->lse_floats;
+    // ragged batches: the packed token rows of the encoder ([n_tok + 1, d]: + the shared PAD row), one more row of the
+    // FFN hidden buffer for it, and the SeqPlan's 3 mb + 3 ints
+    pl->per_sample_floats += size_t(T) * m->d_model + 3;
+    pl->fixed_floats += size_t(m->d_model) + size_t(m->d_inner) + 64 * 3 + 4;
     // K/V of all decoder layers' enc-attention, projected together right after the encoder when the batch fits
     pl->side_kv_floats = size_t(m->n_layers_dec) * T * (pl->hdk + pl->hdv);
     return 0;
@@ -534,14 +572,22 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
     int64_t mb = int64_t((ws_floats - pl.fixed_floats) / per_sample);
     if (mb > B) mb = B;
 
+    // Ragged batches.  Every micro-batch first counts its samples' extents on the device (SeqPlan).  `packed`: the encoder
+    // runs on the packed non-PAD token rows (+ ONE shared PAD row: all PAD positions of lamp/Encoders.py:64-79 hold the
+    // same row-wise result), its last LayerNorm scatters into the padded enc_output, and K / V are projected from the
+    // packed rows only.  Row-wise kernels and an M-independent k-order make this bit-identical to computing every
+    // padded position.  Not packed (the dead encoder self-attention's maps are wanted, or wide heads): padded layout as
+    // before; the enc-dec attention still stops at each sample's last real key either way.
+    const bool packed = !want_enc_attn && !wide_heads(dk, dv) && m->n_layers_enc > 0;
     const int Rq = want_enc_attn ? pl.R : L;
-    float *H = nullptr, *Y = nullptr;
+    float *H = nullptr, *Y = nullptr, *Xp = nullptr;
+    int* plan_ints = nullptr;
     float* Kahead[MAX_AHEAD_LAYERS] = {};
     float* Vahead[MAX_AHEAD_LAYERS] = {};
     MhaScratch sc{};
     for (int attempt = 0; attempt < 2; ++attempt) {
         Carver c(workspace, workspace_bytes);
-        H = c.take(size_t(mb) * pl.R * dff);
+        H = c.take(size_t(mb) * pl.R * dff + dff);
         sc.Q = c.take(size_t(mb) * Rq * pl.hdk);
         sc.K = c.take(size_t(mb) * pl.R * pl.hdk);
         sc.V = c.take(size_t(mb) * pl.R * pl.hdv);
@@ -549,6 +595,8 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         sc.S = pl.score_floats ? c.take(size_t(mb) * pl.score_floats) : nullptr;
         sc.lse = c.take(size_t(mb) * pl.lse_floats);
         Y = c.take(size_t(mb) * L * d);
+        Xp = c.take(size_t(mb) * T * d + d);
+        plan_ints = reinterpret_cast<int*>(c.take(plan_int_count(mb)));
         for (int i = 0; i < n_ahead; ++i) {
             Kahead[i] = c.take(size_t(mb) * T * pl.hdk);
             Vahead[i] = c.take(size_t(mb) * T * pl.hdv);
@@ -562,23 +610,39 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         const int nb = int(B - b0 < mb ? B - b0 : mb);
         const int64_t* seq = src_seq + b0 * T;
         const int64_t* pos = src_pos ? src_pos + b0 * T : nullptr;
-        float* x = enc_output + b0 * int64_t(T) * d;  // encoder state lives in the output buffer
+        float* x = enc_output + b0 * int64_t(T) * d;  // the padded encoder output of this micro-batch
         const int64_t Me = int64_t(nb) * T;
+        const SeqPlan sp = plan_from(plan_ints, nb);
+        LAMP_CK(launch_seq_plan(seq, m->position_enc ? pos : nullptr, nb, T, T, packed, sp, s));
 
         // ---- GraphEncoder.forward (lamp/Encoders.py:64-110) ----
-        LAMP_CK(launch_embed(seq, pos, Me, m->src_word_emb, m->n_src_vocab, m->position_enc, m->n_position, d, x, s));
         lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq, T, 0, nullptr, 0};
-        for (int i = 0; i < m->n_layers_enc; ++i) {
-            const lamp_enc_layer& l = m->enc_layers[i];
-            if (want_enc_attn && aux->enc_self_attn[i]) {
-                // lamp/Layers.py:16 -- only the attention map of this block is ever observable.  Maps are
-                // (h*B, T, T) over the WHOLE batch: this micro-batch fills rows h*B + b0 + b.
-                LAMP_CK(mha_core(x, false, x, nb, T, T, d, dk, dv, l.slf_attn, &pad_mask, nullptr,
-                                 aux->enc_self_attn[i], sc, s, false, nullptr, B, int(b0)));
+        const float* xk = x;  // what the decoder's K / V projections read
+        if (packed) {
+            LAMP_CK(launch_embed_packed(seq, pos, nb, T, m->src_word_emb, m->n_src_vocab, m->position_enc, m->n_position, d,
+                                        sp, Xp, s));
+            for (int i = 0; i < m->n_layers_enc; ++i) {
+                const bool last = i + 1 == m->n_layers_enc;
+                LAMP_CK(ffn_core(Xp, Me + 1, d, dff, m->enc_layers[i].pos_ffn, Xp, H, s, nullptr, 0, nullptr, sp.rows + 1,
+                                 last ? &sp : nullptr, nb, T, x));  // lamp/Layers.py:18
             }
-            LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s));  // lamp/Layers.py:18
+            xk = Xp;
+        } else {
+            LAMP_CK(launch_embed(seq, pos, Me, m->src_word_emb, m->n_src_vocab, m->position_enc, m->n_position, d, x, s));
+            for (int i = 0; i < m->n_layers_enc; ++i) {
+                const lamp_enc_layer& l = m->enc_layers[i];
+                if (want_enc_attn && aux->enc_self_attn[i]) {
+                    // lamp/Layers.py:16 -- only the attention map of this block is ever observable.  Maps are
+                    // (h*B, T, T) over the WHOLE batch: this micro-batch fills rows h*B + b0 + b.
+                    LAMP_CK(mha_core(x, false, x, nb, T, T, d, dk, dv, l.slf_attn, &pad_mask, nullptr,
+                                     aux->enc_self_attn[i], sc, s, false, nullptr, B, int(b0), &sp));
+                }
+                LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s));  // lamp/Layers.py:18
+            }
         }
-        if (n_ahead > 0) LAMP_CK(project_kv_layers(x, Me, d, dk, dv, m->dec_layers, n_ahead, Kahead, Vahead, s));
+        const int* kv_rows = packed ? sp.rows : nullptr;
+        if (n_ahead > 0)
+            LAMP_CK(project_kv_layers(xk, Me, d, dk, dv, m->dec_layers, n_ahead, Kahead, Vahead, s, kv_rows, packed ? x : nullptr));
 
         // ---- GraphDecoder.forward (lamp/Decoders.py:127-163) ----
         // the label graph: bit-packed rows when the caller provides them (one dword per 32-key tile), else bytes
@@ -610,11 +674,11 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             // input->label messages (lamp/Layers.py:35); layer 0's query is the label table itself (its LayerNorm
             // kernel adds the shared residual)
             if (i == 0)
-                LAMP_CK(mha_core(m->tgt_word_emb, true, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s,
-                                 ahead, m->dec0_query, B, int(b0)));
+                LAMP_CK(mha_core(m->tgt_word_emb, true, xk, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s,
+                                 ahead, m->dec0_query, B, int(b0), &sp, packed, x));
             else
-                LAMP_CK(mha_core(Y, false, x, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s, ahead, nullptr,
-                                 B, int(b0)));
+                LAMP_CK(mha_core(Y, false, xk, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s, ahead, nullptr,
+                                 B, int(b0), &sp, packed, x));
             LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn1, Y, H, s));  // lamp/Layers.py:36
             if (has_slf) {
                 LAMP_CK(int_pred());  // dec_output_int, lamp/Decoders.py:149-151

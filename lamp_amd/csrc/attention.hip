@@ -75,14 +75,19 @@ __global__ __launch_bounds__(256, PM == 0 ? 2 : 1) void attn_kernel(AttnParams p
     const int qc = qi < p.lq ? qi : p.lq - 1;
 
     const int q_r = int(p.lay.q_r), k_r = int(p.lay.k_r), v_r = int(p.lay.v_r);
+    // this sample's keys: all lk, or (ragged batches, AttnParams::kv_len) its own count and its first row in the packed
+    // K / V matrices; the descriptors end at the sample's last key (rows past it read as zeros)
+    const int lk_b = p.kv_len ? p.kv_len[b] : p.lk;
+    const int64_t k_row0 = p.kv_len ? int64_t(p.kv_off[b]) * k_r : int64_t(b) * p.lay.k_b;
+    const int64_t v_row0 = p.kv_len ? int64_t(p.kv_off[b]) * v_r : int64_t(b) * p.lay.v_b;
     const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q + int64_t(b) * p.lay.q_b + int64_t(h) * p.lay.q_h,
                                                  (uint64_t(p.lq - 1) * q_r + p.dk) * 4u);
-    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K + int64_t(b) * p.lay.k_b + int64_t(h) * p.lay.k_h,
-                                                 (uint64_t(p.lk - 1) * k_r + p.dk) * 4u);
+    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K + k_row0 + int64_t(h) * p.lay.k_h,
+                                                 lk_b > 0 ? (uint64_t(lk_b - 1) * k_r + p.dk) * 4u : 0);
     const bool has_v = p.V != nullptr;
     const __amdgpu_buffer_rsrc_t rsV =
-        make_rsrc(has_v ? p.V + int64_t(b) * p.lay.v_b + int64_t(h) * p.lay.v_h : p.K,
-                  has_v ? (uint64_t(p.lk - 1) * v_r + p.dv) * 4u : 0);
+        make_rsrc(has_v ? p.V + v_row0 + int64_t(h) * p.lay.v_h : p.K,
+                  (has_v && lk_b > 0) ? (uint64_t(lk_b - 1) * v_r + p.dv) * 4u : 0);
     const __amdgpu_buffer_rsrc_t rsM =
         MK == LAMP_MASK_BITS_U32
             ? make_rsrc(static_cast<const unsigned*>(p.mask) + int64_t(b) * p.m_sb,
@@ -111,7 +116,9 @@ __global__ __launch_bounds__(256, PM == 0 ? 2 : 1) void attn_kernel(AttnParams p
     }
     __syncthreads();
 
-    const int nt = (p.lk + 31) / 32;
+    // key tiles to visit: the sample's own (tiles past them hold PAD keys only: exp2(-inf) = 0 exactly); the map-writing
+    // variants walk the padded length, every column of a map row has to be produced
+    const int nt = PM == 0 ? (lk_b + 31) / 32 : (p.lk + 31) / 32;
     float4 kf[DKC];
     float vf[16][DVB];   // V[key_r(hi)][DVB*l31 + e]: block e of O^T holds dv columns {DVB*i + e}
     unsigned mraw[16];   // raw mask bytes / token-is-PAD flags of the tile, loaded one tile ahead
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256, PM == 0 ? 2 : 1) void attn_kernel(AttnParams p
             bool blk = false;
             if constexpr (MK == LAMP_MASK_BITS_U32) blk = (mw & (1u << ((r & 3) + 8 * (r >> 2)))) != 0;
             if constexpr (MK == LAMP_MASK_U8 || MK == LAMP_MASK_KEY_TOKENS_I64) blk = mraw[r] != 0;
-            if (key >= p.lk || blk) s[r] = -INFINITY;
+            if (key >= lk_b || blk) s[r] = -INFINITY;
         }
     };
     auto pv = [&](const f32x16& pr, f32x16 (&o)[DVB]) {

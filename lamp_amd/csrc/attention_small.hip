@@ -50,7 +50,12 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int qb = wave / KSPLIT, ks = wave % KSPLIT;
+    // Key share of this wave.  With ragged keys a short sample uses fewer shares than the launch has waves for; which
+    // waves idle rotates with the workgroup, else the idle ones would always be the same SIMDs' (wave w runs on SIMD w % 4)
+    // and the busy SIMDs would be as loaded as without the skipping.
+    const int rot = (KSPLIT > 1 && p.kv_len) ? int(blockIdx.x % KSPLIT) : 0;
+    const int qb = wave / KSPLIT, ks = (wave % KSPLIT + KSPLIT - rot) % KSPLIT;
+    const int slot = qb * KSPLIT + ks;   // position among the workgroup's partial results
 #ifdef LAMP_TUNING
     const unsigned long long t_entry = p.trace ? wall_clock64() : 0ull;
     unsigned long long t_loop = 0, t_merge = 0;
@@ -66,12 +71,17 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     const int qc = qi < p.lq ? qi : p.lq - 1;
 
     const int q_r = int(p.lay.q_r), k_r = int(p.lay.k_r), v_r = int(p.lay.v_r);
+    // this sample's keys: all lk, or (ragged batches) its own count and its first row in the packed K / V matrices.
+    // The descriptors end at the sample's last key: rows past it read as zeros (never another sample's, never NaNs).
+    const int lk_b = p.kv_len ? p.kv_len[b] : p.lk;
+    const int64_t k_row0 = p.kv_len ? int64_t(p.kv_off[b]) * k_r : int64_t(b) * p.lay.k_b;
+    const int64_t v_row0 = p.kv_len ? int64_t(p.kv_off[b]) * v_r : int64_t(b) * p.lay.v_b;
     const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q + int64_t(b) * p.lay.q_b + int64_t(h) * p.lay.q_h,
                                                  (uint64_t(p.lq - 1) * q_r + p.dk) * 4u);
-    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K + int64_t(b) * p.lay.k_b + int64_t(h) * p.lay.k_h,
-                                                 (uint64_t(p.lk - 1) * k_r + p.dk) * 4u);
-    const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.V + int64_t(b) * p.lay.v_b + int64_t(h) * p.lay.v_h,
-                                                 (uint64_t(p.lk - 1) * v_r + p.dv) * 4u);
+    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K + k_row0 + int64_t(h) * p.lay.k_h,
+                                                 lk_b > 0 ? (uint64_t(lk_b - 1) * k_r + p.dk) * 4u : 0);
+    const __amdgpu_buffer_rsrc_t rsV = make_rsrc(p.V + v_row0 + int64_t(h) * p.lay.v_h,
+                                                 lk_b > 0 ? (uint64_t(lk_b - 1) * v_r + p.dv) * 4u : 0);
     const __amdgpu_buffer_rsrc_t rsM =
         MK == LAMP_MASK_BITS_U32
             ? make_rsrc(static_cast<const unsigned*>(p.mask) + int64_t(b) * p.m_sb,
@@ -106,7 +116,13 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     }
     __syncthreads();
 
-    const int nt = (p.lk + 15) / 16;
+    // key tiles to visit: the sample's own (the rest holds PAD keys only: exp2(-inf) = 0 exactly); with the map
+    // write-out every column of the map row has to be produced, so all tiles of the padded length are walked
+    const int nt_b = (lk_b + 15) / 16;
+    const int nt = PM == 2 ? (p.lk + 15) / 16 : nt_b;
+    // key shares in use: the launch's KSPLIT, or -- ragged batches -- the share count launch_attn_small would choose for
+    // THIS sample's key count (<= KSPLIT: the launch was sized for the padded length); the other waves idle
+    const int ks_eff = (KSPLIT > 1 && p.kv_len) ? (nt_b >= 12 ? (KSPLIT < 4 ? KSPLIT : 4) : (nt_b >= 4 ? 2 : 1)) : KSPLIT;
     float4 kg[DKC];        // the NEXT tile's K rows in flight (coalesced layout: row = i * RPI + lane / C4K, float4 lane % C4K)
     constexpr int C4K = DP / 4, RPI = 64 / C4K;   // float4 per K row; rows per load instruction
     float vf[4][DV8];      // V[kt*16 + 4g + r][.]: block e of O^T holds the d_v columns given at load_v below
@@ -195,7 +211,7 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v = s0[r] + s1[r];
-            const bool blk = (MK != LAMP_MASK_NONE && ((mbits >> r) & 1u)) || kbase + r >= p.lk;
+            const bool blk = (MK != LAMP_MASK_NONE && ((mbits >> r) & 1u)) || kbase + r >= lk_b;
             s[r] = blk ? -INFINITY : v;
         }
     };
@@ -209,13 +225,13 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
 #ifdef LAMP_TUNING
     if (p.trace) t_loop = wall_clock64();
 #endif
-    if (wave_active && ks < nt) {
+    if (wave_active && ks < ks_eff && ks < nt) {
         int kt = ks;
         load_k(kt);
         load_mask(kt);
         load_v(kt);
-        for (; kt < nt; kt += KSPLIT) {
-            const int kn = kt + KSPLIT;   // past the end: range-checked zeros
+        for (; kt < nt; kt += ks_eff) {
+            const int kn = kt + ks_eff;   // past the end: range-checked zeros
             f32x4 s;
             stage_k();       // the tile requested one iteration ago: registers -> LDS, read back as fragments by scores()
             scores(kt, s);
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
         // ---- merge the KSPLIT partial results of each query block (lane-local positions, fixed order) ----
         constexpr int CW = (DV8 * 4 + 4) * 64;  // floats per wave: o blocks as float4 per lane, then (m, l, -, -) per lane
         __syncthreads();                        // every wave is done reading its Q block: the region is reused
-        float* mine = smem + wave * CW;
+        float* mine = smem + slot * CW;
 #pragma unroll
         for (int e = 0; e < DV8; ++e)
             *reinterpret_cast<float4*>(mine + (e * 64 + lane) * 4) = make_float4(o[e][0], o[e][1], o[e][2], o[e][3]);
@@ -273,7 +289,8 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
         if (ks == 0 && wave_active) {
             float m_all = m_run;
 #pragma unroll
-            for (int s2 = 1; s2 < KSPLIT; ++s2) m_all = fmaxf(m_all, smem[(wave + s2) * CW + (DV8 * 64 + lane) * 4]);
+            for (int s2 = 1; s2 < KSPLIT; ++s2)
+                if (s2 < ks_eff) m_all = fmaxf(m_all, smem[(slot + s2) * CW + (DV8 * 64 + lane) * 4]);
             const float m_use = (m_all == -INFINITY) ? 0.f : m_all;
             const float w0 = exp2f(m_run - m_use);
             l_part *= w0;
@@ -283,7 +300,8 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
                 for (int r = 0; r < 4; ++r) o[e][r] *= w0;
 #pragma unroll
             for (int s2 = 1; s2 < KSPLIT; ++s2) {
-                const float* other = smem + (wave + s2) * CW;
+                if (s2 >= ks_eff) break;
+                const float* other = smem + (slot + s2) * CW;
                 const float4 ml = *reinterpret_cast<const float4*>(other + (DV8 * 64 + lane) * 4);
                 const float ws = exp2f(ml.x - m_use);
                 l_part = fmaf(ml.y, ws, l_part);  // explicit fma: same bits in every variant

@@ -29,6 +29,8 @@ namespace lamp {
 // MF = edge of the MFMA block a wave tile is built from: 16 (v_mfma_f32_16x16x4_f32, 4 accumulator registers
 // per block; the production tiles -- see launch_gemm) or 32 (v_mfma_f32_32x32x2_f32, 16 registers per block;
 // kept as forced configurations for comparison).  Both issue 64 FLOP/cycle/SIMD.
+constexpr int gemm_min_waves(int bm, int bn, int bk, int mf) { return (mf == 16 && bm == 64 && bn == 64 && bk == 16) ? 5 : 1; }
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF = 32>
 struct GemmTile {
     static constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -40,6 +42,10 @@ struct GemmTile {
     static constexpr int A_LD = BM * BK / 4 / NT;  // float4 loads per thread per tile
     static constexpr int B_LD = BN * BK / 4 / NT;
     static constexpr size_t LDS_BYTES = size_t(2) * (BM + BN) * LDS_STRIDE * sizeof(float);
+    // Waves per SIMD the register allocator must leave room for.  The 64x64x16 tile serves launches of ~1200 tiles
+    // (encoder FFN at batch 32: 1208): five workgroups per CU hold them all at once, four leave a second, mostly empty
+    // round (44 -> 51 us when the 16-byte epilogue operands pushed the kernel from 92 to 100 registers).
+    static constexpr int MIN_WAVES = gemm_min_waves(BM, BN, BK, MF);
     static_assert(MF == 32 || MF == 16, "MFMA block edge");
     static_assert(WTM % MF == 0 && WTN % MF == 0, "wave tile must be a multiple of the MFMA block");
     static_assert(BK % (MF == 32 ? 8 : 16) == 0, "BK must cover whole fragment reads");
@@ -51,8 +57,10 @@ struct GemmTile {
 // Infinity Cache then hides under the MFMAs instead of standing between the last k-step and the stores).  Used by the
 // small tiles, whose accumulators -- hence the prefetched values -- are few registers; the large tiles amortise the
 // round trip over 8-16x more matrix work per wave and keep the registers for occupancy.
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
+// VEC: bias / residual / C move as 16-byte accesses (N, ldc, ldr multiples of 4 and 16-byte aligned bases -- every shape
+// of the forward); the scalar instantiation serves odd widths.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, MF))) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
                                                                           int tiles_n, int tiles_m,
                                                                           int panel_split) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
@@ -87,6 +95,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     // share exit), so a row of C is written by one XCD only -- the LayerNorm / attention / GEMM that reads it next
     // walks rows in the same XCD order and finds it in its own L2.  Used when it costs no extra round of tiles.
     constexpr int GROUP_M = 8;
+    // Row count from device memory (ragged batches: the packed token rows of this micro-batch, known only on the device):
+    // the launch was sized for the host's upper bound p.M; the tile walk below is rebuilt from the real count so that
+    // the live tiles still spread over all eight XCDs, and workgroups past it exit.
+    int64_t M = p.M;
+    if (p.m_dev) {
+        M = *p.m_dev;
+        if (M > p.M) M = p.M;
+        tiles_m = int((M + BM - 1) / BM);
+        const int nwg = tiles_m * tiles_n, pan_xcd = (tiles_m + 7) >> 3;
+        panel_split = tiles_m >= 16 && (pan_xcd * tiles_n + 31) / 32 <= ((nwg + 7) / 8 + 31) / 32;
+    }
     int item, pan0, pan1;
     if (panel_split) {
         const int q = tiles_m >> 3, r = tiles_m & 7, xcd = blockIdx.x & 7;
@@ -95,7 +114,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
         item = blockIdx.x >> 3;
         if (item >= (pan1 - pan0) * tiles_n) return;
     } else {
-        item = xcd_remap(blockIdx.x, gridDim.x);
+        const int nwg = p.m_dev ? tiles_m * tiles_n : int(gridDim.x);
+        if (int(blockIdx.x) >= nwg) return;
+        item = xcd_remap(blockIdx.x, nwg);
         pan0 = 0;
         pan1 = tiles_m;
     }
@@ -110,12 +131,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     const int tn = tn_all - seg * tiles_n_seg;
     const int64_t m0 = int64_t(tm) * BM;
     const int n0 = tn * BN;
-    const int rows_m = int(p.M - m0 < BM ? p.M - m0 : BM);  // valid rows / columns of this tile
+    const int rows_m = int(M - m0 < BM ? M - m0 : BM);  // valid rows / columns of this tile
     const int rows_n = p.N - n0 < BN ? p.N - n0 : BN;
 
     const int lda = int(p.lda), ldw = int(p.ldw);
+    const float* Abase = p.A;
+    if (p.A_dense) {
+        if (p.m_dev[0] == p.m_dev[1]) Abase = p.A_dense;
+    }
     const __amdgpu_buffer_rsrc_t rsA =
-        make_rsrc(p.A + m0 * p.lda, (uint64_t(rows_m - 1) * lda + p.K) * 4u);
+        make_rsrc(Abase + m0 * p.lda, (uint64_t(rows_m - 1) * lda + p.K) * 4u);
     const __amdgpu_buffer_rsrc_t rsW =
         make_rsrc(p.W[seg] + int64_t(n0) * p.ldw, (uint64_t(rows_n - 1) * ldw + p.K) * 4u);
 
@@ -197,15 +222,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
 #pragma unroll
                 for (int j = 0; j < T::NI; ++j) {
                     if constexpr (MF == 32) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
                     } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
                     }
                 }
         }
@@ -214,35 +239,47 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     const int nk = (p.K + BK - 1) / BK;
     gload(0, ra0, rb0);
 
-    // Epilogue operands.  C/D layouts: 32x32 block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16;
-    //                                  16x16 block: col = lane&15, row = 4*(lane>>4) + r,            r < 4.
+    // Epilogue operands.  The products are issued TRANSPOSED -- W fragment as the MFMA's A operand, activation fragment as
+    // its B operand -- so the accumulator block holds C^T: lane (m = lane & (MF-1), hi) owns, for ITS output row m, four
+    // CONSECUTIVE output columns per register quad (16x16 block: columns 4 hi + r, r < 4; 32x32 block: 8 q + 4 hi + (r & 3)
+    // for quad q = r >> 2).  Same products, same k-order, same bits as the untransposed issue; but bias, residual and C
+    // now move as 16-byte accesses and the four lane groups of a row write 64 contiguous bytes per instruction, the
+    // next block of the same wave the adjacent 64 (round 2 stored one float per lane: four rows x 64 B per
+    // instruction; the 128x64 tile's WRITE_SIZE was 1.31x its output, profiles/r02_hbm_traffic.txt).
     // Stores to rows past M fall outside the descriptor and are dropped by the hardware; columns past N are steered
-    // to an out-of-range offset.
+    // to an out-of-range offset.  N, ldc (and ldr) not multiples of 4, or unaligned bases, take the scalar path.
     const int ldc = int(p.ldc), ldr = int(p.ldr);
     const bool has_r = p.R != nullptr;
     const __amdgpu_buffer_rsrc_t rsR =
         make_rsrc(has_r ? p.R + m0 * p.ldr + n0 : p.A, has_r ? (uint64_t(rows_m - 1) * ldr + rows_n) * 4u : 0);
     const float* bias = p.bias[seg];
     const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias ? bias + n0 : p.A, bias ? uint64_t(rows_n) * 4u : 0);
-    auto blk_row = [&](int r) { return MF == 32 ? (r & 3) + 8 * (r >> 2) : r; };
-    const int lrow0 = wm * T::WTM + 4 * hi;
-    const int lcol0 = wn * T::WTN + l31;
-    constexpr int NPRE = RPRE ? T::MI * T::NI * NACC : 1;
-    float pre_r[NPRE], pre_b[RPRE ? T::NI : 1];
+    constexpr int NQ = NACC / 4;  // register quads (= float4 of consecutive columns) per block
+    constexpr bool vec = VEC;
+    const int lrow0 = wm * T::WTM + l31;
+    const int lcol0 = wn * T::WTN + 4 * hi;
+    auto load4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, int lcol) -> float4 {  // off in floats; lcol: first column
+        if constexpr (vec) return bload4(rs, lcol < rows_n ? off * 4u : OOB, 0);
+        float4 v;
+        v.x = bload1(rs, lcol + 0 < rows_n ? (off + 0) * 4u : OOB);
+        v.y = bload1(rs, lcol + 1 < rows_n ? (off + 1) * 4u : OOB);
+        v.z = bload1(rs, lcol + 2 < rows_n ? (off + 2) * 4u : OOB);
+        v.w = bload1(rs, lcol + 3 < rows_n ? (off + 3) * 4u : OOB);
+        return v;
+    };
+    constexpr int NPRE = RPRE ? T::MI * T::NI * NQ : 1;
+    float4 pre_r[NPRE], pre_b[RPRE ? T::NI * NQ : 1];
     if constexpr (RPRE) {
 #pragma unroll
-        for (int j = 0; j < T::NI; ++j) {
-            const int lcol = lcol0 + j * MF;
-            const bool col_ok = lcol < rows_n;
-            pre_b[j] = bload1(rsBias, col_ok ? unsigned(lcol) * 4u : OOB);
+        for (int j = 0; j < T::NI; ++j)
 #pragma unroll
-            for (int i = 0; i < T::MI; ++i)
+            for (int q = 0; q < NQ; ++q) {
+                const int lcol = lcol0 + j * MF + 8 * q;
+                pre_b[j * NQ + q] = load4(rsBias, unsigned(lcol), lcol);
 #pragma unroll
-                for (int r = 0; r < NACC; ++r) {
-                    const int lrow = lrow0 + i * MF + blk_row(r);
-                    pre_r[(j * T::MI + i) * NACC + r] = bload1(rsR, col_ok ? unsigned(lrow * ldr + lcol) * 4u : OOB);
-                }
-        }
+                for (int i = 0; i < T::MI; ++i)
+                    pre_r[(j * T::MI + i) * NQ + q] = load4(rsR, unsigned((lrow0 + i * MF) * ldr + lcol), lcol);
+            }
     }
 
     lstore(0, ra0, rb0);
@@ -273,36 +310,35 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
     const __amdgpu_buffer_rsrc_t rsC =
         make_rsrc(p.C[seg] + m0 * p.ldc + n0, (uint64_t(rows_m - 1) * ldc + rows_n) * 4u);
 #pragma unroll
-    for (int j = 0; j < T::NI; ++j) {
-        const int lcol = lcol0 + j * MF;
-        const bool col_ok = lcol < rows_n;
-        float bv;
-        if constexpr (RPRE)
-            bv = pre_b[j];
-        else
-            bv = bload1(rsBias, col_ok ? unsigned(lcol) * 4u : OOB);
+    for (int i = 0; i < T::MI; ++i) {
+        const int lrow = lrow0 + i * MF;
 #pragma unroll
-        for (int i = 0; i < T::MI; ++i) {
-            float res[NACC];
-            if constexpr (RPRE) {
+        for (int j = 0; j < T::NI; ++j)   // the blocks of one row back to back: adjacent 64-byte pieces of its lines
 #pragma unroll
-                for (int r = 0; r < NACC; ++r) res[r] = pre_r[(j * T::MI + i) * NACC + r];
-            } else if (has_r) {
-#pragma unroll
-                for (int r = 0; r < NACC; ++r) {
-                    const int lrow = lrow0 + i * MF + blk_row(r);
-                    res[r] = bload1(rsR, col_ok ? unsigned(lrow * ldr + lcol) * 4u : OOB);
+            for (int q = 0; q < NQ; ++q) {
+                const int lcol = lcol0 + j * MF + 8 * q;
+                float4 bv, res = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (RPRE) {
+                    bv = pre_b[j * NQ + q];
+                    res = pre_r[(j * T::MI + i) * NQ + q];
+                } else {
+                    bv = load4(rsBias, unsigned(lcol), lcol);
+                    if (has_r) res = load4(rsR, unsigned(lrow * ldr + lcol), lcol);
+                }
+                float4 v = make_float4(acc[i][j][4 * q + 0] + bv.x, acc[i][j][4 * q + 1] + bv.y,
+                                       acc[i][j][4 * q + 2] + bv.z, acc[i][j][4 * q + 3] + bv.w);
+                if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                if (has_r) v = make_float4(v.x + res.x, v.y + res.y, v.z + res.z, v.w + res.w);
+                const unsigned off = unsigned(lrow * ldc + lcol);
+                if constexpr (vec) {
+                    bstore4(rsC, lcol < rows_n ? off * 4u : OOB, v);
+                } else {
+                    bstore1(rsC, lcol + 0 < rows_n ? (off + 0) * 4u : OOB, v.x);
+                    bstore1(rsC, lcol + 1 < rows_n ? (off + 1) * 4u : OOB, v.y);
+                    bstore1(rsC, lcol + 2 < rows_n ? (off + 2) * 4u : OOB, v.z);
+                    bstore1(rsC, lcol + 3 < rows_n ? (off + 3) * 4u : OOB, v.w);
                 }
             }
-#pragma unroll
-            for (int r = 0; r < NACC; ++r) {
-                const int lrow = lrow0 + i * MF + blk_row(r);
-                float v = acc[i][j][r] + bv;
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (has_r) v += res[r];
-                bstore1(rsC, col_ok ? unsigned(lrow * ldc + lcol) * 4u : OOB, v);
-            }
-        }
     }
 #ifdef LAMP_TUNING
     if (p.trace && tid == 0) {
@@ -317,15 +353,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(GemmPara
 }
 
 #ifdef LAMP_TUNING
+static long long g_trace_slab_words = 0;   // capacity of one timeline slab (8 words per workgroup), see lamp_debug_set_gemm_trace
 static size_t g_extra_lds = 0;
 extern "C" __attribute__((visibility("default"))) void lamp_debug_set_gemm_extra_lds(int bytes) { g_extra_lds = size_t(bytes); }
 #endif
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool VEC>
 static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
     constexpr bool RPRE = T::MI * T::NI * (MF == 32 ? 16 : 4) <= 16;
-    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE>;
+    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC>;
     size_t LDS = T::LDS_BYTES;
     static AttrOnce once;
 #ifdef LAMP_TUNING
@@ -342,11 +379,20 @@ static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     const int tiles_n_seg = (p.N + BN - 1) / BN;
     const int tiles_n = tiles_n_seg * p.nseg;
     int64_t nwg = tiles_m * tiles_n;
-    if (nwg > 0x7fffffffLL) return LAMP_E_DIMS;
     // whole row-panels per XCD when the fullest XCD then needs no more rounds of tiles (32 CUs each) than an even split
     const int64_t pan_xcd = (tiles_m + 7) / 8;
-    const int panel_split = tiles_m >= 16 && (pan_xcd * tiles_n + 31) / 32 <= ((nwg + 7) / 8 + 31) / 32;
+    int panel_split = tiles_m >= 16 && (pan_xcd * tiles_n + 31) / 32 <= ((nwg + 7) / 8 + 31) / 32;
     if (panel_split) nwg = 8 * pan_xcd * tiles_n;
+    if (p.m_dev) {
+        // the kernel takes this decision again from the device-side row count: size the grid for either outcome
+        const int64_t split_grid = 8 * pan_xcd * tiles_n;
+        if (split_grid > nwg) nwg = split_grid;
+        panel_split = 0;
+    }
+    if (nwg > 0x7fffffffLL) return LAMP_E_DIMS;
+#ifdef LAMP_TUNING
+    if (p.trace && nwg * 8 > g_trace_slab_words) return LAMP_E_WORKSPACE;  // the timeline is indexed by blockIdx.x
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(T::NT), LDS, s, p, tiles_n_seg, tiles_n, int(tiles_m),
                        panel_split);
     return int(hipGetLastError());
@@ -354,8 +400,12 @@ static int launch_cfg2(const GemmParams& p, hipStream_t s) {
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF = 32>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
-    if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF>(p, s);
-    return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF>(p, s);
+    if (p.vec_epilogue) {
+        if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF, true>(p, s);
+        return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF, true>(p, s);
+    }
+    if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF, false>(p, s);
+    return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF, false>(p, s);
 }
 
 #ifdef LAMP_TUNING
@@ -369,6 +419,7 @@ extern "C" __attribute__((visibility("default"))) void lamp_debug_force_gemm_til
 extern "C" __attribute__((visibility("default"))) void lamp_debug_set_gemm_trace(unsigned long long* buf, long long slab_words, int n_slabs) {
     g_gemm_trace = buf;
     g_trace_slab = slab_words;
+    g_trace_slab_words = slab_words;
     g_trace_slabs = n_slabs;
     g_trace_count = 0;
 }
@@ -378,8 +429,8 @@ int launch_gemm(const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.nseg < 1 || p.nseg > GEMM_MAX_SEG) return LAMP_E_DIMS;
     if ((p.K & 3) || (p.lda & 3) || (p.ldw & 3)) return LAMP_E_ALIGN;
-    if (!p.A) return LAMP_E_NULL;
-    if (!aligned16(p.A)) return LAMP_E_ALIGN;
+    if (!p.A || (p.A_dense && !p.m_dev)) return LAMP_E_NULL;
+    if (!aligned16(p.A) || (p.A_dense && !aligned16(p.A_dense))) return LAMP_E_ALIGN;
     for (int i = 0; i < p.nseg; ++i) {
         if (!p.W[i] || !p.C[i]) return LAMP_E_NULL;
         if (!aligned16(p.W[i])) return LAMP_E_ALIGN;
@@ -389,6 +440,9 @@ int launch_gemm(const GemmParams& p_in, hipStream_t s) {
                                 double(p.M) * p.N * p.nseg * (p.R ? 2 : 1));
     ProfScope prof(LAMP_K_GEMM, flops, bytes, s);
     p.trace = nullptr;
+    bool vec = !(p.N & 3) && !(p.ldc & 3) && (!p.R || (!(p.ldr & 3) && aligned16(p.R)));
+    for (int i = 0; i < p.nseg; ++i) vec = vec && aligned16(p.C[i]) && (!p.bias[i] || aligned16(p.bias[i]));
+    p.vec_epilogue = vec ? 1 : 0;
 #ifdef LAMP_TUNING
     if (g_gemm_trace && g_trace_slabs > 0) {
         // upper bound of the grid over the tile menu: 32x64 tiles

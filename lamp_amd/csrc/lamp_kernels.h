@@ -31,6 +31,12 @@ struct GemmParams {
     const float* R;  // residual, same for every segment (only meaningful with nseg == 1)
     int64_t ldr;
     int relu;
+    const int* m_dev;   // nullable: the live row count in DEVICE memory (<= M, which then only sizes the launch) -- the
+                        // packed token rows of a ragged batch, counted on the device (pointwise.hip: seq_plan_kernel)
+    const float* A_dense;  // nullable, with m_dev = SeqPlan::rows: read A_dense instead of A when m_dev[0] == m_dev[1], i.e. no
+                           // position of the batch was skipped and the padded encoder output IS the packed matrix (the
+                           // last encoder LayerNorm then skips its packed copy)
+    int vec_epilogue;   // set by launch_gemm: bias / residual / C can move as 16-byte accesses
     unsigned long long* trace;  // tuning build only (per-workgroup timeline, see gemm.hip); NULL in production
 };
 
@@ -53,6 +59,12 @@ struct AttnParams {
     int64_t m_sb, m_sq;
     const int* tiles;      // optional per-32-query-block active key-tile lists (shared masks), or nullptr
     int64_t tiles_stride;
+    // Ragged keys (lamp_forward's enc-dec attention; SeqPlan): sample b has kv_len[b] <= lk keys -- every key past it is a PAD
+    // token, i.e. exactly masked -- and its K / V rows start at row kv_off[b] of the K / V matrices (packed token rows;
+    // lay.k_b / lay.v_b are then unused).  Both in device memory, both or neither.  The key loop stops at kv_len[b] and
+    // the key split is chosen from kv_len[b], so a sample's bits do not depend on the padded length of its batch.
+    const int* kv_len;
+    const int* kv_off;
     unsigned long long* trace;  // tuning build only: per-workgroup timeline of attention_small.hip; NULL in production
 };
 
@@ -88,11 +100,28 @@ __device__ __forceinline__ float4 drop4(float4 v, int64_t e, const DropoutSpec& 
     return make_float4(drop1(v.x, e, d), drop1(v.y, e + 1, d), drop1(v.z, e + 2, d), drop1(v.w, e + 3, d));
 }
 
+// Ragged token batches (lamp_forward): per-sample extents counted ON THE DEVICE by seq_plan_kernel (pointwise.hip), so
+// that the encoder runs on the packed non-PAD rows and the enc-dec attention stops at each sample's last real key --
+// without a host round trip.  All pointers are device int32 arrays in the caller's workspace.
+struct SeqPlan {
+    int* klen;  // [nb]     keys of sample b: 1 + its last non-PAD token position
+    int* plen;  // [nb]     rows of sample b in the packed matrix (>= klen; T in the padded layout)
+    int* off;   // [nb + 1] first packed row of sample b; off[nb] = n_tok
+    int* rows;  // [2]      n_tok, and n_tok + 1 when the shared PAD row (row n_tok) is live
+};
+int launch_seq_plan(const int64_t* seq, const int64_t* pos, int nb, int T, int64_t seq_stride, bool packed,
+                    const SeqPlan& sp, hipStream_t s);
+int launch_embed_packed(const int64_t* seq, const int64_t* pos, int nb, int T, const float* emb, int n_vocab,
+                        const float* pos_table, int n_position, int d, const SeqPlan& sp, float* out, hipStream_t s);
+
 // y = LayerNorm(dropout(x) + residual[row % r_mod or row])   (residual nullable; r_mod 0 = per-row residual; drop nullable)
+// m_dev: live row count in device memory (M sizes the launch).  scatter (+ T, y_flat): the last LayerNorm of the packed
+// encoder -- M = nb * T flat positions, y = the packed rows (in place), y_flat = the padded [nb, T, d] encoder output.
 int launch_layernorm(const float* x, int64_t M, int d, const float* g, const float* b, float eps,
                      const float* residual, int64_t r_mod, float* y, hipStream_t s, const float* w_out = nullptr,
                      int n_labels = 0, float* logits = nullptr,  // w_out: fused read-out, y may then be NULL
-                     const DropoutSpec* drop = nullptr);
+                     const DropoutSpec* drop = nullptr, const int* m_dev = nullptr, const SeqPlan* scatter = nullptr,
+                     int T = 0, float* y_flat = nullptr);
 size_t layernorm_bwd_workspace_bytes(int64_t M, int d);
 int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_t M, int d, const float* g, float eps,
                          const DropoutSpec* drop, const float* dy, float* dz, float* dz_drop, float* dgamma, float* dbeta,
@@ -145,6 +174,11 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff)
 }
 __device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, unsigned voff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff, float4 v) {
+    const f32x4 f = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), r, voff, 0, 0);
 }
 
 __device__ __forceinline__ unsigned bload_u8(__amdgpu_buffer_rsrc_t r, unsigned voff) {

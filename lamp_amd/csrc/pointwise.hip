@@ -33,21 +33,141 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
     }
 }
 
+// Per-sample extents of a (possibly ragged) token batch, counted on the device -- no host round trip (SeqPlan,
+// lamp_kernels.h).  klen[b] = 1 + the last position whose token is not PAD: keys past it are exactly masked
+// (lamp/utils.py:26-34), so the enc-dec attention stops there.  plen[b] >= klen[b] additionally covers every position
+// with a non-zero POSITION index: rows past plen[b] are all the same row, emb[PAD] + pos_table[0] pushed through the
+// row-wise encoder (lamp/Encoders.py:64-79), which the packed encoder computes once (row n_tok) instead of per
+// position.  packed: off[b] = sum of plen before b (the sample's first row of the packed matrix); else off[b] = b * T
+// and plen[b] = T (padded layout, only klen is of interest).  rows[0] = off[nb]; rows[1] = off[nb] + 1 when some
+// position is skipped (the shared PAD row is then live), else off[nb].  ONE workgroup: a wave per sample for the scan
+// from the end (64 positions per step), then a wave-level prefix sum.
+__global__ __launch_bounds__(1024) void seq_plan_kernel(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
+                                                        int nb, int T, int64_t seq_stride, int packed, SeqPlan sp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    for (int b = wave; b < nb; b += nwave) {
+        const int64_t* row = seq + int64_t(b) * seq_stride;
+        const int64_t* prow = pos ? pos + int64_t(b) * seq_stride : nullptr;
+        int kl = 0, pl = 0;
+        for (int base = ((T - 1) / 64) * 64; base >= 0 && (kl == 0 || (prow && pl == 0)); base -= 64) {
+            const int j = base + lane;
+            const bool tok = j < T && row[j] != 0;
+            const bool act = tok || (prow && j < T && prow[j] != 0);
+            const unsigned long long mt = __ballot(tok), ma = __ballot(act);
+            if (kl == 0 && mt) kl = base + 64 - __builtin_clzll(mt);
+            if (pl == 0 && ma) pl = base + 64 - __builtin_clzll(ma);
+            if (!prow) pl = kl;
+        }
+        if (pl < kl) pl = kl;
+        if (lane == 0) {
+            sp.klen[b] = kl;
+            sp.plen[b] = packed ? pl : T;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    int carry = 0;
+    bool skipped = false;
+    for (int base = 0; base < nb; base += 64) {
+        const int b = base + lane;
+        const int v = b < nb ? sp.plen[b] : 0;
+        skipped = skipped || (b < nb && v < T);
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int u = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += u;
+        }
+        if (b < nb) sp.off[b] = packed ? carry + incl - v : b * T;
+        carry += __shfl(incl, 63, 64);
+    }
+    const bool any_skipped = __any(skipped);
+    if (lane == 0) {
+        const int n_tok = packed ? carry : nb * T;
+        sp.off[nb] = n_tok;
+        sp.rows[0] = n_tok;
+        sp.rows[1] = n_tok + ((packed && any_skipped) ? 1 : 0);
+    }
+}
+
+// Embedding gather of the packed encoder: flat position (b, j) with j < plen[b] -> packed row off[b] + j; the extra
+// work item nb * T writes the shared PAD row (row n_tok = emb[PAD] + pos_table[0]) when some position is skipped.
+__global__ __launch_bounds__(256) void embed_packed_kernel(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
+                                                           int nb, int T, const float* __restrict__ emb, int n_vocab,
+                                                           const float* __restrict__ pos_table, int n_position, int d,
+                                                           SeqPlan sp, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t flat = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);
+    const int64_t n_flat = int64_t(nb) * T;
+    if (flat > n_flat) return;
+    int64_t tok = 0, ps = 0, dst;
+    if (flat == n_flat) {
+        if (sp.rows[1] == sp.rows[0]) return;   // no position skipped: no PAD row
+        dst = sp.rows[0];
+    } else {
+        const int b = int(flat / T), j = int(flat - int64_t(b) * T);
+        if (j >= sp.plen[b]) return;
+        tok = seq[flat];
+        ps = pos_table ? pos[flat] : 0;
+        dst = int64_t(sp.off[b]) + j;
+    }
+    const bool ok = tok >= 0 && tok < n_vocab && ps >= 0 && (!pos_table || ps < n_position);
+    const float4* e = reinterpret_cast<const float4*>(emb + (ok ? tok : 0) * d);
+    const float4* q = pos_table ? reinterpret_cast<const float4*>(pos_table + (ok ? ps : 0) * d) : nullptr;
+    float4* o = reinterpret_cast<float4*>(out + dst * d);
+    const float nan = __builtin_nanf("");
+    for (int c = lane; c < d / 4; c += 64) {
+        float4 v = e[c];
+        if (q) {
+            const float4 w = q[c];
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        if (!ok) v = make_float4(nan, nan, nan, nan);
+        o[c] = v;
+    }
+}
+
 // y = (x - mean) / sqrt(var_biased + eps) * g + b over the last dim.  Two-pass (mean, then centred
 // sum of squares) on a register-resident row; NV float4 per lane.
-template <int NV, bool DROP>
+// RG (ragged encoder, packed rows -- see seq_plan_kernel):  0 = plain rows 0 .. M-1.  1 = the row count comes from device
+// memory (*m_dev <= M; M only sizes the launch).  2 = the last encoder LayerNorm: the launch walks the FLAT positions
+// (b, j) of the padded [nb, T, d] encoder output; position (b, j) normalises packed row off[b] + j (or the shared PAD row
+// n_tok for j >= plen[b]), writes it to y2[b, j] and -- live positions only -- back to its packed row in y, which the
+// K/V projections read.  The PAD row is read by many positions and written by none.
+template <int NV, bool DROP, int RG>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t M, int d,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ bta, float eps,
                                                         const float* __restrict__ res, int64_t r_mod,
                                                         float* __restrict__ y,
                                                         const float* __restrict__ w_out, int n_labels,
-                                                        float* __restrict__ logits, DropoutSpec drop) {
+                                                        float* __restrict__ logits, DropoutSpec drop,
+                                                        const int* __restrict__ m_dev, SeqPlan sp, int T,
+                                                        float* __restrict__ y2) {
     const int lane = threadIdx.x & 63;
     // rows in the XCD-contiguous order of the GEMM that produced x (and of the one that reads y): most of a row's
     // cache lines are then still in THIS XCD's L2 instead of a round trip to the Infinity Cache away
-    const int64_t row = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    int64_t row;
+    int64_t flat = 0;
+    bool live = true;
+    if constexpr (RG == 1) {
+        const int64_t Mrt = *m_dev < M ? *m_dev : M;
+        const int nblk = int((Mrt + 3) / 4);
+        if (int(blockIdx.x) >= nblk) return;
+        row = int64_t(xcd_remap(blockIdx.x, nblk)) * 4 + (threadIdx.x >> 6);
+        if (row >= Mrt) return;
+    } else if constexpr (RG == 2) {
+        flat = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);
+        if (flat >= M) return;
+        const int b = int(flat / T), j = int(flat - int64_t(b) * T);
+        live = j < sp.plen[b];
+        row = live ? int64_t(sp.off[b]) + j : int64_t(sp.rows[0]);
+        // no position skipped anywhere: packed row == flat position, and the K / V projections read y2 (GemmParams::A_dense)
+        if (sp.rows[1] == sp.rows[0]) y = nullptr;
+    } else {
+        row = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);
+        if (row >= M) return;
+    }
     const float4* xr = reinterpret_cast<const float4*>(x + row * d);
     const float4* rr = res ? reinterpret_cast<const float4*>(res + (r_mod > 0 ? row % r_mod : row) * d) : nullptr;
     const int nv = d / 4;
@@ -75,7 +195,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(ss) / float(d) + eps);
-    float4* yr = y ? reinterpret_cast<float4*>(y + row * d) : nullptr;
+    float4* yr = (y && live) ? reinterpret_cast<float4*>(y + row * d) : nullptr;
+    float4* yf = RG == 2 ? reinterpret_cast<float4*>(y2 + flat * d) : nullptr;
     const float4* g4 = reinterpret_cast<const float4*>(g);
     const float4* b4 = reinterpret_cast<const float4*>(bta);
     // optional fused label read-out (lamp/Models.py:124-126): logits[row] = <LN(row), w_out[row % L]>
@@ -89,6 +210,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const float4 o = make_float4((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
                                          (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
             if (yr) yr[c] = o;
+            if constexpr (RG == 2) yf[c] = o;
             if (w4) {
                 const float4 ww = w4[c];
                 dot += (o.x * ww.x + o.y * ww.y) + (o.z * ww.z + o.w * ww.w);
@@ -194,27 +316,37 @@ int launch_embed(const int64_t* seq, const int64_t* pos, int64_t n_tok, const fl
 
 int launch_layernorm(const float* x, int64_t M, int d, const float* g, const float* b, float eps,
                      const float* residual, int64_t r_mod, float* y, hipStream_t s, const float* w_out, int n_labels,
-                     float* logits, const DropoutSpec* drop) {
+                     float* logits, const DropoutSpec* drop, const int* m_dev, const SeqPlan* scatter, int T,
+                     float* y_flat) {
     if (M <= 0 || d <= 0) return LAMP_E_DIMS;
     if ((d & 3) || d > 4096) return LAMP_E_UNSUPPORTED;
     if (!x || !g || !b || (!y && !w_out) || (w_out && (!logits || n_labels <= 0))) return LAMP_E_NULL;
+    if (scatter && (!y_flat || !y || T <= 0 || residual || w_out || (drop && drop->threshold > 0))) return LAMP_E_UNSUPPORTED;
+    if (m_dev && (scatter || residual || w_out || (drop && drop->threshold > 0))) return LAMP_E_UNSUPPORTED;
     if (!aligned16(x) || (y && !aligned16(y)) || !aligned16(g) || !aligned16(b) || (residual && !aligned16(residual)) ||
-        (w_out && !aligned16(w_out)))
+        (w_out && !aligned16(w_out)) || (y_flat && !aligned16(y_flat)))
         return LAMP_E_ALIGN;
     unsigned grid;
     if (int e = grid4(M, &grid)) return e;
-    ProfScope prof(LAMP_K_LAYERNORM, 0.0, 8.0 * double(M) * d, s);
+    ProfScope prof(LAMP_K_LAYERNORM, 0.0, (scatter ? 12.0 : 8.0) * double(M) * d, s);
     const int nv = (d / 4 + 63) / 64;
     const bool dr = drop && drop->threshold > 0;
     const DropoutSpec ds = dr ? *drop : DropoutSpec{0u, 1.f, 0u};
+    const SeqPlan sp = scatter ? *scatter : SeqPlan{nullptr, nullptr, nullptr, nullptr};
 #define LAMP_LN_LAUNCH(NV_)                                                                                          \
     do {                                                                                                              \
         if (dr)                                                                                                       \
-            hipLaunchKernelGGL((layernorm_kernel<NV_, true>), dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps, residual, \
-                               r_mod, y, w_out, n_labels, logits, ds);                                                \
+            hipLaunchKernelGGL((layernorm_kernel<NV_, true, 0>), dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps,      \
+                               residual, r_mod, y, w_out, n_labels, logits, ds, m_dev, sp, T, y_flat);                \
+        else if (scatter)                                                                                             \
+            hipLaunchKernelGGL((layernorm_kernel<NV_, false, 2>), dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps,     \
+                               residual, r_mod, y, w_out, n_labels, logits, ds, m_dev, sp, T, y_flat);                \
+        else if (m_dev)                                                                                               \
+            hipLaunchKernelGGL((layernorm_kernel<NV_, false, 1>), dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps,     \
+                               residual, r_mod, y, w_out, n_labels, logits, ds, m_dev, sp, T, y_flat);                \
         else                                                                                                          \
-            hipLaunchKernelGGL((layernorm_kernel<NV_, false>), dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps,        \
-                               residual, r_mod, y, w_out, n_labels, logits, ds);                                      \
+            hipLaunchKernelGGL((layernorm_kernel<NV_, false, 0>), dim3(grid), dim3(256), 0, s, x, M, d, g, b, eps,     \
+                               residual, r_mod, y, w_out, n_labels, logits, ds, m_dev, sp, T, y_flat);                \
     } while (0)
     if (nv <= 1)
         LAMP_LN_LAUNCH(1);
@@ -227,6 +359,32 @@ int launch_layernorm(const float* x, int64_t M, int d, const float* g, const flo
     else
         LAMP_LN_LAUNCH(16);
 #undef LAMP_LN_LAUNCH
+    return int(hipGetLastError());
+}
+
+// seq: [nb, T] tokens (row stride seq_stride), pos: nullable [nb, T] position indices (same stride).
+int launch_seq_plan(const int64_t* seq, const int64_t* pos, int nb, int T, int64_t seq_stride, bool packed,
+                    const SeqPlan& sp, hipStream_t s) {
+    if (nb <= 0 || T <= 0) return LAMP_E_DIMS;
+    if (!seq || !sp.klen || !sp.plen || !sp.off || !sp.rows) return LAMP_E_NULL;
+    if (int64_t(nb) * T >= 0x7fffffffLL) return LAMP_E_DIMS;   // packed row indices are 32-bit
+    const int threads = nb >= 16 ? 1024 : (nb >= 4 ? 256 : 64);
+    hipLaunchKernelGGL(seq_plan_kernel, dim3(1), dim3(threads), 0, s, seq, pos, nb, T, seq_stride, packed ? 1 : 0, sp);
+    return int(hipGetLastError());
+}
+
+int launch_embed_packed(const int64_t* seq, const int64_t* pos, int nb, int T, const float* emb, int n_vocab,
+                        const float* pos_table, int n_position, int d, const SeqPlan& sp, float* out, hipStream_t s) {
+    if (nb <= 0 || T <= 0 || d <= 0 || n_vocab <= 0) return LAMP_E_DIMS;
+    if (d & 3) return LAMP_E_UNSUPPORTED;
+    if (!seq || !emb || !out || (pos_table && !pos)) return LAMP_E_NULL;
+    if (!aligned16(emb) || !aligned16(out) || (pos_table && !aligned16(pos_table))) return LAMP_E_ALIGN;
+    unsigned g;
+    const int64_t n_tok = int64_t(nb) * T;
+    if (int e = grid4(n_tok + 1, &g)) return e;
+    ProfScope prof(LAMP_K_EMBED, 0.0, double(n_tok) * (16.0 + 4.0 * d * (pos_table ? 3 : 2)), s);
+    hipLaunchKernelGGL(embed_packed_kernel, dim3(g), dim3(256), 0, s, seq, pos, nb, T, emb, n_vocab, pos_table,
+                       n_position, d, sp, out);
     return int(hipGetLastError());
 }
 

@@ -51,6 +51,15 @@ def test_bench_spawns_its_own_ranks(dev):
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert two['n_gpus'] == 2 and two['ranks_seen'] == [0, 1] and len(two['per_rank']) == 2
     assert two['config']['launcher'] == 'self-spawned ranks' and two['physical_devices'] == 1
+    # same weights on both ranks, different batches: rank 0 recomputed rank 1's samples bit for bit
+    assert two['backend'] == 'gloo' and two['control_plane_ranks'] == 2
+    assert two['cross_rank_check']['bitwise_equal'] is True and two['cross_rank_check']['ranks_checked'] == [1]
+    assert two['per_rank'][0]['device_identity'] == two['per_rank'][1]['device_identity']
+    # ragged batches: the two ranks pad to DIFFERENT lengths; the samples still come out bit-identical on rank 0
+    r2r, rag = _bench(['--gpus', '2', '--ragged'] + common, {'LAMP_BENCH_BACKEND': 'gloo'})
+    assert r2r.returncode == 0, r2r.stderr[-2000:]
+    assert rag['per_rank'][0]['padded_length'] != rag['per_rank'][1]['padded_length']
+    assert rag['cross_rank_check']['bitwise_equal'] is True
     assert all(p['value'] > 0 for p in two['per_rank'])
     # aggregate = all samples / slowest rank's time
     slowest = max(p['ms_per_step'] for p in two['per_rank'])
@@ -72,8 +81,8 @@ def test_bench_spawns_its_own_ranks(dev):
 
 
 def test_rccl_control_plane_calls_work(dev):
-    """bench.py's "nccl" (= RCCL) control plane -- init with device_id, barrier(device_ids), all_gather of a float64 device
-    tensor -- as a one-rank group (RCCL refuses two ranks on one device, so the 2-rank tests above run on gloo)."""
+    """bench.py's control plane class with its "nccl" (= RCCL) group -- probe all_reduce, barrier(device_ids), gathers of
+    device tensors -- as a one-rank group (RCCL refuses two ranks on one device, so the 2-rank tests above run on gloo)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_rccl_control_plane.py')], capture_output=True,
                        text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert r.returncode == 0 and 'rccl control plane ok' in r.stdout, r.stderr[-2000:]

@@ -271,8 +271,11 @@ CONFIGS = {
     'inveye_8h': (300, 70, 50, 256, 512, 8, 'inveye', True, 3, 0.0, [50, 1, 23]),
     # 4096 labels (configs[4]'s label graph: 128 key tiles per label row, sparse prior mask), narrow model
     'labels4096': (500, 4096, 64, 256, 512, 2, 'prior', True, 2, 0.05, [64, 30]),
-    # BASELINE.json configs[1] at its full batch, directly against the oracle (0.15 s of CPU)
+    # BASELINE.json configs[1] / configs[2] at their full batch, directly against the oracle (0.15 / 0.3 s of CPU)
     'reuters_b32': (23666, 90, 302, 512, 512, 4, 'prior', True, 32, 0.10, None),
+    'bibtex_b32': (1840, 159, 100, 512, 1024, 4, 'prior', False, 32, 0.05, None),
+    'reuters_b32_ragged': (23666, 90, 302, 512, 512, 4, 'prior', True, 32, 0.10,
+                           [302, 20, 150, 77, 201, 33, 288, 9, 64, 65, 16, 17, 191, 192, 193, 48] * 2),
     # BASELINE.json configs[4] EXACTLY: 4096 labels x 512 tokens, d_model 1024, 8 heads, d_ff 2048,
     # prior p = 0.05 -- one full and one ragged sample (the oracle needs ~0.8 TFLOP and ~2 GB of host memory), and
     # its fully connected variant
@@ -281,10 +284,14 @@ CONFIGS = {
 }
 
 
-def make_case(cfg, dev, seed=0):
+def make_case(cfg, dev, seed=0, qk_scale=1.0):
     from lamp_amd.Models import LAMP
     V, L, T, d, dff, h, mask, pos, B, p, lengths = cfg
     sd = R.make_state_dict(V, L, T, d, dff, h, 2, 2, pos_emb=pos, seed=seed)
+    if qk_scale != 1.0:   # sharper attention, as trained weights have it
+        for k in sd:
+            if k.startswith('decoder.') and ('w_qs' in k or 'w_ks' in k):
+                sd[k] = sd[k] * qk_scale
     adj = R.make_adjacency(L, p, seed) if mask == 'prior' else None
     seq, spos = R.make_batch(B, V, T, lengths=lengths, seed=seed)
     m = LAMP(V, L, T, L, n_layers_enc=2, n_layers_dec=2, n_head=h, n_head2=h, d_word_vec=d, d_model=d,
@@ -305,6 +312,24 @@ def test_model_vs_oracle_at_baseline_sizes(dev, name):
     logits, enc, _ = m((seq.to(dev), spos.to(dev)), None, None, None)
     assert max_abs_diff(enc, ref_enc) < TOL_ACT
     assert max_abs_diff(logits, ref_logits) < TOL_LOGIT
+
+
+@pytest.mark.parametrize('name,B', [('reuters_fixed', 4), ('reuters_ragged', 6), ('delicious', 2)])
+def test_sharp_attention_at_real_width(dev, name, B):
+    """Conditioning at the BASELINE widths: decoder Q / K weights x3 make the softmax as peaked as
+    trained weights do.  The yardstick is the oracle evaluated in fp64; the bar is max(1e-4, 3 x the fp32 oracle's own
+    distance from it)."""
+    cfg = list(CONFIGS[name])
+    cfg[8] = B
+    if cfg[10] is not None:
+        cfg[10] = cfg[10][:B]
+    m, sd, blocked, seq, spos, h = make_case(tuple(cfg), dev, qk_scale=3.0)
+    with torch.no_grad():
+        ref32, _, _ = R.forward(sd, seq, spos, h, blocked)
+        ref64, _, _ = R.forward(R.to_dtype(sd, torch.float64), seq, spos, h, blocked)
+    gap = max_abs_diff(ref32, ref64)
+    logits, _, _ = m((seq.to(dev), spos.to(dev)), None, None, None)
+    assert max_abs_diff(logits, ref64) <= max(1e-4, 3 * gap), (max_abs_diff(logits, ref64), gap)
 
 
 # ------------------------------------------------------------------ size-independent properties
@@ -520,13 +545,47 @@ def test_model_with_clustered_label_graph_uses_tile_lists(dev):
 
 
 def test_trailing_padding_does_not_change_results(dev):
-    """Extra PAD columns are blocked keys and PAD rows of the encoder: logits must not move beyond
-    rounding noise (tile boundaries shift, so not bitwise)."""
+    """Extra PAD columns are blocked keys and PAD rows of the encoder.  The encoder runs on the packed non-PAD rows and
+    the enc-dec attention takes its key split from each sample's own key count, so a sample's logits and encoder
+    rows do not depend on the padded length of its batch -- bit for bit -- and every PAD position of enc_output
+    holds the one shared PAD row."""
     m, sd, blocked, seq, spos, h = make_case(CONFIGS['reuters_ragged'], dev)
     seq, spos = seq.to(dev), spos.to(dev)
-    base, _, _ = m((seq[1:4, :210], spos[1:4, :210]), None, None, None)
-    wide, _, _ = m((seq[1:4], spos[1:4]), None, None, None)
-    assert max_abs_diff(base, wide) < 2e-5
+    base, enc_base, _ = m((seq[1:4, :210], spos[1:4, :210]), None, None, None)
+    wide, enc_wide, _ = m((seq[1:4], spos[1:4]), None, None, None)
+    assert torch.equal(base, wide)
+    assert torch.equal(enc_base, enc_wide[:, :210])
+    pad_row = enc_wide[0, 301]
+    lengths = [20, 150, 77]
+    for b, n in enumerate(lengths):
+        assert torch.equal(enc_wide[b, n:], pad_row.expand(302 - n, -1))
+    # a sample alone, padded to its own length, and the same sample inside the 6-sample ragged batch
+    full, enc_full, _ = m((seq, spos), None, None, None)
+    for b, n in enumerate([302, 20, 150, 77, 201, 33]):
+        one, enc_one, _ = m((seq[b:b + 1, :n], spos[b:b + 1, :n]), None, None, None)
+        assert torch.equal(one, full[b:b + 1]) and torch.equal(enc_one, enc_full[b:b + 1, :n])
+
+
+def test_pad_tokens_inside_a_sequence(dev):
+    """PAD tokens that are not trailing are ordinary encoder rows and blocked keys; trailing PAD tokens that still carry a
+    position index are live rows too (their embedding is not the shared PAD row).  Against the oracle, with and
+    without attention maps (packed and padded encoder), bitwise equal between the two."""
+    m, sd, blocked, seq, spos, h = make_case(CONFIGS['reuters_ragged'], dev)
+    seq, spos = seq.clone(), spos.clone()
+    seq[1, 5] = 0                                   # a PAD token inside sample 1 (20 tokens), position index kept
+    seq[2, 100:120] = 0
+    spos[2, 100:120] = 0                            # a hole of real PAD positions inside sample 2
+    spos[3, 77:80] = torch.tensor([78, 79, 80])     # trailing PAD tokens with position indices
+    seq[5, :] = 0                                   # no token at all, positions kept: every key blocked
+    with torch.no_grad():
+        ref_logits, ref_enc, _ = R.forward(sd, seq, spos, h, blocked)
+    src = (seq.to(dev), spos.to(dev))
+    logits, enc, _ = m(src, None, None, None)
+    assert torch.isnan(logits[5]).all() and torch.isnan(ref_logits[5]).all()
+    assert max_abs_diff(enc, ref_enc) < TOL_ACT
+    assert max_abs_diff(logits[:5], ref_logits[:5]) < TOL_LOGIT
+    lg, en, _, _ = m(src, None, None, None, return_attns=True)
+    assert torch.equal(lg[:5], logits[:5]) and torch.equal(en, enc)
 
 
 def test_allpad_row_poisons_only_itself(dev):
@@ -538,6 +597,13 @@ def test_allpad_row_poisons_only_itself(dev):
     clean, _, _ = m((seq[[0, 1, 3, 4, 5]].to(dev), spos[[0, 1, 3, 4, 5]].to(dev)), None, None, None)
     assert torch.isnan(logits[2]).all()
     assert torch.equal(logits[[0, 1, 3, 4, 5]], clean)
+    # a batch of PAD only: no packed row but the shared PAD row
+    seq0, pos0 = torch.zeros(2, 40, dtype=torch.int64, device=dev), torch.zeros(2, 40, dtype=torch.int64, device=dev)
+    lg0, enc0, _ = m((seq0, pos0), None, None, None)
+    with torch.no_grad():
+        _, ref_enc0, _ = R.forward(sd, seq0.cpu(), pos0.cpu(), h, blocked)
+    assert torch.isnan(lg0).all() and max_abs_diff(enc0, ref_enc0) < TOL_ACT
+    assert torch.equal(enc0, enc0[0, 0].expand_as(enc0))
 
 
 def test_label_permutation_equivariance(dev):

@@ -64,3 +64,55 @@ def test_two_rank_gloo_shards_match_single_process(tmp_path):
     assert res['sharded'].shape == res['single'].shape == (7, 10)
     # per-sample arithmetic is independent of the shard: identical padded length T in both runs
     assert torch.equal(res['sharded'], res['single'])
+
+
+def _control_plane_worker(rank, world, port, want, out_dir):
+    """bench.ControlPlane (the only use bench.py makes of torch.distributed) between two CPU processes."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    import bench
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    cp = bench.ControlPlane(rank, world, torch.device('cpu'), want)
+    try:
+        cp.barrier()
+        rows = cp.gather(torch.tensor([float(rank), 10.0 + rank], dtype=torch.float64))
+        logits = cp.gather(torch.full((3, 5), float(rank)))
+        names = cp.gather_objects('dev-%d' % rank)
+        torch.save({'backend': cp.backend, 'note': cp.note, 'rows': rows, 'logits': logits, 'names': names,
+                    'ranks': cp.ranks_in_group()}, os.path.join(out_dir, 'cp%d.pt' % rank))
+    finally:
+        cp.close()
+
+
+@pytest.mark.parametrize('want', ['gloo', 'nccl'])
+def test_bench_control_plane_two_ranks(tmp_path, want):
+    """want='nccl' on this GPU-less box exercises the fallback: RCCL cannot start, every rank agrees on gloo and the
+    reason is kept for the result line."""
+    mp.spawn(_control_plane_worker, args=(2, _free_port(), want, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(tmp_path / ('cp%d.pt' % r))
+        assert res['backend'] == 'gloo' and res['ranks'] == 2
+        assert (res['note'] is None) == (want == 'gloo')
+        assert [t.tolist() for t in res['rows']] == [[0.0, 10.0], [1.0, 11.0]]
+        assert [float(t[0, 0]) for t in res['logits']] == [0.0, 1.0] and res['names'] == ['dev-0', 'dev-1']
+
+
+def test_bench_batches_are_rebuildable_by_every_rank():
+    """The cross-rank bitwise check relies on rank 0 rebuilding rank r's batch exactly."""
+    import argparse
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    import bench
+    from lamp_amd import synthetic as S
+    args = argparse.Namespace(ragged=True, workload='reuters', batch=8)
+    w1, len1 = bench.batch_of_rank(args, bench.WORKLOADS['reuters'], 1)
+    w1b, len1b = bench.batch_of_rank(args, bench.WORKLOADS['reuters'], 1)
+    w0, len0 = bench.batch_of_rank(args, bench.WORKLOADS['reuters'], 0)
+    assert len1 == len1b and w1 == w1b and len1 != len0 and w1['T'] == max(len1) and 20 <= min(len1)
+    a = S.make_batch(8, w1['V'], w1['T'], lengths=len1, seed=1)
+    b = S.make_batch(8, w1['V'], w1['T'], lengths=len1, seed=1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # analytic GEMM FLOPs of a fixed-length reuters step = what the library's launchers count (69.2 GFLOP)
+    gf = bench.gemm_flops_per_step(bench.WORKLOADS['reuters'], 32, 32 * 302)
+    assert abs(gf / 1e9 - 69.22) < 0.05

@@ -105,6 +105,36 @@ def gemm_ab(cfgs=None, rounds=7):
                                                            '*' if med[c] <= best * 1.01 else ' ') for c in cfgs))
 
 
+def lib_ab(rounds=9):
+    """A/B of two BUILDS of the library (argv[2], argv[3]: paths) on the GEMM shapes of the forwards, heuristic tile,
+    round-robin medians in one process -- how a kernel change is judged when box-to-box variance (3-4 %) is larger than
+    the effect."""
+    import statistics
+    libs = [(os.path.basename(p), N.load_library(p)) for p in sys.argv[2:4]]
+    dev = torch.device('cuda:0')
+    shapes = [('encFFN 9664x512x512 +b relu', 9664, 512, 512, 1, 0), ('encFFN 9664x512x512 +b +R', 9664, 512, 512, 0, 1),
+              ('encKVx4 9664x512x512', 9664, 512, 512, 0, 0), ('dec 2880x512x512 +R', 2880, 512, 512, 0, 1),
+              ('dec 2880x512x512 relu', 2880, 512, 512, 1, 0), ('bibtex ffn 5088x1024x512', 5088, 1024, 512, 1, 0),
+              ('delic ffn1 31456x2048x1024', 31456, 2048, 1024, 1, 0), ('delic ffn2 31456x1024x2048', 31456, 1024, 2048, 0, 1),
+              ('delic fc 31456x1024x1024 +R', 31456, 1024, 1024, 0, 1)]
+    print('%-30s' % 'shape (median us)' + ''.join('%26s' % n for n, _ in libs))
+    for name, M, Nn, K, relu, res in shapes:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(Nn, K, device=dev) / K ** 0.5
+        b = torch.randn(Nn, device=dev)
+        r = torch.randn(M, Nn, device=dev)
+        out = torch.empty(M, Nn, device=dev)
+        samples = [[] for _ in libs]
+        for _ in range(rounds):
+            for i, (_, lib) in enumerate(libs):
+                def fn():
+                    N.check(lib.lamp_linear_fwd(x.data_ptr(), M, K, K, w.data_ptr(), Nn, K, b.data_ptr(),
+                                                r.data_ptr() if res else None, Nn, relu, out.data_ptr(), Nn, N.stream()), 'linear')
+                samples[i].append(time_fn(fn, iters=5 if M * Nn * K > 1e11 else 20, warm=2))
+        med = [statistics.median(v) for v in samples]
+        print('%-30s' % name + ''.join('%17.1f/%6.1fT ' % (m, 2.0 * M * Nn * K / m / 1e6) for m in med))
+
+
 def gemm_gen():
     """lamp_gemm (backward-pass GEMM) on the shapes of a reuters training step, every operand layout, next to the
     tuned forward kernel on the same product where it applies."""
@@ -403,5 +433,5 @@ def gemm_trace():
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
-    {'gemm': gemm, 'gemm_ab': gemm_ab, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
+    {'gemm': gemm, 'gemm_ab': gemm_ab, 'lib_ab': lib_ab, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
      'gemm_trace': gemm_trace, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency}[which]()

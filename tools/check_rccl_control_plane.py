@@ -1,26 +1,29 @@
 #!/usr/bin/env python3
-"""The exact torch.distributed calls bench.py makes on its "nccl" (= RCCL) control plane -- init with device_id, barrier
-with device_ids, all_gather of a float64 device tensor -- as a one-rank group, so the code path can be exercised on a
-one-GPU box (RCCL refuses two ranks on one device; the 2-rank tests therefore run on gloo).
+"""bench.py's control plane (bench.ControlPlane: gloo rendezvous, then an "nccl" = RCCL group for the barrier and the
+gathers) as a ONE-rank group, so that the exact calls run on a one-GPU box (RCCL refuses two ranks on one device; the
+2-rank tests therefore run on gloo).
 
     python tools/check_rccl_control_plane.py
 """
-import datetime
 import os
+import sys
 
 import torch
-import torch.distributed as dist
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
 os.environ.setdefault('MASTER_PORT', '29544')
-dev = torch.device('cuda', 0)
+os.environ['LAMP_BENCH_FORCE_DIST'] = '1'
+import bench  # noqa: E402
+
 torch.cuda.set_device(0)
-dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=600))
-dist.barrier(device_ids=[0])
-mine = torch.tensor([0., 0., 1.5, 640.], dtype=torch.float64, device=dev)
-rows = [torch.empty_like(mine)]
-dist.all_gather(rows, mine)
-assert rows[0].cpu().tolist() == [0., 0., 1.5, 640.]
-dist.barrier(device_ids=[0])
-dist.destroy_process_group()
-print('rccl control plane ok')
+cp = bench.ControlPlane(0, 1, torch.device('cuda', 0), 'nccl')
+assert cp.backend == 'nccl', cp.note
+cp.barrier()
+rows = cp.gather(torch.tensor([0., 0., 1.5, 640.], dtype=torch.float64))
+assert len(rows) == 1 and rows[0].tolist() == [0., 0., 1.5, 640.]
+logits = cp.gather(torch.arange(12, dtype=torch.float32, device='cuda').view(3, 4))
+assert logits[0].tolist() == torch.arange(12.).view(3, 4).tolist()
+assert cp.gather_objects(bench.device_identity(0)) == [bench.device_identity(0)] and cp.ranks_in_group() == 1
+cp.close()
+print('rccl control plane ok (%s, device %s)' % (cp.backend, bench.device_identity(0)))

@@ -8,6 +8,7 @@ REPO=$PWD
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+python -c "import bench; print(bench.csrc_fingerprint())" > "$OUT/csrc_fingerprint.txt"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-workloads > "$OUT/bench_driver_style_20steps.json" 2>/dev/null
 for wl in bibtex delicious; do

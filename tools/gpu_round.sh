@@ -29,6 +29,9 @@ for k, v in d.get('workloads', {}).items():
 print('  cpu', d.get('cpu_baseline', {}).get('value'))
 PY
       ;;
+    ragged)
+      timeout 300 python bench.py --ragged --steps 200 --warmup 20 --no-cpu-baseline --no-extra-workloads > "$OUT/bench_ragged.json" 2> "$OUT/bench_ragged.err"; echo "ragged rc=$?"
+      python -c "import json,sys; d=json.load(open(sys.argv[1])); print('ragged value %.0f samples/s  ms/step %.4f  pipelined %s' % (d['value'], d['ms_per_step'], d['pipelined_batches_in_flight'] and round(d['pipelined_batches_in_flight']['value'])))" "$OUT/bench_ragged.json" ;;
     attn) timeout 300 python tools/bench_kernels.py attn 2>&1 | grep -v amdgpu.ids > "$OUT/attn_variants.txt"; grep -E "mode=0" "$OUT/attn_variants.txt" ;;
     trace) timeout 300 python tools/bench_kernels.py gemm_trace 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_trace.txt"; cat "$OUT/gemm_trace.txt" ;;
     tiles) timeout 300 python tools/bench_kernels.py gemm_ab 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles.txt"; cat "$OUT/gemm_tiles.txt" ;;

@@ -12,10 +12,10 @@ import sys
 
 
 def last_forward(rows_by_dispatch):
-    """Dispatch ids of the last complete forward: from its embed_kernel (the first launch of lamp_forward) up to the
+    """Dispatch ids of the last complete forward: from its seq_plan_kernel (the first launch of lamp_forward) up to the
     launch before the next one / the end of the trace."""
     ids = [k for k in rows_by_dispatch if 'lamp::' in rows_by_dispatch[k]['name']]
-    emb = [i for i, k in enumerate(ids) if 'embed_kernel' in rows_by_dispatch[k]['name']]
+    emb = [i for i, k in enumerate(ids) if 'seq_plan_kernel' in rows_by_dispatch[k]['name']]
     return ids[emb[-2]:emb[-1]]
 
 
@@ -28,6 +28,19 @@ def load_pmc(d):
     dur = {r['Dispatch_Id']: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1000.0
            for r in csv.DictReader(open(os.path.join(d, 'p_kernel_trace.csv')))}
     return disp, dur
+
+
+def kernel_only_gemm_us(src, wl):
+    """GEMM kernel time per forward from a rocprofv3 --kernel-trace --stats run of bench.py (no counters): total duration
+    of the gemm_nt_kernel rows / number of forwards (= embed launches)."""
+    path = os.path.join(src, 'stats/p_kernel_stats.csv' if wl == 'reuters' else '../%s_stats_other/kernel_stats_%s.csv' %
+                        (os.path.basename(os.path.normpath(src)), wl))
+    if not os.path.exists(path):
+        return None
+    rows = list(csv.DictReader(open(path)))
+    fwd = sum(int(r['Calls']) for r in rows if 'seq_plan_kernel' in r['Name'])
+    ns = sum(float(r['TotalDurationNs']) for r in rows if 'gemm_nt_kernel' in r['Name'])
+    return ns / fwd / 1e3 if fwd else None
 
 
 def short(name):
@@ -73,6 +86,9 @@ def main():
                                                              d['SQ_WAIT_ANY'] / wc, d['SQ_WAIT_INST_ANY'] / wc))
     open(os.path.join(dst, '%s_mfma_busy.txt' % tag), 'w').write('\n'.join(L) + '\n')
 
+    # fingerprint of the kernel sources the box ran (written there by tools/collect_profiles.sh)
+    fp_path = os.path.join(src, 'csrc_fingerprint.txt')
+    fingerprint = open(fp_path).read().strip() if os.path.exists(fp_path) else None
     traffic = {}
     tables = []
     for wl in ('reuters', 'bibtex', 'delicious'):
@@ -104,6 +120,7 @@ def main():
         tables.append('\n'.join(L))
         traffic[wl] = {'batch': 32, 'gemm_launches': ng, 'gemm_fetch_bytes': gf * 1e6, 'gemm_write_bytes': gw * 1e6,
                        'forward_fetch_bytes': tf * 1e6, 'forward_write_bytes': tw * 1e6,
+                       'csrc_fingerprint': fingerprint, 'gemm_kernel_only_us_per_step': kernel_only_gemm_us(src, wl),
                        'source': 'profiles/%s_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; '
                                  'FETCH_SIZE x2 per the gfx950 calibration of MI355X_MICROARCH.md)' % tag}
     if tables:
