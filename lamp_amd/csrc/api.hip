@@ -106,10 +106,12 @@ struct MhaScratch {
     float *Q, *K, *V, *A;
     float* S = nullptr;    // (h*B, lq, lk) score scratch, only for d_k or d_v > 128 (attention_general.hip)
     float* lse = nullptr;  // [h][B][lq] row log-sum-exp: lets requested attention maps come from the single-pass kernel
-    int* plan_ints = nullptr;  // 3 B + 3 ints: the SeqPlan of a key-token mask when the caller did not bring one
+    int* plan_ints = nullptr;  // plan_int_count(B, lk) ints: the SeqPlan of a key-token mask when the caller did not bring one
 };
-static inline size_t plan_int_count(int64_t B) { return size_t(3) * size_t(B) + 3; }
-static inline SeqPlan plan_from(int* ints, int64_t B) { return SeqPlan{ints, ints + B, ints + 2 * B, ints + 3 * B + 1}; }
+static inline size_t plan_int_count(int64_t B, int T) { return size_t(3) * size_t(B) + 3 + size_t(B) * size_t((T + 31) / 32); }
+static inline SeqPlan plan_from(int* ints, int64_t B, int T) {
+    return SeqPlan{ints, ints + B, ints + 2 * B, ints + 3 * B + 1, reinterpret_cast<unsigned*>(ints + 3 * B + 3), (T + 31) / 32};
+}
 static inline bool wide_heads(int dk, int dv) { return dk > 128 || dv > 128; }
 
 // MultiHeadAttention.forward (lamp/SubLayers.py:77-121).  `xq_shared`: xq is ONE [lq, d] block used
@@ -168,7 +170,7 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     // the module-by-module route takes the same per-sample key split as lamp_forward -- same bits.
     SeqPlan local_plan{};
     if (!keys && mask && mask->kind == LAMP_MASK_KEY_TOKENS_I64 && sc.plan_ints && !wide_heads(dk, dv)) {
-        local_plan = plan_from(sc.plan_ints, B);
+        local_plan = plan_from(sc.plan_ints, B, lk);
         LAMP_CK(launch_seq_plan(static_cast<const int64_t*>(mask->ptr), nullptr, B, lk, mask->stride_b, false, local_plan, s));
         keys = &local_plan;
     }
@@ -194,6 +196,12 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     if (keys && mask && mask->kind == LAMP_MASK_KEY_TOKENS_I64) {
         a.kv_len = keys->klen;
         a.kv_off = keys->off;
+        if (!wide_heads(dk, dv)) {   // the plan's bit-packed copy of the same mask: one word per 32-key tile
+            a.mask_kind = LAMP_MASK_BITS_U32;
+            a.mask = keys->padbits;
+            a.m_sb = keys->words;
+            a.m_sq = 0;
+        }
     }
     LAMP_CK(launch_attn(a, s));
     if (!out) return 0;
@@ -374,7 +382,7 @@ size_t lamp_mha_workspace_bytes(int32_t B, int32_t lq, int32_t lk, int32_t d_mod
     return (mha_ws_floats(B, lq, lk, n_head * d_k, n_head * d_v,
                           wide_heads(d_k, d_v) ? int64_t(n_head) * B * lq * lk : 0) +
             align_up(size_t(n_head) * B * lq * sizeof(float), 256) / sizeof(float) +
-            align_up(plan_int_count(B) * sizeof(int), 256) / sizeof(float)) * sizeof(float);
+            align_up(plan_int_count(B, lk) * sizeof(int), 256) / sizeof(float)) * sizeof(float);
 }
 
 int lamp_mha_fwd(const float* xq, const float* xkv, int32_t B, int32_t lq, int32_t lk, int32_t d_model,
@@ -393,7 +401,7 @@ int lamp_mha_fwd(const float* xq, const float* xkv, int32_t B, int32_t lq, int32
     sc.A = c.take(size_t(B) * lq * hdv);
     if (wide_heads(d_k, d_v)) sc.S = c.take(size_t(w->n_head) * B * lq * lk);
     sc.lse = c.take(size_t(w->n_head) * B * lq);
-    sc.plan_ints = reinterpret_cast<int*>(c.take(plan_int_count(B)));
+    sc.plan_ints = reinterpret_cast<int*>(c.take(plan_int_count(B, lk)));
     if (!c.ok) return LAMP_E_WORKSPACE;
     return mha_core(xq, false, xkv, B, lq, lk, d_model, d_k, d_v, *w, mask, out, attn, sc, hipStream_t(stream));
 }
@@ -542,7 +550,7 @@ static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
     pl->per_sample_floats += pl->lse_floats;
     // ragged batches: the packed token rows of the encoder ([n_tok + 1, d]: + the shared PAD row), one more row of the
     // FFN hidden buffer for it, and the SeqPlan's 3 mb + 3 ints
-    pl->per_sample_floats += size_t(T) * m->d_model + 3;
+    pl->per_sample_floats += size_t(T) * m->d_model + 3 + size_t((T + 31) / 32);
     pl->fixed_floats += size_t(m->d_model) + size_t(m->d_inner) + 64 * 3 + 4;
     // K/V of all decoder layers' enc-attention, projected together right after the encoder when the batch fits
     pl->side_kv_floats = size_t(m->n_layers_dec) * T * (pl->hdk + pl->hdv);
@@ -596,7 +604,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         sc.lse = c.take(size_t(mb) * pl.lse_floats);
         Y = c.take(size_t(mb) * L * d);
         Xp = c.take(size_t(mb) * T * d + d);
-        plan_ints = reinterpret_cast<int*>(c.take(plan_int_count(mb)));
+        plan_ints = reinterpret_cast<int*>(c.take(plan_int_count(mb, T)));
         for (int i = 0; i < n_ahead; ++i) {
             Kahead[i] = c.take(size_t(mb) * T * pl.hdk);
             Vahead[i] = c.take(size_t(mb) * T * pl.hdv);
@@ -612,7 +620,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         const int64_t* pos = src_pos ? src_pos + b0 * T : nullptr;
         float* x = enc_output + b0 * int64_t(T) * d;  // the padded encoder output of this micro-batch
         const int64_t Me = int64_t(nb) * T;
-        const SeqPlan sp = plan_from(plan_ints, nb);
+        const SeqPlan sp = plan_from(plan_ints, nb, T);
         LAMP_CK(launch_seq_plan(seq, m->position_enc ? pos : nullptr, nb, T, T, packed, sp, s));
 
         // ---- GraphEncoder.forward (lamp/Encoders.py:64-110) ----

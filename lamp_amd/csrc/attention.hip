@@ -77,9 +77,10 @@ __global__ __launch_bounds__(256, PM == 0 ? 2 : 1) void attn_kernel(AttnParams p
     const int q_r = int(p.lay.q_r), k_r = int(p.lay.k_r), v_r = int(p.lay.v_r);
     // this sample's keys: all lk, or (ragged batches, AttnParams::kv_len) its own count and its first row in the packed
     // K / V matrices; the descriptors end at the sample's last key (rows past it read as zeros)
-    const int lk_b = p.kv_len ? p.kv_len[b] : p.lk;
-    const int64_t k_row0 = p.kv_len ? int64_t(p.kv_off[b]) * k_r : int64_t(b) * p.lay.k_b;
-    const int64_t v_row0 = p.kv_len ? int64_t(p.kv_off[b]) * v_r : int64_t(b) * p.lay.v_b;
+    const int lk_b = __builtin_amdgcn_readfirstlane(p.kv_len ? p.kv_len[b] : p.lk);   // wave-uniform: keep it scalar
+    const int row0 = __builtin_amdgcn_readfirstlane(p.kv_len ? p.kv_off[b] : 0);
+    const int64_t k_row0 = p.kv_len ? int64_t(row0) * k_r : int64_t(b) * p.lay.k_b;
+    const int64_t v_row0 = p.kv_len ? int64_t(row0) * v_r : int64_t(b) * p.lay.v_b;
     const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(p.Q + int64_t(b) * p.lay.q_b + int64_t(h) * p.lay.q_h,
                                                  (uint64_t(p.lq - 1) * q_r + p.dk) * 4u);
     const __amdgpu_buffer_rsrc_t rsK = make_rsrc(p.K + k_row0 + int64_t(h) * p.lay.k_h,

@@ -108,6 +108,8 @@ struct SeqPlan {
     int* plen;  // [nb]     rows of sample b in the packed matrix (>= klen; T in the padded layout)
     int* off;   // [nb + 1] first packed row of sample b; off[nb] = n_tok
     int* rows;  // [2]      n_tok, and n_tok + 1 when the shared PAD row (row n_tok) is live
+    unsigned* padbits;  // [nb][words] bit-packed key mask: bit j of word j / 32 set = position j holds a PAD token
+    int words;          // (T + 31) / 32
 };
 int launch_seq_plan(const int64_t* seq, const int64_t* pos, int nb, int T, int64_t seq_stride, bool packed,
                     const SeqPlan& sp, hipStream_t s);

@@ -40,8 +40,10 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
 // row-wise encoder (lamp/Encoders.py:64-79), which the packed encoder computes once (row n_tok) instead of per
 // position.  packed: off[b] = sum of plen before b (the sample's first row of the packed matrix); else off[b] = b * T
 // and plen[b] = T (padded layout, only klen is of interest).  rows[0] = off[nb]; rows[1] = off[nb] + 1 when some
-// position is skipped (the shared PAD row is then live), else off[nb].  ONE workgroup: a wave per sample for the scan
-// from the end (64 positions per step), then a wave-level prefix sum.
+// position is skipped (the shared PAD row is then live), else off[nb].  padbits[b][w]: the key mask of sample b, one bit per
+// position (set = PAD token) -- the attention kernels then fetch ONE word per 32-key tile instead of testing 32 int64
+// tokens (LAMP_MASK_BITS_U32 with a zero query stride).  ONE workgroup: a wave per sample (64 positions per step), then
+// a wave-level prefix sum.
 __global__ __launch_bounds__(1024) void seq_plan_kernel(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
                                                         int nb, int T, int64_t seq_stride, int packed, SeqPlan sp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
@@ -49,16 +51,17 @@ __global__ __launch_bounds__(1024) void seq_plan_kernel(const int64_t* __restric
         const int64_t* row = seq + int64_t(b) * seq_stride;
         const int64_t* prow = pos ? pos + int64_t(b) * seq_stride : nullptr;
         int kl = 0, pl = 0;
-        for (int base = ((T - 1) / 64) * 64; base >= 0 && (kl == 0 || (prow && pl == 0)); base -= 64) {
+        for (int base = 0; base < T; base += 64) {   // one pass: 64 positions per step, all loads independent
             const int j = base + lane;
             const bool tok = j < T && row[j] != 0;
             const bool act = tok || (prow && j < T && prow[j] != 0);
             const unsigned long long mt = __ballot(tok), ma = __ballot(act);
-            if (kl == 0 && mt) kl = base + 64 - __builtin_clzll(mt);
-            if (pl == 0 && ma) pl = base + 64 - __builtin_clzll(ma);
-            if (!prow) pl = kl;
+            if (mt) kl = base + 64 - __builtin_clzll(mt);
+            if (ma) pl = base + 64 - __builtin_clzll(ma);
+            // bit-packed key mask of this sample (bit = PAD token = blocked key; positions past T count as PAD)
+            if (lane < 2 && base / 32 + lane < sp.words)
+                sp.padbits[int64_t(b) * sp.words + base / 32 + lane] = ~unsigned(mt >> (32 * lane));
         }
-        if (pl < kl) pl = kl;
         if (lane == 0) {
             sp.klen[b] = kl;
             sp.plen[b] = packed ? pl : T;
@@ -105,11 +108,13 @@ __global__ __launch_bounds__(256) void embed_packed_kernel(const int64_t* __rest
         if (sp.rows[1] == sp.rows[0]) return;   // no position skipped: no PAD row
         dst = sp.rows[0];
     } else {
+        // token, position and plan entries are independent loads: all requested before the first use
         const int b = int(flat / T), j = int(flat - int64_t(b) * T);
-        if (j >= sp.plen[b]) return;
         tok = seq[flat];
         ps = pos_table ? pos[flat] : 0;
-        dst = int64_t(sp.off[b]) + j;
+        const int pl = sp.plen[b], o = sp.off[b];
+        if (j >= pl) return;
+        dst = int64_t(o) + j;
     }
     const bool ok = tok >= 0 && tok < n_vocab && ps >= 0 && (!pos_table || ps < n_position);
     const float4* e = reinterpret_cast<const float4*>(emb + (ok ? tok : 0) * d);
@@ -145,6 +150,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const int* __restrict__ m_dev, SeqPlan sp, int T,
                                                         float* __restrict__ y2) {
     const int lane = threadIdx.x & 63;
+    const int nv = d / 4;
+    float4 v[NV];
+    auto load_row = [&](int64_t r) {
+        const float4* xr = reinterpret_cast<const float4*>(x + r * d);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
     // rows in the XCD-contiguous order of the GEMM that produced x (and of the one that reads y): most of a row's
     // cache lines are then still in THIS XCD's L2 instead of a round trip to the Infinity Cache away
     int64_t row;
@@ -159,24 +174,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     } else if constexpr (RG == 2) {
         flat = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);
         if (flat >= M) return;
+        // speculative: the row a batch without PAD positions would read (packed row == flat position), requested
+        // together with the plan entries instead of after them; a ragged batch re-reads its real row
+        load_row(flat);
         const int b = int(flat / T), j = int(flat - int64_t(b) * T);
         live = j < sp.plen[b];
         row = live ? int64_t(sp.off[b]) + j : int64_t(sp.rows[0]);
         // no position skipped anywhere: packed row == flat position, and the K / V projections read y2 (GemmParams::A_dense)
         if (sp.rows[1] == sp.rows[0]) y = nullptr;
+        if (row != flat) load_row(row);
     } else {
         row = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);
         if (row >= M) return;
     }
-    const float4* xr = reinterpret_cast<const float4*>(x + row * d);
+    if constexpr (RG != 2) load_row(row);
     const float4* rr = res ? reinterpret_cast<const float4*>(res + (r_mod > 0 ? row % r_mod : row) * d) : nullptr;
-    const int nv = d / 4;
-    float4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
-        v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (DROP) v[i] = drop4(v[i], row * d + 4 * c, drop);  // training: dropout on the sub-layer output
         if (rr && c < nv) {
             const float4 w = rr[c];
@@ -332,7 +348,7 @@ int launch_layernorm(const float* x, int64_t M, int d, const float* g, const flo
     const int nv = (d / 4 + 63) / 64;
     const bool dr = drop && drop->threshold > 0;
     const DropoutSpec ds = dr ? *drop : DropoutSpec{0u, 1.f, 0u};
-    const SeqPlan sp = scatter ? *scatter : SeqPlan{nullptr, nullptr, nullptr, nullptr};
+    const SeqPlan sp = scatter ? *scatter : SeqPlan{};
 #define LAMP_LN_LAUNCH(NV_)                                                                                          \
     do {                                                                                                              \
         if (dr)                                                                                                       \
@@ -366,7 +382,8 @@ int launch_layernorm(const float* x, int64_t M, int d, const float* g, const flo
 int launch_seq_plan(const int64_t* seq, const int64_t* pos, int nb, int T, int64_t seq_stride, bool packed,
                     const SeqPlan& sp, hipStream_t s) {
     if (nb <= 0 || T <= 0) return LAMP_E_DIMS;
-    if (!seq || !sp.klen || !sp.plen || !sp.off || !sp.rows) return LAMP_E_NULL;
+    if (!seq || !sp.klen || !sp.plen || !sp.off || !sp.rows || !sp.padbits) return LAMP_E_NULL;
+    if (sp.words != (T + 31) / 32) return LAMP_E_DIMS;
     if (int64_t(nb) * T >= 0x7fffffffLL) return LAMP_E_DIMS;   // packed row indices are 32-bit
     const int threads = nb >= 16 ? 1024 : (nb >= 4 ? 256 : 64);
     hipLaunchKernelGGL(seq_plan_kernel, dim3(1), dim3(threads), 0, s, seq, pos, nb, T, seq_stride, packed ? 1 : 0, sp);
