@@ -13,7 +13,6 @@ import torch.nn as nn
 from . import Constants, utils
 from . import _native as N
 from .Layers import DecoderLayer
-from .SubLayers import _eval_only
 
 
 def build_label_mask(n_tgt_vocab, label_adj_matrix, label_mask):
@@ -72,13 +71,20 @@ class GraphDecoder(nn.Module):
         return N.Mask(N.LAMP_MASK_U8, 0, m.data_ptr(), 0, L, *tl)
 
     def forward(self, tgt, src_seq, enc_output, return_attns=False, int_preds=False):
-        _eval_only(self)
         B = src_seq.size(0)
         T = enc_output.size(1)
-        y = self.tgt_word_emb.weight.unsqueeze(0).expand(B, -1, -1).contiguous()
+        label_mask = self.label_mask_struct()
+        if self.training:
+            # module-by-module training (graph decoder over a vector encoder): the label-table broadcast records autograd
+            # here, the layers dispatch to lamp_amd/training.py; its map-writing attention visits every key tile
+            from . import training
+            y = training._LabelRowsFn.apply(self.tgt_word_emb.weight, B)
+            if label_mask is not None:
+                label_mask = N.Mask(label_mask.kind, 0, label_mask.ptr, label_mask.stride_b, label_mask.stride_q, None, 0)
+        else:
+            y = self.tgt_word_emb.weight.unsqueeze(0).expand(B, -1, -1).contiguous()
         # lamp/Decoders.py:136-138: with a vector encoder there is nothing to pad-mask
         pad_mask, keep = (None, None) if self.enc_vec else N.key_token_mask(src_seq[:, :T], T)
-        label_mask = self.label_mask_struct()
         int_outs, slf_attns, enc_attns = [], [], []
         for layer in self.layer_stack:
             y, y_int, slf_attn, enc_attn = layer(y, enc_output, slf_attn_mask=label_mask,

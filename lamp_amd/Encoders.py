@@ -14,7 +14,6 @@ import torch.nn.functional as F
 from . import Constants, utils
 from . import _native as N
 from .Layers import EncoderLayer
-from .SubLayers import _eval_only
 
 
 class GraphEncoder(nn.Module):
@@ -40,9 +39,16 @@ class GraphEncoder(nn.Module):
             EncoderLayer(d_model, d_inner_hid, n_head, d_k, d_v, dropout=dropout) for _ in range(n_layers))
 
     def forward(self, src_seq, adj, src_pos, return_attns=False):
-        _eval_only(self)
         pos_table = self.position_enc.weight if hasattr(self, 'position_enc') else None
-        x = N.embed(src_seq, src_pos, self.src_word_emb.weight, pos_table)
+        if self.training:
+            # module-by-module training (graph encoder + enc_transform feeding another decoder): the embedding records
+            # autograd here, the layers below dispatch to lamp_amd/training.py by themselves
+            from . import training
+            N.require_device(src_seq)
+            x = training._EmbedFn.apply(src_seq.long().contiguous(), src_pos.long().contiguous(),
+                                        self.src_word_emb.weight, pos_table)
+        else:
+            x = N.embed(src_seq, src_pos, self.src_word_emb.weight, pos_table)
         attns = []
         pad_mask, keep = (N.key_token_mask(src_seq, src_seq.size(1)) if return_attns else (None, None))
         if adj and return_attns:

@@ -7,6 +7,8 @@ self-attention (lamp/Layers.py:16-18) is simply not computed unless its maps are
 """
 import ctypes as C
 
+import collections
+
 import torch
 import torch.nn as nn
 
@@ -107,7 +109,12 @@ class LAMP(nn.Module):
         """nn.Module.load_state_dict; additionally accepts checkpoints saved from an nn.DataParallel wrapper
         (main.py:106-108 wraps the model BEFORE utils.save_model, so multi-GPU hosts write ``module.``-prefixed keys)."""
         if state_dict and all(k.startswith('module.') for k in state_dict):
-            state_dict = type(state_dict)((k[len('module.'):], v) for k, v in state_dict.items())
+            stripped = collections.OrderedDict((k[len('module.'):], v) for k, v in state_dict.items())
+            meta = getattr(state_dict, '_metadata', None)
+            if meta is not None:   # per-module version records, keyed by module path
+                stripped._metadata = collections.OrderedDict(
+                    (k[len('module.'):] if k.startswith('module.') else ('' if k == 'module' else k), v) for k, v in meta.items())
+            state_dict = stripped
         self.invalidate_native_cache()
         return super().load_state_dict(state_dict, *args, **kwargs)
 
@@ -221,14 +228,22 @@ class LAMP(nn.Module):
         else:
             w = self.tgt_word_proj.linear.weight
             if self.decoder_type == 'graph' and w.size(0) == dec_output.size(1) and self.tgt_word_proj.linear.bias is None:
-                seq_logit = N.diag_logits(dec_output, w)   # diag(y W^T) without the (B, L, L) product
+                if self.training:
+                    from . import training
+                    seq_logit = training._ReadoutFn.apply(dec_output, w)
+                else:
+                    seq_logit = N.diag_logits(dec_output, w)   # diag(y W^T) without the (B, L, L) product
             else:
                 seq_logit = self.tgt_word_proj(dec_output)
                 if self.decoder_type == 'graph':
                     seq_logit = torch.diagonal(seq_logit, 0, 1, 2)
         if int_preds:
             w = self.tgt_word_proj.linear.weight.detach()
-            preds = [N.diag_logits(o, w) for o in dec_output2[0][:-1]]
+            if self.training:
+                from . import training
+                preds = [training._ReadoutFn.apply(o, w) for o in dec_output2[0][:-1]]
+            else:
+                preds = [N.diag_logits(o, w) for o in dec_output2[0][:-1]]
             return seq_logit.reshape(-1, seq_logit.size(-1)), enc_output, preds
         if return_attns:
             return seq_logit.reshape(-1, seq_logit.size(-1)), enc_output, enc_self_attns, dec_output2

@@ -6,21 +6,14 @@ arithmetic in PyTorch: every op goes through the C ABI of liblamp_hip.so (lamp_a
 
 Scope: a HIP device; a CPU tensor raises -- there is no fallback.  ``module.eval()`` is the fused inference
 path.  In training mode MultiHeadAttention and PositionwiseFeedForward (and LAMP.forward as a whole) run the
-autograd-recording path of lamp_amd/training.py, whose backward is HIP kernels as well; the
-bare XavierLinear / ScaledDotProductAttention wrappers stay eval-only.
+autograd-recording path of lamp_amd/training.py, whose backward is HIP kernels as well; so do the
+bare XavierLinear / ScaledDotProductAttention wrappers when called on their own.
 """
 import numpy as np
 import torch
 import torch.nn as nn
 
 from . import _native as N
-
-
-def _eval_only(module):
-    if module.training:
-        raise NotImplementedError(
-            '%s: only the eval-mode forward of this wrapper is implemented (call .eval()); training runs through '
-            'MultiHeadAttention / PositionwiseFeedForward / LAMP.forward (lamp_amd/training.py).' % type(module).__name__)
 
 
 class XavierLinear(nn.Module):
@@ -33,7 +26,9 @@ class XavierLinear(nn.Module):
         nn.init.xavier_normal_(self.linear.weight)
 
     def forward(self, x):
-        _eval_only(self)
+        if self.training:
+            from . import training
+            return training.linear_train(self, x)
         return N.linear(x, self.linear.weight, self.linear.bias)
 
 
@@ -55,7 +50,9 @@ class ScaledDotProductAttention(nn.Module):
         self.need_attn = True
 
     def forward(self, q, k, v, attn_mask=None, stop_sig=False):
-        _eval_only(self)
+        if self.training:
+            from . import training
+            return training.sdpa_train(self, q, k, v, attn_mask)
         return N.sdpa(q, k, v, attn_mask, 1.0 / float(self.temperature), need_attn=self.need_attn)
 
 
@@ -95,17 +92,26 @@ class MultiHeadAttention(nn.Module):
         lk = k.size(1)
         mstruct, keep = self._mask_struct(attn_mask, B, lq, lk)
         same_kv = (k is v) or (k.data_ptr() == v.data_ptr() and k.shape == v.shape and k.stride() == v.stride())
-        if same_kv and self.training:
+        if self.training:
             from . import training
-            N.require_device(q, k)
-            return training.mha_train(self, q, k, mstruct, keep, training._Seeds())
+            N.require_device(q, k, v)
+            return training.mha_train(self, q, k, mstruct, keep, training._Seeds(), xv=None if same_kv else v)
         if same_kv:
             out, attn = N.mha(q, k, N.mha_weights(self), self.d_k, self.d_v, mstruct, self.need_attn)
             del keep
             return out, attn
-        # The reference's own layers always pass the same tensor as key and value source
-        # (lamp/Layers.py:16,35,40); distinct sources have no kernel here.
-        raise NotImplementedError('MultiHeadAttention with distinct key and value sources is not on the path')
+        # Distinct key and value sources (lamp/SubLayers.py:77-93 projects them independently; no layer of the reference
+        # does this, lamp/Layers.py:16,35,40): the same kernels, launched piecewise through the C ABI -- three
+        # projections, the fused-layout attention, output projection + residual, LayerNorm.
+        N.require_device(q, k, v)
+        H = self.n_head
+        a, attn = N.sdpa_fused(N.linear(q, self.w_qs.weight), N.linear(k, self.w_ks.weight), N.linear(v, self.w_vs.weight),
+                               H, mstruct, 1.0 / float(self.d_k) ** 0.5, need_attn=self.need_attn)
+        del keep
+        if H > 1:
+            o = N.linear(a, self.fc.weight, residual=q)
+            return N.layernorm(o, self.layer_norm.weight, self.layer_norm.bias).view(q.shape), attn
+        return N.layernorm_residual(a, q, self.layer_norm.weight, self.layer_norm.bias).view(q.shape), attn
 
 
 class PositionwiseFeedForward(nn.Module):

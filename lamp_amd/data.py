@@ -91,7 +91,11 @@ class EvalBatcher(object):
         return len(self._src_insts)
 
     def __iter__(self):
-        for b in range(self._n_batch):
+        return self.iter_range(0, self._n_batch)
+
+    def iter_range(self, b_lo, b_hi):
+        """Batches b_lo .. b_hi - 1 only: a rank of a sharded evaluation materialises (pads, uploads) just its own share."""
+        for b in range(max(b_lo, 0), min(b_hi, self._n_batch)):
             lo, hi = b * self._batch_size, (b + 1) * self._batch_size
             src_seq, src_pos = pad_to_longest(self._src_insts[lo:hi])
             tgt = None

@@ -42,7 +42,10 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
     bce_total = 0.0
     lanes = [torch.cuda.Stream(device=device) for _ in range(streams)] if streams > 1 else [None]
     b_lo, b_hi = sharding.shard_bounds(len(batches), world_size, rank) if world_size > 1 else (0, len(batches))
-    it = iter((bi, b) for bi, b in enumerate(batches) if b_lo <= bi < b_hi)
+    if hasattr(batches, 'iter_range'):   # EvalBatcher: only this rank's batches are padded and uploaded at all
+        it = zip(range(b_lo, b_hi), batches.iter_range(b_lo, b_hi))
+    else:
+        it = iter((bi, b) for bi, b in enumerate(batches) if b_lo <= bi < b_hi)
     while True:
         host = []
         for bi, ((src_seq, src_pos), adj, tgt) in itertools.islice(it, prefetch):

@@ -97,14 +97,17 @@ class _MHAFn(torch.autograd.Function):
     """LayerNorm(dropout(concat_heads(dropout(softmax(mask(q k^T / t))) v) Wfc^T) + xq)   (lamp/SubLayers.py:77-121)."""
 
     @staticmethod
-    def forward(ctx, xq, xkv, wq, wk, wv, fc, ln_g, ln_b, n_head, mask, keep, p_attn, p_out, seed_attn, seed_out):
+    def forward(ctx, xq, xkv, wq, wk, wv, fc, ln_g, ln_b, n_head, mask, keep, p_attn, p_out, seed_attn, seed_out,
+                xv=None):
+        """xkv: the key source and, unless ``xv`` is given, the value source too (every layer of the reference passes one
+        tensor for both, lamp/Layers.py:16,35,40; the module itself accepts two, lamp/SubLayers.py:77-93)."""
         B, lq, d = xq.shape
         lk = xkv.size(1)
         H = n_head
         dk, dv = wq.size(0) // H, wv.size(0) // H
         q = N.linear(xq, wq)
         k = N.linear(xkv, wk)
-        v = N.linear(xkv, wv)
+        v = N.linear(xkv if xv is None else xv, wv)
         inv_t = 1.0 / float(dk) ** 0.5
         a, P = N.sdpa_fused(q, k, v, H, mask, inv_t, need_attn=True, fast_maps=True)
         Pd = P
@@ -114,18 +117,20 @@ class _MHAFn(torch.autograd.Function):
                         out=a.view(B, lq, H, dv).permute(2, 0, 1, 3))
         o = N.linear(a, fc) if fc is not None else a
         y = N.layernorm_residual(o, xq, ln_g, ln_b, dropout_p=p_out, seed=seed_out)
-        ctx.save_for_backward(xq, xkv, wq, wk, wv, fc if fc is not None else wq.new_empty(0), ln_g, q, k, v, a, P, o)
-        ctx.cfg = (B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, fc is not None)
+        ctx.save_for_backward(xq, xkv, wq, wk, wv, fc if fc is not None else wq.new_empty(0), ln_g, q, k, v, a, P, o,
+                              xv if xv is not None else wq.new_empty(0))
+        ctx.cfg = (B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, fc is not None, xv is not None)
         attn = Pd if p_attn > 0 else P.clone()  # what the reference returns (lamp/SubLayers.py:40-43): the dropped map
         ctx.mark_non_differentiable(attn)
         return y, attn
 
     @staticmethod
     def backward(ctx, dy, _dP_unused):
-        xq, xkv, wq, wk, wv, fc, ln_g, q, k, v, a, P, o = ctx.saved_tensors
-        B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, has_fc = ctx.cfg
+        xq, xkv, wq, wk, wv, fc, ln_g, q, k, v, a, P, o, xv = ctx.saved_tensors
+        B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, has_fc, has_xv = ctx.cfg
         d = xq.size(-1)
         xq2, xkv2 = xq.reshape(-1, d), xkv.reshape(-1, d)
+        xv2 = xv.reshape(-1, d) if has_xv else xkv2
         dz, do, dg, db, _ = N.layernorm_bwd(o.view(xq2.shape), xq2, ln_g, dy.reshape(xq2.shape), dropout_p=p_out,
                                             seed=seed_out)
         a2 = a.view(-1, H * dv)
@@ -150,11 +155,15 @@ class _MHAFn(torch.autograd.Function):
         dq2, dk2, dv2 = dq_buf.view(-1, H * dk), dk_buf.view(-1, H * dk), dv_buf.view(-1, H * dv)
         dwq = N.matmul_nt(dq2.t(), xq2.t())
         dwk = N.matmul_nt(dk2.t(), xkv2.t())
-        dwv = N.matmul_nt(dv2.t(), xkv2.t())
+        dwv = N.matmul_nt(dv2.t(), xv2.t())
         dxq = N.matmul_nt(dq2, wq.t(), out=dz, accumulate=True)  # + the residual branch
         dxkv = N.matmul_nt(dk2, wk.t())
-        N.matmul_nt(dv2, wv.t(), out=dxkv, accumulate=True)
-        return (dxq.view(xq.shape), dxkv.view(xkv.shape), dwq, dwk, dwv, dfc, dg, db) + (None,) * 7
+        dxv = None
+        if has_xv:
+            dxv = N.matmul_nt(dv2, wv.t()).view(xv.shape)
+        else:
+            N.matmul_nt(dv2, wv.t(), out=dxkv, accumulate=True)
+        return (dxq.view(xq.shape), dxkv.view(xkv.shape), dwq, dwk, dwv, dfc, dg, db) + (None,) * 7 + (dxv,)
 
 
 class _ReadoutFn(torch.autograd.Function):
@@ -176,11 +185,74 @@ def ffn_train(mod, x, seeds):
                         mod.layer_norm.bias, float(mod.dropout.p), seeds.next())
 
 
-def mha_train(mod, xq, xkv, mask, keep, seeds):
+def mha_train(mod, xq, xkv, mask, keep, seeds, xv=None):
     fc = mod.fc.weight if hasattr(mod, 'fc') else None
     return _MHAFn.apply(xq, xkv, mod.w_qs.weight, mod.w_ks.weight, mod.w_vs.weight, fc, mod.layer_norm.weight,
                         mod.layer_norm.bias, mod.n_head, mask, keep, float(mod.attention.dropout.p),
-                        float(mod.dropout.p), seeds.next(), seeds.next())
+                        float(mod.dropout.p), seeds.next(), seeds.next(), xv)
+
+
+class _LinearFn(torch.autograd.Function):
+    """XavierLinear on its own (lamp/SubLayers.py:7-13): y = x W^T + b."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return N.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        x2, dy2 = x.reshape(-1, x.size(-1)), dy.reshape(-1, dy.size(-1)).contiguous()
+        dx = N.matmul_nt(dy2, w.t()).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = N.matmul_nt(dy2.t(), x2.t()) if ctx.needs_input_grad[1] else None
+        db = N.colsum(dy2) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear_train(mod, x):
+    N.require_device(x)
+    return _LinearFn.apply(x, mod.linear.weight, mod.linear.bias)
+
+
+class _SDPAFn(torch.autograd.Function):
+    """ScaledDotProductAttention on its own (lamp/SubLayers.py:27-43) on head-major batches q (n, lq, dk), k (n, lk, dk),
+    v (n, lk, dv): out = dropout(softmax(mask(q k^T / t))) v; returns (out, the dropped map) like the reference."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, inv_t, p, seed):
+        out, P = N.sdpa(q, k, v, mask, inv_t, need_attn=True)
+        Pd = P
+        if p > 0:
+            Pd = N.dropout(P, p, seed)
+            out = N.matmul_nt(Pd, v.transpose(-1, -2))
+        ctx.save_for_backward(q, k, v, P)
+        ctx.cfg = (inv_t, p, seed)
+        attn = Pd if p > 0 else P.clone()
+        ctx.mark_non_differentiable(attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, do, _dattn_unused):
+        q, k, v, P = ctx.saved_tensors
+        inv_t, p, seed = ctx.cfg
+        do = do.contiguous()
+        Pd = N.dropout(P, p, seed) if p > 0 else P
+        dv = N.matmul_nt(Pd.transpose(-1, -2), do.transpose(-1, -2))    # dV = Pd^T dO
+        dP = N.matmul_nt(do, v)                                         # dPd = dO V^T
+        if p > 0:
+            N.dropout(dP, p, seed, out=dP)
+        N.softmax_bwd(P, dP, inv_t, out=dP)                             # dS (in place)
+        dq = N.matmul_nt(dP, k.transpose(-1, -2))                       # dQ = dS K
+        dk = N.matmul_nt(dP.transpose(-1, -2), q.transpose(-1, -2))     # dK = dS^T Q
+        return dq, dk, dv, None, None, None, None
+
+
+def sdpa_train(mod, q, k, v, attn_mask):
+    N.require_device(q, k, v)
+    seed = _Seeds().next()
+    return _SDPAFn.apply(q, k, v, attn_mask, 1.0 / float(mod.temperature), float(mod.dropout.p), seed)
 
 
 def forward_train(model, src_seq, src_pos, return_attns=False, int_preds=False):

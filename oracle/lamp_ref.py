@@ -113,8 +113,9 @@ def sdpa(q, k, v, blocked=None, temperature=None):
     return torch.bmm(attn, v), attn
 
 
-def mha(xq, xkv, blocked, wq, wk, wv, wfc, g, b, n_head, as_written=False):
-    """lamp/SubLayers.py:77-121.
+def mha(xq, xkv, blocked, wq, wk, wv, wfc, g, b, n_head, as_written=False, xv=None):
+    """lamp/SubLayers.py:77-121.  ``xv``: a value source distinct from the key source xkv (the module projects k and v
+    independently, lamp/SubLayers.py:91-93; every layer of the reference passes the same tensor for both).
 
     xq (B, lq, d), xkv (B, lk, d); blocked broadcastable to (B, lq, lk) bool or
     None; wq/wk (h*dk, d), wv (h*dv, d), wfc (d, h*dv) or None when h == 1.
@@ -128,7 +129,7 @@ def mha(xq, xkv, blocked, wq, wk, wv, wfc, g, b, n_head, as_written=False):
     dv = wv.size(0) // n_head
     q = F.linear(xq, wq).view(B, lq, n_head, dk)
     k = F.linear(xkv, wk).view(B, lk, n_head, dk)
-    v = F.linear(xkv, wv).view(B, lk, n_head, dv)
+    v = F.linear(xkv if xv is None else xv, wv).view(B, lk, n_head, dv)
     q = q.permute(2, 0, 1, 3).contiguous().view(-1, lq, dk)
     k = k.permute(2, 0, 1, 3).contiguous().view(-1, lk, dk)
     v = v.permute(2, 0, 1, 3).contiguous().view(-1, lk, dv)

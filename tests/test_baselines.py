@@ -187,3 +187,50 @@ def test_rnn_baseline_runs_on_the_device():
     t, _ = load_golden('baseline_translate')
     assert max_abs_diff(logits, d['logits']) < 1e-4
     assert hyp[0][0] == [v for v in t['hyp'][0, 0].tolist() if v >= 0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,dec,et,mask', [('baseline_graph_mean_mlp', 'mlp', 'mean', 'none'),
+                                               ('baseline_graph_mean_graph', 'graph', 'mean', 'prior')])
+def test_composite_graph_models_train_through_the_hip_path(name, dec, et, mask):
+    """The model combinations outside the fused launcher (graph encoder pooled by enc_transform, feeding the mlp or the
+    graph decoder) record autograd module by module in train(): logits equal the eval forward, and the gradient agrees
+    with a central finite difference of the EVAL-mode loss (a different code path: the inference kernels) along a
+    random direction over all parameters."""
+    d, sd = load_golden(name)
+    dev = torch.device('cuda:0')
+    m = _model(d, sd, 'graph', dec, enc_transform=et, label_mask=mask).to(dev)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    src = (d['src_seq'].to(dev), d['src_pos'].to(dev))
+    tgt = (torch.rand(d['logits'].shape, generator=torch.Generator().manual_seed(1)) < 0.3).float().to(dev)
+    loss_fn = torch.nn.functional.binary_cross_entropy_with_logits
+
+    def eval_loss():
+        m.eval()
+        with torch.no_grad():
+            return loss_fn(m(src, None, None, None)[0].double(), tgt.double()).item()
+
+    base = eval_loss()
+    m.train()
+    logits = m(src, None, None, tgt)[0]
+    assert logits.requires_grad and abs(loss_fn(logits.double(), tgt.double()).item() - base) < 1e-6
+    loss_fn(logits, tgt).backward()
+    params = [p for p in m.get_trainable_parameters() if p.grad is not None]
+    assert len(params) > 8
+    g = torch.Generator().manual_seed(2)
+    dirs = [torch.randn(p.shape, generator=g).to(dev) * (p.grad.abs() > 0).float() for p in params]
+    analytic = sum((p.grad.double() * u.double()).sum().item() for p, u in zip(params, dirs))
+    eps = 1e-2 / max(1e-12, sum((u.double() ** 2).sum().item() for u in dirs) ** 0.5)
+    with torch.no_grad():
+        for p, u in zip(params, dirs):
+            p.add_(eps * u)
+        m.invalidate_native_cache()
+        up = eval_loss()
+        for p, u in zip(params, dirs):
+            p.sub_(2 * eps * u)
+        m.invalidate_native_cache()
+        down = eval_loss()
+    numeric = (up - down) / (2 * eps)
+    assert abs(numeric - analytic) < 3e-2 * max(abs(analytic), 1e-3), (numeric, analytic)

@@ -291,3 +291,75 @@ def test_gradients_with_wide_heads(dev):
             continue
         ref = sd64[pname].grad
         assert max_abs_diff(p.grad, ref) <= 3e-4 * ref.abs().max().item() + 1e-9, pname
+
+
+@pytest.mark.parametrize('H', [1, 4])
+def test_mha_with_distinct_key_and_value_sources(dev, H):
+    """lamp/SubLayers.py:77-93 projects k and v independently; no layer of the reference passes different tensors, the
+    module surface allows it.  Eval forward and every training gradient against the fp64 oracle."""
+    from lamp_amd.SubLayers import MultiHeadAttention
+    g = torch.Generator().manual_seed(7 + H)
+    B, lq, lk, d = 3, 21, 34, 64
+    mod = MultiHeadAttention(H, d, d // H, d // H, dropout=0.0).to(dev)
+    xq, xk, xv = (torch.randn(B, l, d, generator=g) for l in (lq, lk, lk))
+    mask = torch.rand(B, lq, lk, generator=g) < 0.3
+    mask[:, :, 0] = False
+    w = {k: v.detach().cpu().double().requires_grad_() for k, v in mod.state_dict().items()}
+    xq64, xk64, xv64 = (t.double().requires_grad_() for t in (xq, xk, xv))
+    ref, ref_attn = R.mha(xq64, xk64, mask, w['w_qs.weight'], w['w_ks.weight'], w['w_vs.weight'], w.get('fc.weight'),
+                          w['layer_norm.weight'], w['layer_norm.bias'], H, xv=xv64)
+    mod.eval()
+    out, attn = mod(xq.to(dev), xk.to(dev), xv.to(dev), attn_mask=mask.to(dev))
+    assert max_abs_diff(out, ref.detach()) < 2e-5 and max_abs_diff(attn, ref_attn.detach()) < 5e-6
+    mod.train()
+    xs = [t.to(dev).requires_grad_() for t in (xq, xk, xv)]
+    out_t, _ = mod(*xs, attn_mask=mask.to(dev))
+    assert max_abs_diff(out_t, ref.detach()) < 2e-5
+    dy = torch.randn(B, lq, d, generator=g)
+    out_t.backward(dy.to(dev))
+    ref.backward(dy.double())
+    for got, want in zip(xs, (xq64, xk64, xv64)):
+        assert max_abs_diff(got.grad, want.grad) < 3e-4 * max(1.0, want.grad.abs().max().item())
+    for n, p in mod.named_parameters():
+        assert max_abs_diff(p.grad, w[n].grad) < 3e-4 * max(1.0, w[n].grad.abs().max().item()), n
+
+
+def test_bare_wrappers_record_autograd_in_training_mode(dev):
+    """XavierLinear and ScaledDotProductAttention called on their own in train() (lamp/SubLayers.py:7-43 are plain
+    autograd modules in the reference): forward and gradients against fp64 torch."""
+    from lamp_amd.SubLayers import ScaledDotProductAttention, XavierLinear
+    g = torch.Generator().manual_seed(11)
+    lin = XavierLinear(48, 30).to(dev).train()
+    x = torch.randn(5, 9, 48, generator=g)
+    xd = x.to(dev).requires_grad_()
+    y = lin(xd)
+    dy = torch.randn(5, 9, 30, generator=g)
+    y.backward(dy.to(dev))
+    w64, b64, x64 = (t.detach().cpu().double().requires_grad_() for t in (lin.linear.weight, lin.linear.bias, x))
+    ref = F.linear(x64, w64, b64)
+    ref.backward(dy.double())
+    assert max_abs_diff(y, ref.detach()) < 2e-5 and max_abs_diff(xd.grad, x64.grad) < 1e-4
+    assert max_abs_diff(lin.linear.weight.grad, w64.grad) < 1e-4 and max_abs_diff(lin.linear.bias.grad, b64.grad) < 1e-4
+
+    att = ScaledDotProductAttention(temperature=8.0, dropout=0.0).to(dev).train()
+    n, lq, lk, dk = 6, 17, 29, 64
+    q, k, v = (torch.randn(n, l, dk, generator=g) for l in (lq, lk, lk))
+    mask = torch.rand(n, lq, lk, generator=g) < 0.25
+    mask[:, :, 0] = False
+    qd, kd, vd = (t.to(dev).requires_grad_() for t in (q, k, v))
+    out, attn = att(qd, kd, vd, attn_mask=mask.to(dev))
+    do = torch.randn(n, lq, dk, generator=g)
+    out.backward(do.to(dev))
+    q64, k64, v64 = (t.double().requires_grad_() for t in (q, k, v))
+    ref_o, ref_a = R.sdpa(q64, k64, v64, mask, 8.0)
+    ref_o.backward(do.double())
+    assert max_abs_diff(out, ref_o.detach()) < 2e-5 and max_abs_diff(attn, ref_a.detach()) < 5e-6
+    for got, want in ((qd, q64), (kd, k64), (vd, v64)):
+        assert max_abs_diff(got.grad, want.grad) < 1e-4
+    # attention dropout: the returned map is the dropped one, and the output is its product with v
+    att_p = ScaledDotProductAttention(temperature=8.0, dropout=0.3).to(dev).train()
+    torch.manual_seed(5)
+    out_p, attn_p = att_p(q.to(dev), k.to(dev), v.to(dev), attn_mask=mask.to(dev))
+    assert max_abs_diff(out_p, attn_p.double().cpu() @ v.double()) < 2e-5
+    kept = attn_p != 0
+    assert 0.6 < kept.float().mean().item() / (ref_a > 0).float().mean().item() < 0.8

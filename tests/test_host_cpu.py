@@ -154,8 +154,10 @@ def test_product_has_no_cpu_path():
         m((d['src_seq'], d['src_pos']), None, None, None)
     with pytest.raises(RuntimeError, match='HIP device only'):
         m.encoder.layer_stack[0].pos_ffn(torch.zeros(1, 2, 64))
-    with pytest.raises(NotImplementedError, match='eval-mode'):
+    with pytest.raises(RuntimeError, match='HIP device only'):   # the bare wrappers record autograd on the device too
         m.tgt_word_proj(torch.zeros(1, 2, 64))
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        m.decoder.layer_stack[0].enc_attn.attention(torch.zeros(1, 2, 16), torch.zeros(1, 3, 16), torch.zeros(1, 3, 16))
 
 
 def test_out_of_scope_branches_raise_at_construction():
