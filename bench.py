@@ -276,90 +276,6 @@ def measure(N, name, w, batch, steps, warmup, device, rank, sync, lengths=None, 
                 device_warmup_steps=warm_n, graph=g)
 
 
-class ControlPlane:
-    """torch.distributed as a CONTROL plane only (the forward has no collective): barrier around the timed region, the
-    gather of per-rank reports, and the gather of a few logits for the cross-rank bitwise check.
-
-    The rendezvous and the default group are gloo (CPU, cannot fail on GPU topology); the barrier and the gathers run on a
-    "nccl" (= RCCL over xGMI on ROCm) group when it works -- first use is probed with one all_reduce, and every rank
-    agrees on the outcome through gloo -- so a node where RCCL cannot initialise still produces a line, with
-    `backend: "gloo"` and the reason in `config.backend_note`.  LAMP_BENCH_BACKEND=gloo skips RCCL (two ranks sharing
-    the one GPU of a test box)."""
-
-    def __init__(self, rank, world, device, want):
-        self.rank, self.world, self.device = rank, world, device
-        self.backend, self.note, self.group, self.dist = None, None, None, None
-        if world == 1 and not os.environ.get('LAMP_BENCH_FORCE_DIST'):   # the variable: tools/check_rccl_control_plane.py
-            return
-        import datetime
-        import torch.distributed as dist
-        self.dist = dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
-        self.backend = 'gloo'
-        if want != 'nccl':
-            return
-        ok, note = 1, None
-        try:
-            self.group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=300))
-            t = torch.ones(1, device=device)
-            dist.all_reduce(t, group=self.group)
-            torch.cuda.synchronize()
-            ok = int(t.item() == world)
-            if not ok:
-                note = 'RCCL all_reduce over %d ranks returned %r' % (world, t.item())
-        except Exception as e:  # noqa: BLE001 -- whatever RCCL raises here, the bench falls back to gloo and says so
-            ok, note = 0, '%s: %s' % (type(e).__name__, e)
-        flag = torch.tensor([ok], dtype=torch.int64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        notes = [None] * world
-        dist.all_gather_object(notes, note)
-        if int(flag.item()) == 1:
-            self.backend = 'nccl'
-        else:
-            self.group = None
-            self.note = 'nccl (RCCL) control plane unavailable, gloo used: ' + '; '.join(
-                'rank %d: %s' % (r, n) for r, n in enumerate(notes) if n)
-
-    @property
-    def nccl(self):
-        return self.backend == 'nccl'
-
-    def barrier(self):
-        if self.dist is None:
-            return
-        if self.nccl:
-            self.dist.barrier(group=self.group, device_ids=[self.device.index])
-        else:
-            self.dist.barrier()
-
-    def ranks_in_group(self):
-        if self.dist is None:
-            return 1
-        return self.dist.get_world_size(group=self.group) if self.nccl else self.dist.get_world_size()
-
-    def gather(self, t):
-        """All ranks' copies of tensor `t` (same shape and dtype everywhere), as CPU tensors, rank order."""
-        if self.dist is None:
-            return [t.detach().cpu()]
-        src = t.detach().to(self.device if self.nccl else 'cpu').contiguous()
-        out = [torch.empty_like(src) for _ in range(self.world)]
-        self.dist.all_gather(out, src, group=self.group if self.nccl else None)
-        return [o.cpu() for o in out]
-
-    def gather_objects(self, obj):
-        if self.dist is None:
-            return [obj]
-        out = [None] * self.world
-        self.dist.all_gather_object(out, obj)
-        return out
-
-    def close(self):
-        if self.dist is not None:
-            self.barrier()
-            self.dist.destroy_process_group()
-
-
 def device_identity(index):
     """A string that is the same for two ranks iff they sit on the same physical GPU, whatever HIP_VISIBLE_DEVICES says."""
     p = torch.cuda.get_device_properties(index)
@@ -456,6 +372,7 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     # "nccl" is RCCL on ROCm.  LAMP_BENCH_BACKEND=gloo lets two ranks share one GPU to smoke-test this path.
+    from lamp_amd.sharding import ControlPlane
     cp = ControlPlane(rank, world, device, os.environ.get('LAMP_BENCH_BACKEND', 'nccl'))
     if world != args.gpus and rank == 0:
         print('error: --gpus %d but %d rank(s) were launched' % (args.gpus, world), file=sys.stderr)

@@ -24,13 +24,35 @@
 namespace lamp {
 
 namespace {
-__device__ __forceinline__ float group_max(float v) {  // max over the 4 lane groups (lanes l, l^16, l^32, l^48)
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
+// Exchange across the four lane groups of a query (lanes l, l^16, l^32, l^48) with gfx950's row-swap instructions instead
+// of __shfl_xor (= ds_bpermute through the LDS crossbar, ~100 cycles a step):
+//   v_permlane16_swap a, b  swaps the odd 16-lane rows of a with the even rows of b;  v_permlane32_swap a, b swaps the
+//   upper half of a with the lower half of b.  Starting from a = b = v, a and b then hold the two partners of every lane.
+// (Inline asm: the builtins return their second result equal to the first in hipcc 7.2 -- DESIGN.md 4.4.  Only used in
+// the rescale branch and after the key loop, where the scheduling barrier an asm statement implies costs nothing.)
+// The s_nop pairs: hipcc cannot see inside an asm statement, so the wait states it would insert between a VALU write and
+// a permlane swap reading it (and between the swap and its consumers) are spelled out.
+__device__ __forceinline__ void swap16(float& a, float& b) {
+    asm volatile("s_nop 3\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
 }
-__device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    asm volatile("s_nop 3\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float group_max(float v) {  // max over the 4 lane groups
+    float a = v, b = v;
+    swap16(a, b);
+    a = fmaxf(a, b);
+    b = a;
+    swap32(a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float group_sum(float v) {  // (v[l] + v[l^16]) + (v[l^32] + v[l^48]), the pairing of the xor butterfly
+    float a = v, b = v;
+    swap16(a, b);
+    a = a + b;
+    b = a;
+    swap32(a, b);
+    return a + b;
 }
 }  // namespace
 

@@ -120,13 +120,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
         pan0 = 0;
         pan1 = tiles_m;
     }
-    const int group_sz = GROUP_M * tiles_n;
-    const int grp = item / group_sz;
-    const int in_grp = item - grp * group_sz;
-    const int first_m = pan0 + grp * GROUP_M;
-    const int gm = pan1 - first_m < GROUP_M ? pan1 - first_m : GROUP_M;
-    const int tn_all = in_grp / gm;
-    const int tm = first_m + (in_grp - tn_all * gm);
+    int tn_all, tm;
+    if (p.walk_gn > 0) {
+        // (4) W-resident walk, for weight matrices that crowd the 4 MiB L2 on their own (delicious' 8 MB FFN weights):
+        // groups of walk_gn COLUMN panels (~2 MiB of W), and inside a group row-panel by row-panel -- the group's W
+        // stays in the L2 while the XCD's A panels stream past it once per group, instead of every group of 8 row-panels
+        // re-fetching all of W and, with A + W over 4 MiB in flight, its own A panels once per column step
+        // (profiles/r02_hbm_traffic.txt: 1231 MB fetched for 137 MB of operands).  Placement only, as above.
+        const int rows = pan1 - pan0;
+        const int group_sz = rows * p.walk_gn;
+        const int grp = item / group_sz;
+        const int in_grp = item - grp * group_sz;
+        const int first_n = grp * p.walk_gn;
+        const int gn = tiles_n - first_n < p.walk_gn ? tiles_n - first_n : p.walk_gn;
+        const int tml = in_grp / gn;
+        tm = pan0 + tml;
+        tn_all = first_n + (in_grp - tml * gn);
+    } else {
+        const int group_sz = GROUP_M * tiles_n;
+        const int grp = item / group_sz;
+        const int in_grp = item - grp * group_sz;
+        const int first_m = pan0 + grp * GROUP_M;
+        const int gm = pan1 - first_m < GROUP_M ? pan1 - first_m : GROUP_M;
+        tn_all = in_grp / gm;
+        tm = first_m + (in_grp - tn_all * gm);
+    }
     const int seg = tn_all / tiles_n_seg;
     const int tn = tn_all - seg * tiles_n_seg;
     const int64_t m0 = int64_t(tm) * BM;
@@ -353,6 +371,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
 }
 
 #ifdef LAMP_TUNING
+static int g_force_walk = -1;   // -1 = heuristic; 0 = row-panel groups; n > 0 = W-resident walk with n column panels per group
+extern "C" __attribute__((visibility("default"))) void lamp_debug_force_gemm_walk(int gn) { g_force_walk = gn; }
 static long long g_trace_slab_words = 0;   // capacity of one timeline slab (8 words per workgroup), see lamp_debug_set_gemm_trace
 static size_t g_extra_lds = 0;
 extern "C" __attribute__((visibility("default"))) void lamp_debug_set_gemm_extra_lds(int bytes) { g_extra_lds = size_t(bytes); }
@@ -390,10 +410,16 @@ static int launch_cfg2(const GemmParams& p, hipStream_t s) {
         panel_split = 0;
     }
     if (nwg > 0x7fffffffLL) return LAMP_E_DIMS;
+    GemmParams q = p;
+    // W-resident walk (8 column panels per group) once the weight matrices of the launch reach 8 MiB -- twice an XCD's L2:
+    // delicious' FFN and fused Q/K/V weights.  Measured (profiles/r03_gemm_walk.txt): 3-22 % fewer bytes fetched, the same
+    // time (the kernel is MFMA-bound; everything hits the Infinity Cache).  Below that size the row-panel groups fetch less.
+    q.walk_gn = (int64_t(p.nseg) * p.N * p.K * 4 >= (8ll << 20) && tiles_n > 8) ? 8 : 0;
 #ifdef LAMP_TUNING
     if (p.trace && nwg * 8 > g_trace_slab_words) return LAMP_E_WORKSPACE;  // the timeline is indexed by blockIdx.x
+    if (g_force_walk >= 0) q.walk_gn = g_force_walk < tiles_n ? g_force_walk : tiles_n;
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(T::NT), LDS, s, p, tiles_n_seg, tiles_n, int(tiles_m),
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(T::NT), LDS, s, q, tiles_n_seg, tiles_n, int(tiles_m),
                        panel_split);
     return int(hipGetLastError());
 }

@@ -37,6 +37,7 @@ struct GemmParams {
                            // position of the batch was skipped and the padded encoder output IS the packed matrix (the
                            // last encoder LayerNorm then skips its packed copy)
     int vec_epilogue;   // set by launch_gemm: bias / residual / C can move as 16-byte accesses
+    int walk_gn;        // set by the launcher: > 0 = W-resident tile walk with this many column panels per group (gemm.hip)
     unsigned long long* trace;  // tuning build only (per-workgroup timeline, see gemm.hip); NULL in production
 };
 

@@ -42,25 +42,39 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
 // and plen[b] = T (padded layout, only klen is of interest).  rows[0] = off[nb]; rows[1] = off[nb] + 1 when some
 // position is skipped (the shared PAD row is then live), else off[nb].  padbits[b][w]: the key mask of sample b, one bit per
 // position (set = PAD token) -- the attention kernels then fetch ONE word per 32-key tile instead of testing 32 int64
-// tokens (LAMP_MASK_BITS_U32 with a zero query stride).  ONE workgroup: a wave per sample (64 positions per step), then
-// a wave-level prefix sum.
+// tokens (LAMP_MASK_BITS_U32 with a zero query stride).  ONE workgroup: a wave per sample, then a wave-level prefix sum.
 __global__ __launch_bounds__(1024) void seq_plan_kernel(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
                                                         int nb, int T, int64_t seq_stride, int packed, SeqPlan sp) {
+    // A wave per sample; the sample's 64-position chunks are fetched eight at a time -- sixteen loads in flight before the
+    // first ballot, from clamped addresses (a guarded load compiles to a branch plus a full s_waitcnt per element, which
+    // would serialise the round trips again) -- so a sample of up to 512 positions costs ONE memory round trip.
+    constexpr int GROUP = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int64_t* pos_or_seq = pos ? pos : seq;   // always a loadable address: no branch around the load
     for (int b = wave; b < nb; b += nwave) {
-        const int64_t* row = seq + int64_t(b) * seq_stride;
-        const int64_t* prow = pos ? pos + int64_t(b) * seq_stride : nullptr;
+        const int64_t row0 = int64_t(b) * seq_stride;
         int kl = 0, pl = 0;
-        for (int base = 0; base < T; base += 64) {   // one pass: 64 positions per step, all loads independent
-            const int j = base + lane;
-            const bool tok = j < T && row[j] != 0;
-            const bool act = tok || (prow && j < T && prow[j] != 0);
-            const unsigned long long mt = __ballot(tok), ma = __ballot(act);
-            if (mt) kl = base + 64 - __builtin_clzll(mt);
-            if (ma) pl = base + 64 - __builtin_clzll(ma);
-            // bit-packed key mask of this sample (bit = PAD token = blocked key; positions past T count as PAD)
-            if (lane < 2 && base / 32 + lane < sp.words)
-                sp.padbits[int64_t(b) * sp.words + base / 32 + lane] = ~unsigned(mt >> (32 * lane));
+        for (int base = 0; base < T; base += 64 * GROUP) {
+            int64_t tok[GROUP], ps[GROUP];
+#pragma unroll
+            for (int u = 0; u < GROUP; ++u) {
+                const int j = base + 64 * u + lane;
+                const int64_t at = row0 + (j < T ? j : 0);
+                tok[u] = seq[at];
+                ps[u] = pos_or_seq[at];
+            }
+#pragma unroll
+            for (int u = 0; u < GROUP; ++u) {
+                const int c0 = base + 64 * u, j = c0 + lane;
+                const bool t = j < T && tok[u] != 0;
+                const bool a = t || (pos && j < T && ps[u] != 0);
+                const unsigned long long mt = __ballot(t), ma = __ballot(a);
+                if (mt) kl = c0 + 64 - __builtin_clzll(mt);
+                if (ma) pl = c0 + 64 - __builtin_clzll(ma);
+                // bit-packed key mask of this sample (bit = PAD token = blocked key; positions past T count as PAD)
+                if (lane < 2 && c0 / 32 + lane < sp.words)
+                    sp.padbits[int64_t(b) * sp.words + c0 / 32 + lane] = ~unsigned(mt >> (32 * lane));
+            }
         }
         if (lane == 0) {
             sp.klen[b] = kl;
@@ -108,13 +122,11 @@ __global__ __launch_bounds__(256) void embed_packed_kernel(const int64_t* __rest
         if (sp.rows[1] == sp.rows[0]) return;   // no position skipped: no PAD row
         dst = sp.rows[0];
     } else {
-        // token, position and plan entries are independent loads: all requested before the first use
         const int b = int(flat / T), j = int(flat - int64_t(b) * T);
+        if (j >= sp.plen[b]) return;
         tok = seq[flat];
         ps = pos_table ? pos[flat] : 0;
-        const int pl = sp.plen[b], o = sp.off[b];
-        if (j >= pl) return;
-        dst = int64_t(o) + j;
+        dst = int64_t(sp.off[b]) + j;
     }
     const bool ok = tok >= 0 && tok < n_vocab && ps >= 0 && (!pos_table || ps < n_position);
     const float4* e = reinterpret_cast<const float4*>(emb + (ok ? tok : 0) * d);
@@ -174,20 +186,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     } else if constexpr (RG == 2) {
         flat = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);
         if (flat >= M) return;
-        // speculative: the row a batch without PAD positions would read (packed row == flat position), requested
-        // together with the plan entries instead of after them; a ragged batch re-reads its real row
-        load_row(flat);
         const int b = int(flat / T), j = int(flat - int64_t(b) * T);
         live = j < sp.plen[b];
         row = live ? int64_t(sp.off[b]) + j : int64_t(sp.rows[0]);
         // no position skipped anywhere: packed row == flat position, and the K / V projections read y2 (GemmParams::A_dense)
         if (sp.rows[1] == sp.rows[0]) y = nullptr;
-        if (row != flat) load_row(row);
     } else {
         row = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);
         if (row >= M) return;
     }
-    if constexpr (RG != 2) load_row(row);
+    load_row(row);
     const float4* rr = res ? reinterpret_cast<const float4*>(res + (r_mod > 0 ? row % r_mod : row) * d) : nullptr;
     float s = 0.f;
 #pragma unroll

@@ -28,6 +28,7 @@ import time
 import torch
 
 from . import data as D
+from . import sharding
 from .evaluate import test_epoch
 from .Models import LAMP
 
@@ -140,13 +141,9 @@ def main(argv=None):
     dev_index = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count() if world > 1 else torch.cuda.current_device()
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-    if world > 1:
-        import torch.distributed as dist
-        backend = os.environ.get('LAMP_EVAL_BACKEND', 'nccl')   # gloo lets several ranks share one GPU (tests)
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    # gloo rendezvous + an RCCL group for the final gather when RCCL comes up (probed; falls back to gloo and says so);
+    # LAMP_EVAL_BACKEND=gloo lets several ranks share one GPU (tests)
+    plane = sharding.ControlPlane(rank, world, device, os.environ.get('LAMP_EVAL_BACKEND', 'nccl'))
     data = D.load_dataset(opt.data)
     n_src, n_labels = D.vocabulary_sizes(data)
     adj = (D.prior_adjacency_device(data['train']['tgt'], len(data['dict']['tgt']), device).cpu()
@@ -166,19 +163,16 @@ def main(argv=None):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     preds, targets, bce_total = test_epoch(model, batches, n_labels, opt.batch_size, device, streams=opt.streams,
-                                           world_size=world, rank=rank)
+                                           world_size=world, rank=rank, group=plane.group)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = {'split': opt.split, 'n_samples': batches.n_insts, 'n_labels': n_labels, 'n_batches': len(batches),
            'bce_total': bce_total, 'seconds': dt, 'samples_per_s': batches.n_insts / dt,
-           'checkpoint': opt.checkpoint, 'n_gpus': world}
+           'checkpoint': opt.checkpoint, 'n_gpus': world, 'backend': plane.backend, 'backend_note': plane.note}
     out.update(multilabel_metrics(preds, targets, opt.br_threshold))
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    plane.close()
     return out
 
 

@@ -7,6 +7,8 @@ batch per rank, NO collective on the data path.  ``torch.distributed`` is only n
 per-rank logits together when a caller wants them on one rank (evaluation metrics), or for timing
 barriers.  Works with any backend ("nccl" = RCCL on GPUs, "gloo" on CPU for tests).
 """
+import os
+
 import torch
 
 
@@ -50,3 +52,88 @@ def sharded_forward(forward_fn, src_seq, src_pos, world_size, rank):
     if seq.size(0) == 0:
         return None
     return forward_fn(seq, pos)
+
+
+class ControlPlane:
+    """torch.distributed as a CONTROL plane only (the forward has no collective): bench.py's barrier around the timed
+    region, its gathers of per-rank reports and of a few logits for the cross-rank bitwise check, and run_eval's final
+    combination of the per-rank prediction rows.
+
+    The rendezvous and the default group are gloo (CPU, cannot fail on GPU topology); the barrier and the gathers run on a
+    "nccl" (= RCCL over xGMI on ROCm) group when it works -- first use is probed with one all_reduce, and every rank
+    agrees on the outcome through gloo -- so a node where RCCL cannot initialise still produces a line, with
+    `backend: "gloo"` and the reason in `config.backend_note`.  want='gloo' (bench.py: LAMP_BENCH_BACKEND=gloo, run_eval: LAMP_EVAL_BACKEND=gloo) skips RCCL (two ranks sharing
+    the one GPU of a test box)."""
+
+    def __init__(self, rank, world, device, want):
+        self.rank, self.world, self.device = rank, world, device
+        self.backend, self.note, self.group, self.dist = None, None, None, None
+        if world == 1 and not os.environ.get('LAMP_FORCE_DIST'):   # the variable: tools/check_rccl_control_plane.py
+            return
+        import datetime
+        import torch.distributed as dist
+        self.dist = dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        self.backend = 'gloo'
+        if want != 'nccl':
+            return
+        ok, note = 1, None
+        try:
+            self.group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=300))
+            t = torch.ones(1, device=device)
+            dist.all_reduce(t, group=self.group)
+            torch.cuda.synchronize()
+            ok = int(t.item() == world)
+            if not ok:
+                note = 'RCCL all_reduce over %d ranks returned %r' % (world, t.item())
+        except Exception as e:  # noqa: BLE001 -- whatever RCCL raises here, the bench falls back to gloo and says so
+            ok, note = 0, '%s: %s' % (type(e).__name__, e)
+        flag = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        notes = [None] * world
+        dist.all_gather_object(notes, note)
+        if int(flag.item()) == 1:
+            self.backend = 'nccl'
+        else:
+            self.group = None
+            self.note = 'nccl (RCCL) control plane unavailable, gloo used: ' + '; '.join(
+                'rank %d: %s' % (r, n) for r, n in enumerate(notes) if n)
+
+    @property
+    def nccl(self):
+        return self.backend == 'nccl'
+
+    def barrier(self):
+        if self.dist is None:
+            return
+        if self.nccl:
+            self.dist.barrier(group=self.group, device_ids=[self.device.index])
+        else:
+            self.dist.barrier()
+
+    def ranks_in_group(self):
+        if self.dist is None:
+            return 1
+        return self.dist.get_world_size(group=self.group) if self.nccl else self.dist.get_world_size()
+
+    def gather(self, t):
+        """All ranks' copies of tensor `t` (same shape and dtype everywhere), as CPU tensors, rank order."""
+        if self.dist is None:
+            return [t.detach().cpu()]
+        src = t.detach().to(self.device if self.nccl else 'cpu').contiguous()
+        out = [torch.empty_like(src) for _ in range(self.world)]
+        self.dist.all_gather(out, src, group=self.group if self.nccl else None)
+        return [o.cpu() for o in out]
+
+    def gather_objects(self, obj):
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        if self.dist is not None:
+            self.barrier()
+            self.dist.destroy_process_group()

@@ -67,13 +67,10 @@ def test_two_rank_gloo_shards_match_single_process(tmp_path):
 
 
 def _control_plane_worker(rank, world, port, want, out_dir):
-    """bench.ControlPlane (the only use bench.py makes of torch.distributed) between two CPU processes."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-    import bench
+    """sharding.ControlPlane (the only use bench.py makes of torch.distributed) between two CPU processes."""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    cp = bench.ControlPlane(rank, world, torch.device('cpu'), want)
+    cp = sharding.ControlPlane(rank, world, torch.device('cpu'), want)
     try:
         cp.barrier()
         rows = cp.gather(torch.tensor([float(rank), 10.0 + rank], dtype=torch.float64))

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""An evaluation epoch end to end on one MI355X -- lamp_amd.evaluate.test_epoch, the reference's `main.py -test_only` flow
+(test.py:16-58): batching + padding on the host, upload, forward, sigmoid + BCE on the device, copy back -- on a
+synthetic test split in the reference's format: 3019 documents (reuters' test size), lengths U{20..300}, V = 23666, 90
+labels, batch 32 -> 95 batches, model reuters d512 2+2 layers 4 heads label_mask = prior.
+
+    python tools/bench_eval_epoch.py            # samples/s = documents / wall time of the whole call, 1 / 2 / 4 streams
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lamp_amd import data as D  # noqa: E402
+from lamp_amd import synthetic as S  # noqa: E402
+from lamp_amd.evaluate import test_epoch  # noqa: E402
+from lamp_amd.Models import LAMP  # noqa: E402
+
+
+def main():
+    dev = torch.device('cuda:0')
+    V, L, T, d, dff, h, n_docs, bs = 23666, 90, 302, 512, 512, 4, 3019, 32
+    g = torch.Generator().manual_seed(0)
+    lengths = torch.randint(20, 301, (n_docs,), generator=g).tolist()
+    # instances as the reference stores them: [BOS, ids..., EOS] (utils/preprocess.py:218-232); labels = vocabulary ids >= 4
+    src = [[2] + torch.randint(4, V, (n,), generator=g).tolist() + [3] for n in lengths]
+    tgt = [[2] + sorted(set((torch.randint(0, L, (3,), generator=g) + 4).tolist())) + [3] for _ in range(n_docs)]
+    sd = S.make_state_dict(V, L, T, d, dff, h, 2, 2, pos_emb=True, seed=0)
+    adj = S.make_adjacency(L, 0.10, 0)
+    m = LAMP(V, L, T, L, n_layers_enc=2, n_layers_dec=2, n_head=h, n_head2=h, d_word_vec=d, d_model=d, d_inner_hid=dff,
+             d_k=d // h, d_v=d // h, encoder='graph', decoder='graph', label_adj_matrix=adj.clone(), label_mask='prior',
+             dec_dropout2=False)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    out = {'documents': n_docs, 'batch': bs, 'mean_length': sum(lengths) / n_docs + 2}
+    for streams in (1, 2, 4):
+        best = 0.0
+        for rep in range(4):   # first repetition warms the allocator and the clocks
+            batches = D.EvalBatcher(src, tgt, bs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            preds, targets, bce = test_epoch(m, batches, L, bs, dev, streams=streams)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if rep:
+                best = max(best, n_docs / dt)
+        assert preds.shape == (n_docs, L) and not torch.isnan(preds).any()
+        out['streams_%d' % streams] = best
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

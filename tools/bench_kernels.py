@@ -135,6 +135,69 @@ def lib_ab(rounds=9):
         print('%-30s' % name + ''.join('%17.1f/%6.1fT ' % (m, 2.0 * M * Nn * K / m / 1e6) for m in med))
 
 
+WALK_SHAPES = [('delic ffn1 31456x2048x1024', 31456, 2048, 1024, 1, 1, 0), ('delic ffn2 31456x1024x2048', 31456, 1024, 2048, 1, 0, 1),
+               ('delic fc 31456x1024x1024 +R', 31456, 1024, 1024, 1, 0, 1), ('delic qkv 31456x(3x1024)x1024', 31456, 1024, 1024, 3, 0, 0),
+               ('reuters kv 9664x(4x512)x512', 9664, 512, 512, 4, 0, 0), ('syn ffn1 65536x2048x1024', 65536, 2048, 1024, 1, 1, 0)]
+WALKS = [0, 2, 4, 8, 16]
+
+
+def _walk_case(lib, name, M, Nn, K, nseg, relu, res, dev):
+    """-> fn launching the GEMM (nseg > 1: that many weight matrices sharing A, through lamp_mha-style segments is not
+    exposed in the ABI, so the segments are emulated by ONE weight of nseg*N rows -- the same tile walk and traffic)."""
+    x = torch.randn(M, K, device=dev)
+    w = torch.randn(Nn * nseg, K, device=dev) / K ** 0.5
+    b = torch.randn(Nn * nseg, device=dev)
+    r = torch.randn(M, Nn * nseg, device=dev) if res else None
+    out = torch.empty(M, Nn * nseg, device=dev)
+
+    def fn():
+        N.check(lib.lamp_linear_fwd(x.data_ptr(), M, K, K, w.data_ptr(), Nn * nseg, K, b.data_ptr(),
+                                    r.data_ptr() if res else None, Nn * nseg, relu, out.data_ptr(), Nn * nseg, N.stream()), 'linear')
+    return fn, (x, w, b, r, out)
+
+
+def walk(rounds=5):
+    """Tile-walk A/B on the shapes whose weight matrix crowds the L2: row-panel groups (0) against the W-resident walk
+    with 2 / 4 / 8 / 16 column panels per group, round-robin medians (time only; traffic: tools/pmc_walk.sh)."""
+    import statistics
+    lib = N.lib()
+    force = lib.lamp_debug_force_gemm_walk
+    force.argtypes = [ctypes.c_int]
+    force.restype = None
+    dev = torch.device('cuda:0')
+    print('%-34s' % 'shape (median us / TFLOP/s)' + ''.join('%18s' % ('walk %d' % g) for g in WALKS))
+    for name, M, Nn, K, nseg, relu, res in WALK_SHAPES:
+        fn, keep = _walk_case(lib, name, M, Nn, K, nseg, relu, res, dev)
+        samples = {g: [] for g in WALKS}
+        for _ in range(rounds):
+            for g in WALKS:
+                force(g)
+                samples[g].append(time_fn(fn, iters=5, warm=2))
+        force(-1)
+        print('%-34s' % name + ''.join('%10.1f/%6.1fT ' % (statistics.median(samples[g]),
+                                                            2.0 * M * Nn * nseg * K / statistics.median(samples[g]) / 1e6) for g in WALKS))
+        del keep
+
+
+def walk_pmc():
+    """For a rocprofv3 --pmc pass: every (shape, walk) launched 3 times in a fixed order (tools/pmc_walk.sh reads the
+    counters back by dispatch order)."""
+    lib = N.lib()
+    force = lib.lamp_debug_force_gemm_walk
+    force.argtypes = [ctypes.c_int]
+    force.restype = None
+    dev = torch.device('cuda:0')
+    for name, M, Nn, K, nseg, relu, res in WALK_SHAPES:
+        fn, keep = _walk_case(lib, name, M, Nn, K, nseg, relu, res, dev)
+        for g in WALKS:
+            force(g)
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+        del keep
+    force(-1)
+
+
 def gemm_gen():
     """lamp_gemm (backward-pass GEMM) on the shapes of a reuters training step, every operand layout, next to the
     tuned forward kernel on the same product where it applies."""
@@ -433,5 +496,5 @@ def gemm_trace():
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
-    {'gemm': gemm, 'gemm_ab': gemm_ab, 'lib_ab': lib_ab, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
+    {'gemm': gemm, 'gemm_ab': gemm_ab, 'lib_ab': lib_ab, 'walk': walk, 'walk_pmc': walk_pmc, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
      'gemm_trace': gemm_trace, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency}[which]()

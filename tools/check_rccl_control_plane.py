@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py's control plane (bench.ControlPlane: gloo rendezvous, then an "nccl" = RCCL group for the barrier and the
+"""The control plane of bench.py and run_eval (lamp_amd.sharding.ControlPlane: gloo rendezvous, then an "nccl" = RCCL group for the barrier and the
 gathers) as a ONE-rank group, so that the exact calls run on a one-GPU box (RCCL refuses two ranks on one device; the
 2-rank tests therefore run on gloo).
 
@@ -13,11 +13,12 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
 os.environ.setdefault('MASTER_PORT', '29544')
-os.environ['LAMP_BENCH_FORCE_DIST'] = '1'
+os.environ['LAMP_FORCE_DIST'] = '1'
 import bench  # noqa: E402
+from lamp_amd import sharding  # noqa: E402
 
 torch.cuda.set_device(0)
-cp = bench.ControlPlane(0, 1, torch.device('cuda', 0), 'nccl')
+cp = sharding.ControlPlane(0, 1, torch.device('cuda', 0), 'nccl')
 assert cp.backend == 'nccl', cp.note
 cp.barrier()
 rows = cp.gather(torch.tensor([0., 0., 1.5, 640.], dtype=torch.float64))

@@ -12,10 +12,11 @@ import sys
 
 
 def last_forward(rows_by_dispatch):
-    """Dispatch ids of the last complete forward: from its seq_plan_kernel (the first launch of lamp_forward) up to the
+    """Dispatch ids of the last complete forward: from its embed_plan_kernel / seq_plan_kernel (the first launch of lamp_forward) up to the
     launch before the next one / the end of the trace."""
     ids = [k for k in rows_by_dispatch if 'lamp::' in rows_by_dispatch[k]['name']]
-    emb = [i for i, k in enumerate(ids) if 'seq_plan_kernel' in rows_by_dispatch[k]['name']]
+    first = lambda n: 'embed_plan_kernel' in n or 'seq_plan_kernel' in n   # noqa: E731 -- the first launch of lamp_forward
+    emb = [i for i, k in enumerate(ids) if first(rows_by_dispatch[k]['name'])]
     return ids[emb[-2]:emb[-1]]
 
 
@@ -38,7 +39,7 @@ def kernel_only_gemm_us(src, wl):
     if not os.path.exists(path):
         return None
     rows = list(csv.DictReader(open(path)))
-    fwd = sum(int(r['Calls']) for r in rows if 'seq_plan_kernel' in r['Name'])
+    fwd = sum(int(r['Calls']) for r in rows if 'seq_plan_kernel' in r['Name'] or 'embed_plan_kernel' in r['Name'])
     ns = sum(float(r['TotalDurationNs']) for r in rows if 'gemm_nt_kernel' in r['Name'])
     return ns / fwd / 1e3 if fwd else None
 
