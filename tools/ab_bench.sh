@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 for round in 1 2 3; do
   for name in "$@"; do
     lib=$PWD/lamp_amd/build/liblamp_$name.so; [ "$name" = cur ] && lib=$PWD/lamp_amd/liblamp_hip.so
-    LAMP_HIP_LIBRARY=$lib python bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-extra-workloads --no-pipelined $FLAGS 2>/dev/null | \
+    LAMP_HIP_LIBRARY=$lib python bench.py --steps ${AB_STEPS:-300} --warmup ${AB_WARMUP:-20} --no-cpu-baseline --no-extra-workloads --no-pipelined $FLAGS 2>/dev/null | \
       python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-8s' % sys.argv[1], '%-10s' % sys.argv[2], round(d['value']), {k: round(v['us_per_step'],1) for k,v in d['kernels'].items()})" "$name" "$FLAGS" | tee -a $OUT/ab_bench.txt
   done
 done
