@@ -334,7 +334,13 @@ size_t lamp_forward_workspace_bytes(const lamp_model* m, int32_t micro_batch, in
 /* LAMP.forward (lamp/Models.py:110-137) for encoder='graph', decoder='graph', eval mode:
  *   src_seq, src_pos int64 [B, T]  ->  logits [B, n_labels], enc_output [B, T, d_model].
  * The encoder self-attention, whose output the reference discards (lamp/Layers.py:16-18), is
- * computed only when aux->enc_self_attn is given. */
+ * computed only when aux->enc_self_attn is given.
+ * Ragged batches (utils/data_loader.py:261-279 pads to the longest document): PAD positions are not computed.  The call's
+ * first kernel counts each sample's extents on the device; the encoder runs on the packed non-PAD rows plus ONE shared PAD
+ * row (every PAD position of lamp/Encoders.py:64-79 holds the same row-wise result), and the enc-dec attention stops at
+ * each sample's last non-PAD key (keys past it are exactly masked, lamp/utils.py:26-34).  enc_output is still the padded
+ * [B, T, d_model] tensor the reference returns, PAD positions included, and a sample's outputs do not depend on T, on
+ * B or on the micro-batch split, bit for bit. */
 int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src_pos,
                  int32_t B, int32_t T, float* logits, float* enc_output, const lamp_aux* aux,
                  void* workspace, size_t workspace_bytes, lamp_stream_t stream);

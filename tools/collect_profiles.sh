@@ -19,6 +19,9 @@ python bench.py --ragged --no-cpu-baseline > "$OUT/bench_reuters_ragged.json" 2>
 python bench.py --workload synthetic4096 --batch 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined > "$OUT/bench_synthetic4096_b1024.json" 2>/dev/null
 python bench.py --workload synthetic4096 --mask none --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined > "$OUT/bench_synthetic4096_none.json" 2>/dev/null
 LAMP_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 5 --no-pipelined > "$OUT/bench_two_ranks_one_gpu_gloo.json" 2>/dev/null
+LAMP_BENCH_BACKEND=gloo python bench.py --gpus 2 --ragged --steps 50 --warmup 5 --no-pipelined > "$OUT/bench_two_ranks_one_gpu_gloo_ragged.json" 2>/dev/null
+python tools/check_rccl_control_plane.py > "$OUT/rccl_control_plane_one_rank.txt" 2>&1
+python tools/bench_eval_epoch.py > "$OUT/eval_epoch_end_to_end.json" 2>/dev/null
 python tools/bench_kernels.py gemm_ab 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles.txt"
 python tools/bench_kernels.py gemm 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles_sweep.txt"
 python tools/bench_kernels.py attn 2>&1 | grep -v amdgpu.ids > "$OUT/attn_variants.txt"
@@ -26,6 +29,7 @@ python tools/bench_kernels.py sparse 2>&1 | grep -v amdgpu.ids > "$OUT/sparse_la
 python tools/bench_kernels.py gemm_trace 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_trace.txt"
 BENCH="python $PWD/bench.py --no-cpu-baseline --no-pipelined --no-extra-workloads"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o p -f csv -- $BENCH --steps 100 --warmup 10 > "$OUT/bench_under_rocprof.json" 2>/dev/null )
+( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats_ragged" -o p -f csv -- $BENCH --ragged --steps 100 --warmup 10 > "$OUT/bench_ragged_under_rocprof.json" 2>/dev/null )
 # PMC passes are separate runs, each with --kernel-trace only (never combined with other trace domains)
 ( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
       -d "$OUT/pmc_sq" -o p -f csv -- $BENCH --steps 5 --warmup 3 > /dev/null 2>&1 )

@@ -54,7 +54,7 @@ def main():
     cp('bench.json', 'bench.json')
     cp('bench_under_rocprof.json', 'bench_under_rocprof.json')
     for wl in ('bibtex', 'delicious', 'synthetic4096', 'reuters_ragged', 'synthetic4096_b1024', 'synthetic4096_none',
-               'driver_style_20steps', 'two_ranks_one_gpu_gloo'):
+               'driver_style_20steps', 'two_ranks_one_gpu_gloo', 'two_ranks_one_gpu_gloo_ragged'):
         if not os.path.exists(os.path.join(src, 'bench_%s.json' % wl)):
             continue
         cp('bench_%s.json' % wl, 'bench_%s.json' % wl)
@@ -65,6 +65,17 @@ def main():
     if os.path.exists(os.path.join(src, 'gemm_trace.txt')):
         cp('gemm_trace.txt', 'gemm_trace.txt')
     cp('stats/p_kernel_stats.csv', 'bench_kernel_stats.csv')
+    for a, b in (('stats_ragged/p_kernel_stats.csv', 'bench_kernel_stats_reuters_ragged.csv'),
+                 ('bench_ragged_under_rocprof.json', 'bench_ragged_under_rocprof.json'),
+                 ('eval_epoch_end_to_end.json', 'eval_epoch_end_to_end.json'),
+                 ('rccl_control_plane_one_rank.txt', 'rccl_control_plane_one_rank.txt')):
+        if os.path.exists(os.path.join(src, a)):
+            cp(a, b)
+    other = os.path.join(src, '..', '%s_stats_other' % os.path.basename(os.path.normpath(src)))
+    for wl in ('bibtex', 'delicious', 'synthetic4096'):
+        f = os.path.join(other, 'kernel_stats_%s.csv' % wl)
+        if os.path.exists(f):
+            shutil.copy(f, os.path.join(dst, '%s_bench_kernel_stats_%s.csv' % (tag, wl)))
     for f in ('train_reuters.json', 'train_reuters_cpu_oracle.json', 'train_delicious.json', 'gemm_gen.txt'):
         if os.path.exists(os.path.join(src, f)):
             cp(f, f)
