@@ -441,8 +441,12 @@ static int launch_small_dp(const AttnParams& p, int qb, int ksplit, hipStream_t 
 // over at most 64 keys (delicious' 983 labels x 40 tokens: 135 -> 121 us; 300 x 100 would be 52 -> 35, but 983 x 100 is a
 // tie and the self-attention shapes beyond 256 belong to attention.hip) -- with V and O given and either no maps or the
 // single-pass map write-out.  The exact two-pass maps and map-only calls stay in attention.hip.
+// With ragged keys (kv_len) lk is only the PADDED length of the batch: the choice then rests on lq alone, so that a sample's
+// bits do not depend on how far its batch was padded (the fuzz campaign found the <= 64-key rule switching kernels between
+// a 300-label sample run alone and the same sample inside a longer batch).
 bool attn_small_applies(const AttnParams& p, bool any_lq) {
-    return (p.lq <= 256 || p.lk <= 64 || any_lq) && p.V && p.O && (!p.P || p.lse) && p.dk <= 128 && p.dv <= 128;
+    const bool few_keys = p.lk <= 64 && !p.kv_len;
+    return (p.lq <= 256 || few_keys || any_lq) && p.V && p.O && (!p.P || p.lse) && p.dk <= 128 && p.dv <= 128;
 }
 
 #ifdef LAMP_TUNING

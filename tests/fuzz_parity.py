@@ -8,7 +8,8 @@
 Eval: random model shapes (1-8 heads, d_k 4..256 incl. widths beyond the fused attention kernel, 1-3 + 1-3 layers,
 every mask kind, L and T from 1 to 300 / 150, ragged lengths, with / without decoder self-attention): logits and
 enc_output against the fp64 oracle (bar: max(1e-4, 4 x the oracle's own fp32-vs-fp64 gap)), every attention map against
-the fp32 oracle (1e-5), and logits bit-identical with and without return_attns.
+the fp32 oracle (1e-5), logits bit-identical with and without return_attns (= packed vs padded encoder), and one sample
+of the batch run alone at its own length bit-identical to its rows in the batch.
 Train: dropout 0, BCE loss, every parameter's gradient against torch.autograd on the fp64 oracle (relative 2e-3 of
 the gradient's max; a larger gap on one layer's FFN is what a ReLU pre-activation of ~1e-7 flipping sign between fp32
 and fp64 looks like -- check the sub-layer in isolation before calling it a bug).
@@ -38,7 +39,7 @@ def case(i):
     if h == 1: d = rng.choice([4, 8, 20, 64, 128, 200])
     dff = rng.choice([4, 12, 64, 100, 200, 516])
     L = rng.choice([1, 2, 17, 31, 32, 33, 64, 95, 129, 300])
-    T = rng.choice([1, 2, 5, 31, 32, 33, 97, 150])
+    T = rng.choice([1, 2, 5, 31, 32, 33, 97, 150, 200, 302])   # 200 / 302: four key shares in the small-shape attention
     B = rng.randint(1, 6)
     mask = rng.choice(['prior', 'none', 'inveye'])
     pos = rng.random() < 0.5
@@ -74,6 +75,11 @@ for i in range(n_eval):
         gap = mad(ref[0], ref64)
         tol = max(1e-4, 4 * gap)
         errs = [mad(enc, ref[1]) < 5e-5, mad(lg, ref64) < tol, torch.equal(got[0], lg)]
+        # a sample alone, padded to its own length: the same bits as inside the batch (packed encoder, per-sample key split)
+        b = i % c['B']; n = c['lengths'][b]
+        with torch.no_grad():
+            one, enc_one, _ = m((seq[b:b + 1, :n].to(dev), spos[b:b + 1, :n].to(dev)), None, None, None)
+        errs.append(torch.equal(one, lg[b:b + 1]) and torch.equal(enc_one, enc[b:b + 1, :n]))
         for a, b in zip(got[3][1], ref[3][1]): errs.append(mad(a, b) < 1e-5)
         for a, b in zip(got[3][0], ref[3][0]):
             if a is not None: errs.append(mad(a, b) < 1e-5)
@@ -97,7 +103,7 @@ for i in range(n_train):
         m.train()
         lg, _, _ = m((seq.to(dev), spos.to(dev)), None, None, tgt.to(dev))
         F.binary_cross_entropy_with_logits(lg, tgt.to(dev)).backward()
-        worst = 0.0
+        worst, worst_name = 0.0, None
         for n, p in m.named_parameters():
             if p.grad is None: continue
             ref = sd64[n].grad
@@ -105,9 +111,13 @@ for i in range(n_train):
                 ref = ref + sd64['tgt_word_proj.weight'].grad
             scale = ref.abs().max().item()
             rel = mad(p.grad, ref) / (scale + 1e-12) if scale > 0 else mad(p.grad, ref)
-            if scale > 1e-9: worst = max(worst, rel)
+            if scale > 1e-9 and rel > worst: worst, worst_name = rel, n
         if not (worst < 2e-3):
-            bad_t += 1; print('TRAIN MISMATCH', i, c, worst)
+            bad_t += 1; print('TRAIN MISMATCH', i, c, worst, worst_name, 'logits', mad(lg, rl))
+            for n, p in m.named_parameters():   # where the gradient departs: per parameter, relative to its own maximum
+                if p.grad is not None and sd64[n].grad is not None:
+                    sc_ = sd64[n].grad.abs().max().item()
+                    if sc_ > 1e-9 and mad(p.grad, sd64[n].grad) / sc_ > 2e-4: print('     ', n, mad(p.grad, sd64[n].grad) / sc_)
     except Exception as e:
         bad_t += 1; print('TRAIN ERROR', i, c, repr(e)); traceback.print_exc()
 print('train cases', n_train, 'bad', bad_t)
