@@ -9,7 +9,6 @@ and the per-sample ``adj`` branch stay outside the scope (they raise).
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import Constants, utils
 from . import _native as N

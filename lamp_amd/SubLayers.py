@@ -10,7 +10,6 @@ autograd-recording path of lamp_amd/training.py, whose backward is HIP kernels a
 bare XavierLinear / ScaledDotProductAttention wrappers when called on their own.
 """
 import numpy as np
-import torch
 import torch.nn as nn
 
 from . import _native as N
