@@ -465,7 +465,9 @@ def main():
 
     ranks_seen = sorted(int(r[0]) for r in rows)
     n_gpus = len(ranks_seen)
-    physical = len(set(identities))
+    # distinct devices: by PCI / uuid identity, and never fewer than the distinct device indices the ranks opened (identity
+    # strings can coincide under virtualisation; indices cannot, unless every rank was given its own HIP_VISIBLE_DEVICES)
+    physical = max(len(set(identities)), len({int(r[1]) for r in rows}))
     samples = sum(r[3] for r in rows)
     value = samples / elapsed
     ms_per_step = elapsed / args.steps * 1e3
