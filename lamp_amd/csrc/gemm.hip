@@ -29,6 +29,26 @@ namespace lamp {
 // MF = edge of the MFMA block a wave tile is built from: 16 (v_mfma_f32_16x16x4_f32, 4 accumulator registers
 // per block; the production tiles -- see launch_gemm) or 32 (v_mfma_f32_32x32x2_f32, 16 registers per block;
 // kept as forced configurations for comparison).  Both issue 64 FLOP/cycle/SIMD.
+// Tile-index arithmetic without integer division.  A runtime 32-bit division is ~40 scalar / vector instructions on gfx950;
+// the five of them in the tile walk were ~0.4 us of every launch's prologue, before its first load is even requested.
+// n / d for 0 <= n < 2^31 with host-made magic numbers: mul = ceil(2^(31 + l) / d), l = ceil(log2 d):  q = umulhi(n, mul) >> (l - 1).
+struct FastDiv {
+    unsigned mul, shift;   // mul == 0: d == 1
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+    if (d <= 1) return FastDiv{0u, 0u};
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    return FastDiv{unsigned(((1ull << (31 + l)) + d - 1) / d), l - 1};
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) { return f.mul ? int(__umulhi(unsigned(n), f.mul) >> f.shift) : n; }
+// divisor 1 .. 8 (the row-panels of a group), same scheme with the magic numbers as literals
+__device__ __forceinline__ int div_1_to_8(int n, int d) {
+    if ((d & (d - 1)) == 0) return n >> (31 - __builtin_clz(unsigned(d)));
+    const unsigned mul = d == 5 ? 0xCCCCCCCDu : (d == 7 ? 0x92492493u : 0xAAAAAAABu);   // 3 and 6 share 0xAAAAAAAB
+    return int(__umulhi(unsigned(n), mul) >> (d == 3 ? 1 : 2));
+}
+
 constexpr int gemm_min_waves(int bm, int bn, int bk, int mf) { return (mf == 16 && bm == 64 && bn == 64 && bk == 16) ? 5 : 1; }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF = 32>
@@ -62,7 +82,8 @@ struct GemmTile {
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, MF))) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
                                                                           int tiles_n, int tiles_m,
-                                                                          int panel_split) {
+                                                                          int panel_split, FastDiv fd_group,
+                                                                          FastDiv fd_seg) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
     // lane -> (row within an MFMA block, which group of 4 consecutive k this lane's b128 read covers)
     constexpr int KQ = 64 / MF;             // 2 for 32x32x2, 4 for 16x16x4
@@ -138,14 +159,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
         tn_all = first_n + (in_grp - tml * gn);
     } else {
         const int group_sz = GROUP_M * tiles_n;
-        const int grp = item / group_sz;
+        const int grp = fdiv(item, fd_group);   // item / group_sz
         const int in_grp = item - grp * group_sz;
         const int first_m = pan0 + grp * GROUP_M;
         const int gm = pan1 - first_m < GROUP_M ? pan1 - first_m : GROUP_M;
-        tn_all = in_grp / gm;
+        tn_all = div_1_to_8(in_grp, gm);
         tm = first_m + (in_grp - tn_all * gm);
     }
-    const int seg = tn_all / tiles_n_seg;
+    const int seg = fdiv(tn_all, fd_seg);       // tn_all / tiles_n_seg
     const int tn = tn_all - seg * tiles_n_seg;
     const int64_t m0 = int64_t(tm) * BM;
     const int n0 = tn * BN;
@@ -420,7 +441,7 @@ static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     if (g_force_walk >= 0) q.walk_gn = g_force_walk < tiles_n ? g_force_walk : tiles_n;
 #endif
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(T::NT), LDS, s, q, tiles_n_seg, tiles_n, int(tiles_m),
-                       panel_split);
+                       panel_split, make_fastdiv(unsigned(8 * tiles_n)), make_fastdiv(unsigned(tiles_n_seg)));
     return int(hipGetLastError());
 }
 
