@@ -171,6 +171,9 @@ __global__ __launch_bounds__(256, PM == 0 ? 2 : 1) void attn_kernel(AttnParams p
         float4 qa[QG], qn[QG];
 #pragma unroll
         for (int j = 0; j < QG; ++j) qa[j] = *reinterpret_cast<const float4*>(qp + j * 8);
+#ifdef LAMP_SETPRIO   // experiment (profiles/r04_setprio.txt)
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int g = 0; g < DKC / QG; ++g) {
             if (g + 1 < DKC / QG) {
@@ -188,6 +191,9 @@ __global__ __launch_bounds__(256, PM == 0 ? 2 : 1) void attn_kernel(AttnParams p
 #pragma unroll
             for (int j = 0; j < QG; ++j) qa[j] = qn[j];
         }
+#ifdef LAMP_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         const int kbase = kt * 32 + 4 * hi;
         const unsigned mw = MK == LAMP_MASK_BITS_U32 ? mword >> (4 * hi) : 0u;
 #pragma unroll
@@ -200,11 +206,17 @@ __global__ __launch_bounds__(256, PM == 0 ? 2 : 1) void attn_kernel(AttnParams p
         }
     };
     auto pv = [&](const f32x16& pr, f32x16 (&o)[DVB]) {
+#ifdef LAMP_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int e = 0; e < DVB; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 o[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r][e], pr[r], o[e], 0, 0, 0);
+#ifdef LAMP_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     f32x16 o[DVB];

@@ -217,6 +217,9 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     // is 40 cycles against 32 of issue), then -inf where blocked / past lk.
     auto scores = [&](int kt, f32x4& s) {
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#ifdef LAMP_SETPRIO   // experiment (profiles/r04_setprio.txt): raised wave priority around the QK^T and PV MFMA runs
+        __builtin_amdgcn_s_setprio(1);
+#endif
         const float* qp = Qs + l15 * QS + 4 * g;   // lane (query l15, group g): Q[q][16c + 4g + j]
         const float* kp = Ks + l15 * QS + 4 * g;   // lane (key   l15, group g): K[k][16c + 4g + j]
 #pragma unroll
@@ -234,6 +237,9 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
             s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.w, qa.w, s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.w, qb2.w, s1, 0, 0, 0);
         }
+#ifdef LAMP_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         const int kbase = kt * 16 + 4 * g;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -290,11 +296,17 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
             l_part += (s[0] + s[1]) + (s[2] + s[3]);
+#ifdef LAMP_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int e = 0; e < DV8; ++e)
                     o[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r][e], s[r], o[e], 0, 0, 0);
+#ifdef LAMP_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             load_v(kn);      // flies under the next QK^T
         }

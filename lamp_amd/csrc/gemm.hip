@@ -62,6 +62,14 @@ struct GemmTile {
     static constexpr int A_LD = BM * BK / 4 / NT;  // float4 loads per thread per tile
     static constexpr int B_LD = BN * BK / 4 / NT;
     static constexpr size_t LDS_BYTES = size_t(2) * (BM + BN) * LDS_STRIDE * sizeof(float);
+    // Direct-to-LDS staging (DMA = true, see gemm_nt_kernel): two or three unpadded [BM + BN][BK] images, filled by
+    // buffer_load_dwordx4 ... lds in 1 KiB pieces (one wave instruction = 64 lanes x 16 B = RPP whole rows).
+    static constexpr int QPR = BK / 4;            // 16-byte quads per row
+    static constexpr int RPP = 64 / QPR;          // rows per 1 KiB piece
+    static constexpr int A_PW = BM / RPP / (NT / 64);   // pieces per wave and k-step
+    static constexpr int B_PW = BN / RPP / (NT / 64);
+    static constexpr size_t DMA_STAGE_BYTES = size_t(BM + BN) * BK * sizeof(float);   // x 2 (DMA mode 1) or 3 (mode 2)
+    static constexpr bool DMA_OK = (BK == 16 || BK == 32 || BK == 64) && BM % (RPP * (NT / 64)) == 0 && BN % (RPP * (NT / 64)) == 0;
     // Waves per SIMD the register allocator must leave room for.  The 64x64x16 tile serves launches of ~1200 tiles
     // (encoder FFN at batch 32: 1208): five workgroups per CU hold them all at once, four leave a second, mostly empty
     // round (44 -> 51 us when the 16-byte epilogue operands pushed the kernel from 92 to 100 registers).
@@ -79,7 +87,62 @@ struct GemmTile {
 // round trip over 8-16x more matrix work per wave and keep the registers for occupancy.
 // VEC: bias / residual / C move as 16-byte accesses (N, ldc, ldr multiples of 4 and 16-byte aligned bases -- every shape
 // of the forward); the scalar instantiation serves odd widths.
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC>
+//
+// DMA (round 4): the K-step tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction), no
+// staging registers and no ds_write pass.  The LDS-DMA destination is wave-uniform base + lane * 16, so the image cannot be
+// padded; rows are BK floats, stored back to back, and bank conflicts are avoided by an XOR on the 16-byte quad index:
+// quad q of row r sits in slot q ^ f(r & 15), applied to the SOURCE address of the filling lane and to the fragment read
+// (f: see dma_swz; checked against the ds_read_b128 lane groups of MI355X_MICROARCH.md: conflict-free for BK = 16 / 32 / 64
+// and both MFMA shapes, where the padded image is 2-way).  A fragment still holds k = 16c + 4 hi + j: same products, same
+// k-order, same bits as the register-staged kernel.
+//   DMA = 1: fragment reads are ordinary loads.  hipcc (ROCm 7.2) orders every LDS read behind ALL earlier LDS-DMA
+//            (s_waitcnt vmcnt(0) in front of the first ds_read that follows one -- it cannot tell the stages apart), so the
+//            step is: drain, barrier, read ALL fragments of tile t, request tile t + 1, multiply.  Two stages; the request
+//            is covered by one step of MFMAs (and by the other workgroups of the CU).
+//   DMA = 2: fragment reads are inline-asm ds_read_b128 (invisible to that pass; waited for by hand, lgkmcnt + sched_barrier).
+//            Three stages: while tile t is multiplied, t + 1 has landed or is landing and t + 2 is requested; ONE raw
+//            s_barrier per K step, and the only vector-memory wait in the loop is a counted s_waitcnt vmcnt(pieces of one
+//            tile) -- __syncthreads() would drain the DMA queue at every step.
+template <int BK>
+__device__ __forceinline__ int dma_swz(int r) {   // r = row & 15
+    if constexpr (BK == 16) return (0x1230 >> (r & 12)) & 3;   // rows 0-3 / 4-7 / 8-11 / 12-15 -> 0, 3, 2, 1
+    else if constexpr (BK == 32) return (r >> 1) & 7;
+    else return r & 15;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ const float* uniform_ptr(const float* q) {
+    const uint64_t b = reinterpret_cast<uint64_t>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(b)), hi = __builtin_amdgcn_readfirstlane(unsigned(b >> 32));
+    return reinterpret_cast<const float*>((uint64_t(hi) << 32) | lo);
+}
+// One LDS-DMA instruction: 64 lanes x 16 bytes from per-lane buffer offsets to LDS [dst, dst + 1 KiB) in lane order (dst
+// wave-uniform).  (A plain function, not code inside the kernel template: with the builtin spelled in the template hipcc's
+// host pass silently drops the kernel's launch stub -- the library then fails to load with an undefined symbol.)
+typedef __attribute__((address_space(3))) void* lds_ptr;
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, float* dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, voff, soff, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);   // hipcc moves register-only MFMAs across an asm wait otherwise
+}
+__device__ __forceinline__ f32x4 lds_read16(unsigned addr) {   // LDS byte address
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC, int DMA = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, MF))) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
                                                                           int tiles_n, int tiles_m,
                                                                           int panel_split, FastDiv fd_group,
@@ -93,8 +156,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
     constexpr int S = T::LDS_STRIDE;
     constexpr int C4 = BK / 4;  // float4 per tile row
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;               // [2][BM][S]
+    float* As = smem;               // [2][BM][S]                    (DMA: stage s = smem + s * (BM + BN) * BK, A then W rows)
     float* Bs = smem + 2 * BM * S;  // [2][BN][S]
+    static_assert(!DMA || (T::DMA_OK && !KTAIL), "direct-to-LDS staging: whole 1 KiB pieces per wave, K a multiple of BK");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -178,10 +242,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
     if (p.A_dense) {
         if (p.m_dev[0] == p.m_dev[1]) Abase = p.A_dense;
     }
+    // (the tile origin is wave-uniform, but parts of its arithmetic run on the vector ALU; an LDS-DMA load through a descriptor
+    // held in vector registers compiles to a waterfall loop -- hand the compiler scalars)
     const __amdgpu_buffer_rsrc_t rsA =
-        make_rsrc(Abase + m0 * p.lda, (uint64_t(rows_m - 1) * lda + p.K) * 4u);
+        make_rsrc(uniform_ptr(Abase + m0 * p.lda), __builtin_amdgcn_readfirstlane(unsigned((uint64_t(rows_m - 1) * lda + p.K) * 4u)));
     const __amdgpu_buffer_rsrc_t rsW =
-        make_rsrc(p.W[seg] + int64_t(n0) * p.ldw, (uint64_t(rows_n - 1) * ldw + p.K) * 4u);
+        make_rsrc(uniform_ptr(p.W[seg] + int64_t(n0) * p.ldw), __builtin_amdgcn_readfirstlane(unsigned((uint64_t(rows_n - 1) * ldw + p.K) * 4u)));
 
     acc_t acc[T::MI][T::NI];
 #pragma unroll
@@ -246,6 +312,30 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
             *reinterpret_cast<float4*>(b + row * S + c4 * 4) = rb[i];
         }
     };
+    auto mfma_chunk = [&](const float4 (&fa)[T::MI], const float4 (&fb)[T::NI]) {
+#ifdef LAMP_SETPRIO   // experiment (profiles/r04_setprio.txt): raised wave priority around the MFMA run
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int i = 0; i < T::MI; ++i)
+#pragma unroll
+            for (int j = 0; j < T::NI; ++j) {
+                if constexpr (MF == 32) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
+                }
+            }
+#ifdef LAMP_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
     auto compute = [&](int buf) {
         const float* a = As + buf * BM * S + (wm * T::WTM + l31) * S + hi * 4;
         const float* b = Bs + buf * BN * S + (wn * T::WTN + l31) * S + hi * 4;
@@ -256,27 +346,88 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
             for (int i = 0; i < T::MI; ++i) fa[i] = *reinterpret_cast<const float4*>(a + i * MF * S + c * KCH);
 #pragma unroll
             for (int j = 0; j < T::NI; ++j) fb[j] = *reinterpret_cast<const float4*>(b + j * MF * S + c * KCH);
-#pragma unroll
-            for (int i = 0; i < T::MI; ++i)
-#pragma unroll
-                for (int j = 0; j < T::NI; ++j) {
-                    if constexpr (MF == 32) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
-                    }
-                }
+            mfma_chunk(fa, fb);
         }
     };
 
+    // ---- direct-to-LDS staging (DMA) ----
+    constexpr int STAGE = (BM + BN) * BK;   // floats per LDS stage
+    constexpr int PW = T::A_PW + T::B_PW;   // LDS-DMA instructions per wave and k-step
+    unsigned dva[DMA ? T::A_PW : 1], dvb[DMA ? T::B_PW : 1];   // source byte offsets of this lane's quads inside the tile
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    if constexpr (DMA) {
+        const int prow = lane / T::QPR, pq = lane % T::QPR;   // row inside a piece, LDS slot inside the row
+#pragma unroll
+        for (int i = 0; i < T::A_PW; ++i) {
+            const int row = (wave_u * T::A_PW + i) * T::RPP + prow;
+            dva[i] = unsigned(row * lda + ((pq ^ dma_swz<BK>(row & 15)) << 2)) * 4u;
+        }
+#pragma unroll
+        for (int i = 0; i < T::B_PW; ++i) {
+            const int row = (wave_u * T::B_PW + i) * T::RPP + prow;
+            dvb[i] = unsigned(row * ldw + ((pq ^ dma_swz<BK>(row & 15)) << 2)) * 4u;
+        }
+    }
+    auto dma_stage = [&](int kt, int st) {
+        const unsigned so = unsigned(kt * BK) * 4u;   // uniform -> soffset
+        float* base = smem + st * STAGE;
+#pragma unroll
+        for (int i = 0; i < T::A_PW; ++i)
+            lds_dma16(rsA, base + (wave_u * T::A_PW + i) * 256, dva[i], so);
+#pragma unroll
+        for (int i = 0; i < T::B_PW; ++i)
+            lds_dma16(rsW, base + BM * BK + (wave_u * T::B_PW + i) * 256, dvb[i], so);
+    };
+    int qoff[BK / KCH];   // float offset of this lane's quad of chunk c inside its (swizzled) row
+#pragma unroll
+    for (int c = 0; c < BK / KCH; ++c) qoff[c] = ((c * KQ + hi) ^ dma_swz<BK>(l31 & 15)) << 2;
+    constexpr int NCH = BK / KCH;
+    // DMA = 1: all fragments of a stage into registers (ordinary loads), then -- by the caller -- the next request, then the MFMAs
+    float4 fra[DMA == 1 ? NCH : 1][T::MI], frb[DMA == 1 ? NCH : 1][T::NI];
+    auto dma_read = [&](int st) {
+        const float* a = smem + st * STAGE + (wm * T::WTM + l31) * BK;
+        const float* b = smem + st * STAGE + BM * BK + (wn * T::WTN + l31) * BK;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int i = 0; i < T::MI; ++i) fra[c][i] = *reinterpret_cast<const float4*>(a + i * MF * BK + qoff[c]);
+#pragma unroll
+            for (int j = 0; j < T::NI; ++j) frb[c][j] = *reinterpret_cast<const float4*>(b + j * MF * BK + qoff[c]);
+        }
+    };
+    // DMA = 2: inline-asm reads, chunk c + 1 requested before chunk c is multiplied
+    const unsigned lds0 = unsigned(reinterpret_cast<uintptr_t>((lds_ptr)smem));
+    auto dma_compute_asm = [&](int st) {
+        const unsigned a = lds0 + unsigned(st * STAGE + (wm * T::WTM + l31) * BK) * 4u;
+        const unsigned b = lds0 + unsigned(st * STAGE + BM * BK + (wn * T::WTN + l31) * BK) * 4u;
+        f32x4 ra[2][T::MI], rb[2][T::NI];
+        auto rd = [&](int c, f32x4 (&xa)[T::MI], f32x4 (&xb)[T::NI]) {
+#pragma unroll
+            for (int i = 0; i < T::MI; ++i) xa[i] = lds_read16(a + unsigned(i * MF * BK + qoff[c]) * 4u);
+#pragma unroll
+            for (int j = 0; j < T::NI; ++j) xb[j] = lds_read16(b + unsigned(j * MF * BK + qoff[c]) * 4u);
+        };
+        rd(0, ra[0], rb[0]);
+        static_for<0, NCH>([&](auto C) {
+            constexpr int c = decltype(C)::value;
+            if constexpr (c + 1 < NCH) {
+                rd(c + 1, ra[(c + 1) & 1], rb[(c + 1) & 1]);
+                wait_lgkmcnt<T::MI + T::NI>();
+            } else {
+                wait_lgkmcnt<0>();
+            }
+            float4 fa[T::MI], fb[T::NI];
+#pragma unroll
+            for (int i = 0; i < T::MI; ++i) fa[i] = make_float4(ra[c & 1][i].x, ra[c & 1][i].y, ra[c & 1][i].z, ra[c & 1][i].w);
+#pragma unroll
+            for (int j = 0; j < T::NI; ++j) fb[j] = make_float4(rb[c & 1][j].x, rb[c & 1][j].y, rb[c & 1][j].z, rb[c & 1][j].w);
+            mfma_chunk(fa, fb);
+            if constexpr (c + 1 < NCH) __builtin_amdgcn_sched_barrier(0);   // the next chunk's wait stays behind these MFMAs
+        });
+    };
+
     const int nk = (p.K + BK - 1) / BK;
-    gload(0, ra0, rb0);
+    if constexpr (!DMA) gload(0, ra0, rb0);
 
     // Epilogue operands.  The products are issued TRANSPOSED -- W fragment as the MFMA's A operand, activation fragment as
     // its B operand -- so the accumulator block holds C^T: lane (m = lane & (MF-1), hi) owns, for ITS output row m, four
@@ -321,14 +472,47 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
             }
     }
 
-    lstore(0, ra0, rb0);
-    if (nk > 1) gload(BK, ra0, rb0);      // tile 1 -> set 0
-    if (nk > 2) gload(2 * BK, ra1, rb1);  // tile 2 -> set 1
-    __syncthreads();
+    if constexpr (DMA) {
+        // after the epilogue operands' loads: vector-memory operations retire in order, and the counted wait of step 0 must
+        // not have younger register loads between itself and tile 0
+        dma_stage(0, 0);
+        if (DMA == 2 && nk > 1) dma_stage(1, 1);
+    } else {
+        lstore(0, ra0, rb0);
+        if (nk > 1) gload(BK, ra0, rb0);      // tile 1 -> set 0
+        if (nk > 2) gload(2 * BK, ra1, rb1);  // tile 2 -> set 1
+        __syncthreads();
+    }
 #ifdef LAMP_TUNING
     const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
+    const unsigned long long c_loop = p.trace ? __builtin_readcyclecounter() : 0ull;   // shader-clock cycles (s_memtime)
 #endif
 
+    if constexpr (DMA == 1) {
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt<0>();                 // tile kt has landed (this wave's pieces; the barrier makes it everyone's)
+            __builtin_amdgcn_s_barrier();    // ... and every wave is past its reads of tile kt - 1, whose stage is refilled below
+            asm volatile("" ::: "memory");
+            dma_read(kt & 1);
+            if (kt + 1 < nk) dma_stage(kt + 1, (kt + 1) & 1);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) mfma_chunk(fra[c], frb[c]);
+        }
+    } else if constexpr (DMA == 2) {
+        // step kt: tile kt in stage kt % 3 (requested two steps ago), tile kt + 1 in flight, tile kt + 2 requested here --
+        // into the stage tile kt - 1 was read from: every wave is past those reads once it has passed this step's barrier
+        // (its MFMAs of step kt - 1 consumed them).  Loads retire in order, so "at most one tile's pieces outstanding" =
+        // this wave's pieces of tile kt have landed; the barrier then makes that true for every wave's pieces.
+        int st = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) wait_vmcnt<PW>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk) dma_stage(kt + 2, st >= 1 ? st - 1 : 2);
+            dma_compute_asm(st);
+            st = st == 2 ? 0 : st + 1;
+        }
+    } else
     for (int kt = 0; kt < nk; kt += 2) {
         // even step: tile kt in LDS[0]; tile kt+1 in set 0, tile kt+2 in set 1
         compute(0);
@@ -344,6 +528,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
     }
 #ifdef LAMP_TUNING
     const unsigned long long t_epi = p.trace ? wall_clock64() : 0ull;
+    const unsigned long long c_epi = p.trace ? __builtin_readcyclecounter() : 0ull;
 #endif
 
     const __amdgpu_buffer_rsrc_t rsC =
@@ -386,7 +571,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
         t[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID (wave / SIMD / CU / SH / SE ids)
         t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
         t[6] = unsigned(item);
-        t[7] = 0;
+        t[7] = c_epi - c_loop;   // main loop in shader cycles: / ((t[2] - t[1]) x 10 ns) = the clock the loop ran at
     }
 #endif
 }
@@ -399,12 +584,12 @@ static size_t g_extra_lds = 0;
 extern "C" __attribute__((visibility("default"))) void lamp_debug_set_gemm_extra_lds(int bytes) { g_extra_lds = size_t(bytes); }
 #endif
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool VEC>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool VEC, int DMA>
 static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
     constexpr bool RPRE = T::MI * T::NI * (MF == 32 ? 16 : 4) <= 16;
-    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC>;
-    size_t LDS = T::LDS_BYTES;
+    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC, DMA>;
+    size_t LDS = DMA ? T::DMA_STAGE_BYTES * (DMA == 1 ? 2 : 3) : T::LDS_BYTES;
     static AttrOnce once;
 #ifdef LAMP_TUNING
     LDS += g_extra_lds;   // residency experiments: more LDS per workgroup = fewer workgroups per CU
@@ -445,14 +630,16 @@ static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     return int(hipGetLastError());
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF = 32>
+// DMA: direct-to-LDS staging; a K that is not a multiple of BK (columns past K must read as zeros, which only the
+// register path's per-element offsets can arrange) takes the register-staged kernel of the same tile -- same bits.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF = 32, int DMA = 0>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
     if (p.vec_epilogue) {
-        if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF, true>(p, s);
-        return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF, true>(p, s);
+        if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF, true, 0>(p, s);
+        return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF, true, DMA>(p, s);
     }
-    if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF, false>(p, s);
-    return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF, false>(p, s);
+    if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF, false, 0>(p, s);
+    return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF, false, DMA>(p, s);
 }
 
 #ifdef LAMP_TUNING
@@ -461,7 +648,7 @@ static int launch_cfg(const GemmParams& p, hipStream_t s) {
 static int g_force_tile = 0;
 static unsigned long long* g_gemm_trace = nullptr;  // n_slabs slabs of slab_words u64: launch i records into slab i % n_slabs,
 static long long g_trace_slab = 0;                  // 8 words per workgroup (entry, loop start, loop end, exit: wall_clock64
-static int g_trace_slabs = 0, g_trace_count = 0;    // ticks; HW_ID; XCC_ID; work item; -)
+static int g_trace_slabs = 0, g_trace_count = 0;    // ticks; HW_ID; XCC_ID; work item; main loop in shader cycles)
 extern "C" __attribute__((visibility("default"))) void lamp_debug_force_gemm_tile(int cfg) { g_force_tile = cfg; }
 extern "C" __attribute__((visibility("default"))) void lamp_debug_set_gemm_trace(unsigned long long* buf, long long slab_words, int n_slabs) {
     g_gemm_trace = buf;
@@ -516,6 +703,27 @@ int launch_gemm(const GemmParams& p_in, hipStream_t s) {
         case 16: return launch_cfg<128, 64, 32, 2, 2, 16>(p, s);
         case 17: return launch_cfg<64, 128, 32, 2, 2, 16>(p, s);
         case 18: return launch_cfg<128, 64, 16, 2, 2, 16>(p, s);
+        // direct-to-LDS staging: 20-29 inline-asm reads + counted vmcnt (DMA = 2), 40-49 the same tiles with compiler-scheduled reads (DMA = 1)
+        case 20: return launch_cfg<32, 64, 32, 1, 4, 16, 2>(p, s);
+        case 21: return launch_cfg<64, 64, 16, 2, 2, 16, 2>(p, s);
+        case 22: return launch_cfg<64, 64, 32, 2, 2, 16, 2>(p, s);
+        case 23: return launch_cfg<128, 64, 16, 2, 2, 16, 2>(p, s);
+        case 24: return launch_cfg<128, 64, 32, 2, 2, 16, 2>(p, s);
+        case 25: return launch_cfg<128, 128, 16, 2, 2, 16, 2>(p, s);
+        case 26: return launch_cfg<128, 128, 32, 2, 2, 16, 2>(p, s);
+        case 27: return launch_cfg<128, 128, 32, 2, 2, 32, 2>(p, s);
+        case 28: return launch_cfg<32, 64, 64, 1, 4, 16, 2>(p, s);
+        case 29: return launch_cfg<64, 64, 64, 2, 2, 16, 2>(p, s);
+        case 40: return launch_cfg<32, 64, 32, 1, 4, 16, 1>(p, s);
+        case 41: return launch_cfg<64, 64, 16, 2, 2, 16, 1>(p, s);
+        case 42: return launch_cfg<64, 64, 32, 2, 2, 16, 1>(p, s);
+        case 43: return launch_cfg<128, 64, 16, 2, 2, 16, 1>(p, s);
+        case 44: return launch_cfg<128, 64, 32, 2, 2, 16, 1>(p, s);
+        case 45: return launch_cfg<128, 128, 16, 2, 2, 16, 1>(p, s);
+        case 46: return launch_cfg<128, 128, 32, 2, 2, 16, 1>(p, s);
+        case 47: return launch_cfg<128, 128, 32, 2, 2, 32, 1>(p, s);
+        case 48: return launch_cfg<32, 64, 64, 1, 4, 16, 1>(p, s);
+        case 49: return launch_cfg<64, 64, 64, 2, 2, 16, 1>(p, s);
         default: break;
     }
 #endif

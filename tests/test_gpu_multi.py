@@ -80,6 +80,24 @@ def test_bench_spawns_its_own_ranks(dev):
     assert r4.returncode != 0
 
 
+def test_bench_and_eval_with_eight_ranks_on_one_device(dev, tmp_path):
+    """The rank count the driver's scaling run uses (batch shards over 8 GPUs), as far as one GPU allows:
+    eight self-spawned ranks over gloo sharing this box's device -- every rank reports, rank 0 recomputes the first samples
+    of ranks 1..7 bit for bit (fixed and ragged batches), and the aggregate is all samples over the slowest rank."""
+    common = ['--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--no-pipelined', '--no-extra-workloads']
+    for extra in ([], ['--ragged']):
+        r, out = _bench(['--gpus', '8'] + extra + common, {'LAMP_BENCH_BACKEND': 'gloo'})
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert out['n_gpus'] == 8 and out['ranks_seen'] == list(range(8)) and len(out['per_rank']) == 8
+        assert out['backend'] == 'gloo' and out['control_plane_ranks'] == 8 and out['physical_devices'] == 1
+        assert out['cross_rank_check']['ranks_checked'] == list(range(1, 8))
+        assert out['cross_rank_check']['bitwise_equal'] is True
+        slowest = max(p['ms_per_step'] for p in out['per_rank'])
+        assert abs(out['value'] - 8 * 32 / (slowest * 1e-3)) < 1e-6 * out['value']
+        if extra:
+            assert len({p['padded_length'] for p in out['per_rank']}) > 1
+
+
 def test_rccl_control_plane_calls_work(dev):
     """bench.py's control plane class with its "nccl" (= RCCL) group -- probe all_reduce, barrier(device_ids), gathers of
     device tensors -- as a one-rank group (RCCL refuses two ranks on one device, so the 2-rank tests above run on gloo)."""
@@ -109,17 +127,17 @@ def test_run_eval_sharded_over_two_ranks_equals_one(dev, tmp_path):
     env = dict(os.environ, LAMP_EVAL_BACKEND='gloo', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
     env.pop('WORLD_SIZE', None)
     outs = []
-    for gpus in (1, 2):
+    for gpus in (1, 2, 8):   # 8: more ranks than batches for some of them -- empty shares must combine cleanly
         r = subprocess.run([sys.executable, '-m', 'lamp_amd.run_eval'] + args + ['-gpus', str(gpus)], capture_output=True,
                            text=True, env=env, timeout=600, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1]))
-    one, two = outs
-    assert one['n_gpus'] == 1 and two['n_gpus'] == 2 and d['n_batches'] >= 2
+    one, two, eight = outs
+    assert one['n_gpus'] == 1 and two['n_gpus'] == 2 and eight['n_gpus'] == 8 and d['n_batches'] >= 2
     assert abs(one['bce_total'] - d['bce_total']) < 2e-5 * d['n_batches']
-    assert abs(two['bce_total'] - one['bce_total']) < 1e-9
+    assert abs(two['bce_total'] - one['bce_total']) < 1e-9 and abs(eight['bce_total'] - one['bce_total']) < 1e-9
     for k in ('subset_accuracy', 'hamming_accuracy', 'example_f1', 'micro_f1', 'macro_f1', 'n_samples'):
-        assert two[k] == one[k], k
+        assert two[k] == one[k] and eight[k] == one[k], k
 
 
 def test_dataparallel_wrapper_is_bitwise_the_plain_call(dev):

@@ -53,10 +53,13 @@ def test_linear_vs_torch_fp64(dev, M, K, N_):
     assert max_abs_diff(N.linear(x.to(dev), w.to(dev)), ref2) < 2e-5
 
 
-@pytest.mark.parametrize('cfg', list(range(1, 19)))
+GEMM_DMA_CFGS = list(range(20, 30)) + list(range(40, 50))   # direct-to-LDS staging: inline-asm reads / compiler reads
+
+
+@pytest.mark.parametrize('cfg', list(range(1, 19)) + GEMM_DMA_CFGS)
 def test_linear_every_tile_config(dev, tuning, cfg):
-    """Every GEMM tile configuration (32x32x2 and 16x16x4 MFMA variants) against fp64, on shapes with
-    ragged M / N edges and a K that is not a multiple of BK (tuning build of the library)."""
+    """Every GEMM tile configuration (32x32x2 and 16x16x4 MFMA variants, register-staged and direct-to-LDS) against
+    fp64, on shapes with ragged M / N edges and a K that is not a multiple of BK (tuning build of the library)."""
     from lamp_amd import _native as N
     force = tuning.lamp_debug_force_gemm_tile
     try:
@@ -70,6 +73,31 @@ def test_linear_every_tile_config(dev, tuning, cfg):
             ref = (x.double() @ w.double().t() + b.double()).clamp_min(0) + r.double()
             out = N.linear(x.to(dev), w.to(dev), b.to(dev), residual=r.to(dev), relu=True, _lib=tuning)
             assert max_abs_diff(out, ref) < 2e-5, (cfg, M, K, N_)
+    finally:
+        force(0)
+
+
+@pytest.mark.parametrize('cfg', GEMM_DMA_CFGS)
+def test_linear_direct_to_lds_staging_is_bit_identical(dev, tuning, cfg):
+    """The direct-to-LDS (LDS-DMA) staging of gemm.hip moves the same values into the same MFMA fragments: results must
+    equal the register-staged kernel bit for bit (every 16x16x4 tile shares one k-order; config 27 is the 32x32x2 tile
+    of config 1).  Shapes: ragged M and N edges, several K steps, one K step, rows past M inside the last row panel."""
+    from lamp_amd import _native as N
+    force = tuning.lamp_debug_force_gemm_tile
+    ref_cfg = 1 if cfg % 20 == 7 else 9
+    try:
+        for M, K, N_ in ((300, 512, 200), (2880, 512, 512), (97, 64, 1536), (1000, 1024, 130), (5, 2048, 64)):
+            g = torch.Generator().manual_seed(cfg * 1000 + M)
+            x = torch.randn(M, K, generator=g).to(dev)
+            w = (torch.randn(N_, K, generator=g) / K ** 0.5).to(dev)
+            b = torch.randn(N_, generator=g).to(dev)
+            r = torch.randn(M, N_, generator=g).to(dev)
+            force(ref_cfg)
+            want = N.linear(x, w, b, residual=r, relu=True, _lib=tuning)
+            force(cfg)
+            for _ in range(3):   # a race between the DMA queue and the fragment reads would not repeat
+                got = N.linear(x, w, b, residual=r, relu=True, _lib=tuning)
+                assert torch.equal(got, want), (cfg, M, K, N_)
     finally:
         force(0)
 
@@ -383,6 +411,30 @@ def test_delicious_batch32_properties_bitwise(dev):
     m.workspace_limit_bytes = 512 << 20   # forces micro-batches inside lamp_forward
     split, enc_split, _ = m((seq, spos), None, None, None)
     assert torch.equal(split, full) and torch.equal(enc_split, enc_full)
+
+
+def test_synthetic4096_micro_batched_share_bitwise(dev):
+    """BASELINE.json configs[4] as one GPU runs it: its 1024-sample share does not fit one pass, lamp_forward walks it in
+    micro-batches carved from the workspace.  Here 16 samples under a squeezed workspace limit (several micro-batches, the
+    last one ragged in size): every sample equals its run in the unsplit batch bit for bit, and samples 0-1 -- the
+    oracle-checked 'synthetic4096_full' pair (same seed, same lengths) -- are within the north-star tolerance of the
+    oracle."""
+    cfg = list(CONFIGS['synthetic4096_full'])
+    cfg[8] = 16
+    cfg[10] = [512, 300] + [512, 77, 410, 512, 3, 256, 512, 129, 500, 64, 512, 511, 33, 200]
+    m, sd, blocked, seq, spos, h = make_case(tuple(cfg), dev)
+    seq, spos = seq.to(dev), spos.to(dev)
+    full, enc_full, _ = m((seq, spos), None, None, None)
+    assert torch.isfinite(full).all()
+    with torch.no_grad():
+        ref, ref_enc, _ = R.forward(sd, seq[:2].cpu(), spos[:2].cpu(), h, blocked)
+    assert max_abs_diff(full[:2], ref) < TOL_LOGIT and max_abs_diff(enc_full[:2], ref_enc) < TOL_ACT
+    for limit_mb in (768, 300):
+        m.workspace_limit_bytes = limit_mb << 20
+        split, enc_split, _ = m((seq, spos), None, None, None)
+        assert torch.equal(split, full) and torch.equal(enc_split, enc_full), limit_mb
+    pair, _, _ = m((seq[:2], spos[:2]), None, None, None)
+    assert torch.equal(pair, full[:2])
 
 
 def test_requested_maps_do_not_change_logits(dev):

@@ -20,6 +20,11 @@ TILES = {0: 'heuristic', 1: '128x128x32', 2: '64x64x32', 3: '128x64x32', 4: '64x
          6: '64x64x16', 7: '128x64x16', 8: '256x128x16(8w)', 9: 'm16:32x64x32',
          10: 'm16:64x32x32', 11: 'm16:64x64x16', 12: 'm16:64x64x32', 13: 'm16:32x128x32',
          14: 'm16:128x128x32', 15: 'm16:128x128x16', 16: 'm16:128x64x32', 17: 'm16:64x128x32', 18: 'm16:128x64x16'}
+_DMA = {0: 'm16:32x64x32', 1: 'm16:64x64x16', 2: 'm16:64x64x32', 3: 'm16:128x64x16', 4: 'm16:128x64x32', 5: 'm16:128x128x16',
+        6: 'm16:128x128x32', 7: '128x128x32', 8: 'm16:32x64x64', 9: 'm16:64x64x64'}
+for _i, _n in _DMA.items():   # direct-to-LDS staging: 20-29 inline-asm reads + counted vmcnt, 40-49 compiler-scheduled reads
+    TILES[20 + _i] = 'A:' + _n.replace('m16:', '')
+    TILES[40 + _i] = 'C:' + _n.replace('m16:', '')
 
 
 def time_fn(fn, iters=30, warm=5):
@@ -75,6 +80,8 @@ def gemm_ab(cfgs=None, rounds=7):
     force.argtypes = [ctypes.c_int]
     force.restype = None
     dev = torch.device('cuda:0')
+    if len(sys.argv) > 2 and cfgs is None:
+        cfgs = [int(c) for c in sys.argv[2].split(',')]
     cfgs = cfgs or [0, 1, 6, 9, 11, 12, 13, 15, 18]
     shapes = [('encFFN 9664x512x512', 9664, 512, 512), ('encKV 9664x1024x512', 9664, 1024, 512),
               ('encKVx2 9664x2048x512', 9664, 2048, 512), ('dec 2880x512x512', 2880, 512, 512),
@@ -312,6 +319,42 @@ def attn():
             print('%-20s mode=%02x mask=%-10s %9.1f us  %6.1f TFLOP/s' % (name, mode, mname, us, fl / us / 1e6))
 
 
+def attn_lib_ab(rounds=9):
+    """A/B of BUILDS of the library (argv[2:]: paths) on the attention shapes of the forwards, heuristic variant, the
+    masks the forward uses (bit-packed label graph for self-attention, none for enc-dec: the padding mask of a full-length
+    batch blocks nothing), round-robin medians in one process."""
+    import statistics
+    libs = [(os.path.basename(p), N.load_library(p)) for p in sys.argv[2:]]
+    dev = torch.device('cuda:0')
+    cases = [('reuters enc-attn', 32, 4, 90, 302, 128, False), ('reuters self', 32, 4, 90, 90, 128, True),
+             ('bibtex enc-attn', 32, 4, 159, 100, 128, False), ('bibtex self', 32, 4, 159, 159, 128, True),
+             ('delicious enc-attn', 32, 8, 983, 40, 128, False), ('delicious self', 32, 8, 983, 983, 128, False),
+             ('synthetic self', 4, 8, 4096, 4096, 128, True), ('synthetic enc', 4, 8, 4096, 512, 128, False)]
+    print('%-22s' % 'shape (median us)' + ''.join('%28s' % n for n, _ in libs))
+    for name, B, H, lq, lk, dk, masked in cases:
+        q = torch.randn(B, lq, H * dk, device=dev)
+        k = torch.randn(B, lk, H * dk, device=dev)
+        v = torch.randn(B, lk, H * dk, device=dev)
+        o = torch.empty(B, lq, H * dk, device=dev)
+        mask = (torch.rand(lq, lk, device=dev) < 0.9).to(torch.uint8)
+        mask[:, 0] = 0
+        bits = N.pack_mask_bits(mask).to(dev)
+        ms = N.Mask(N.LAMP_MASK_BITS_U32, 0, bits.data_ptr(), 0, bits.size(1)) if masked else None
+        lay = N.AttnLayout(lq * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lk * H * dk, dk, H * dk,
+                           lq * H * dk, dk, H * dk)
+        samples = [[] for _ in libs]
+        for _ in range(rounds):
+            for i, (_, lib) in enumerate(libs):
+                def fn():
+                    N.check(lib.lamp_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), None, B, H, lq, lk, dk,
+                                              dk, dk ** -0.5, ctypes.byref(ms) if ms is not None else None,
+                                              ctypes.byref(lay), N.stream()), 'sdpa')
+                samples[i].append(time_fn(fn, iters=20, warm=3))
+        fl = 4.0 * B * H * lq * lk * dk
+        med = [statistics.median(x) for x in samples]
+        print('%-22s' % name + ''.join('%19.1f/%6.1fT ' % (m, fl / m / 1e6) for m in med))
+
+
 def attn_one():
     """One attention shape, heuristic variant, bit-packed shared mask, a handful of launches: small enough for a
     rocprofv3 --pmc pass (tools/pmc_ta.sh).  argv[2] = case name prefix (default 'synthetic self')."""
@@ -489,12 +532,62 @@ def gemm_trace():
         for c in cu:
             per_cu[c] = per_cu.get(c, 0) + 1
         q = lambda a, f: a[min(len(a) - 1, int(f * len(a)))]  # noqa: E731
-        print('%3d %6d %8.2f | %7.2f %7.2f %7.2f    | %7.2f %7.2f   %7.2f %7.2f   %7.2f %7.2f   | %d, %d' %
+        live = rows[rows[:, 2] > rows[:, 1]]
+        ghz = sorted((live[:, 7].double() / ((live[:, 2] - live[:, 1]).double() * tick_ns)).tolist()) if live.numel() else [0.0]
+        print('%3d %6d %8.2f | %7.2f %7.2f %7.2f    | %7.2f %7.2f   %7.2f %7.2f   %7.2f %7.2f   | %d, %d | clock %.2f GHz' %
               (i, len(start), span, q(start, 0.5), q(start, 0.9), start[-1], q(ph[0], 0.5), ph[0][-1], q(ph[1], 0.5),
-               ph[1][-1], q(ph[2], 0.5), ph[2][-1], max(per_cu.values()), len(per_cu)))
+               ph[1][-1], q(ph[2], 0.5), ph[2][-1], max(per_cu.values()), len(per_cu), q(ghz, 0.5)))
+
+
+def gemm_clock():
+    """The shader clock the GEMM main loops actually run at (tuning build: s_memtime cycles of the main loop / its
+    wall_clock64 duration, median over the workgroups of the LAST of 12 back-to-back launches), beside the TFLOP/s of
+    the same shape measured without stamps.  argv[2]: comma-separated tile configurations (default: heuristic)."""
+    import statistics
+    lib = N.lib()
+    hook = lib.lamp_debug_set_gemm_trace
+    hook.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int]
+    hook.restype = None
+    force = lib.lamp_debug_force_gemm_tile
+    force.argtypes = [ctypes.c_int]
+    force.restype = None
+    dev = torch.device('cuda:0')
+    cfgs = [int(c) for c in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0]
+    shapes = [('encFFN 9664x512x512', 9664, 512, 512), ('encKVx2 9664x2048x512', 9664, 2048, 512),
+              ('dec 2880x512x512', 2880, 512, 512), ('delic ffn1 31456x2048x1024', 31456, 2048, 1024),
+              ('delic ffn2 31456x1024x2048', 31456, 1024, 2048), ('syn ffn1 65536x2048x1024', 65536, 2048, 1024),
+              ('sq 4096^3', 4096, 4096, 4096)]
+    slab = 8 * 70000
+    buf = torch.zeros(slab, dtype=torch.int64, device=dev)
+    print('# main-loop clock = s_memtime cycles / wall_clock64 time, median over workgroups; peak 157.3 TFLOP/s is quoted at 2.4 GHz')
+    print('%-30s %-16s %9s %9s %10s %12s' % ('shape', 'tile', 'us', 'TFLOP/s', 'clock GHz', 'TF at 2.4GHz'))
+    for name, M, Nn, K in shapes:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(Nn, K, device=dev) / K ** 0.5
+        b = torch.randn(Nn, device=dev)
+        out = torch.empty(M, Nn, device=dev)
+
+        def fn():
+            N.check(lib.lamp_linear_fwd(x.data_ptr(), M, K, K, w.data_ptr(), Nn, K, b.data_ptr(), None, Nn, 1,
+                                        out.data_ptr(), Nn, N.stream()), 'linear')
+        for c in cfgs:
+            force(c)
+            us = statistics.median(time_fn(fn, iters=8 if M * Nn * K > 1e11 else 30, warm=3) for _ in range(5))
+            buf.zero_()
+            hook(buf.data_ptr(), slab, 1)
+            for _ in range(12):
+                fn()
+            torch.cuda.synchronize()
+            hook(None, 0, 0)
+            t = buf.cpu().view(-1, 8)
+            live = t[(t[:, 3] != 0) & (t[:, 2] > t[:, 1])]
+            ghz = statistics.median((live[:, 7].double() / ((live[:, 2] - live[:, 1]).double() * 10.0)).tolist()) if live.numel() else float('nan')
+            tf = 2.0 * M * Nn * K / us / 1e6
+            print('%-30s %-16s %9.1f %9.1f %10.3f %12.1f' % (name, TILES.get(c, str(c)), us, tf, ghz, tf * 2.4 / ghz if ghz == ghz else float('nan')))
+        force(0)
 
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
     {'gemm': gemm, 'gemm_ab': gemm_ab, 'lib_ab': lib_ab, 'walk': walk, 'walk_pmc': walk_pmc, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
-     'gemm_trace': gemm_trace, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency}[which]()
+     'gemm_trace': gemm_trace, 'gemm_clock': gemm_clock, 'attn_lib_ab': attn_lib_ab, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency}[which]()

@@ -14,7 +14,8 @@ if [ -d "$REV" ]; then cp "$REV"/lamp_amd/csrc/* "$TMP/lamp_amd/csrc/"; cp "$REV
 else
   for f in $(git -C "$ROOT" ls-tree --name-only "$REV" lamp_amd/csrc/ include/); do git -C "$ROOT" show "$REV:$f" > "$TMP/$f"; done
 fi
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden -Wno-unused-result"
+# EXTRA: additional compiler flags of the variant, e.g. EXTRA="-DLAMP_SETPRIO=1" bash tools/build_variant.sh . setprio
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden -Wno-unused-result ${EXTRA:-}"
 OBJS=""
 for src in "$TMP"/lamp_amd/csrc/*.hip; do
   o="$TMP/$(basename "$src" .hip).o"; /opt/rocm/bin/hipcc $FLAGS -c "$src" -o "$o" & OBJS="$OBJS $o"
