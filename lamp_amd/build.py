@@ -21,8 +21,8 @@ OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'liblamp_hip.so')
 LIB_TUNING = os.path.join(HERE, 'liblamp_hip_tuning.so')
 SOURCES = ['gemm.hip', 'gemm_gen.hip', 'attention.hip', 'attention_small.hip', 'attention_general.hip', 'pointwise.hip',
-           'backward.hip', 'api.hip']
-TUNING_SOURCES = {'gemm.hip', 'attention.hip', 'attention_small.hip'}   # the units that contain LAMP_TUNING code
+           'backward.hip', 'chain.hip', 'api.hip']
+TUNING_SOURCES = {'gemm.hip', 'attention.hip', 'attention_small.hip', 'chain.hip'}   # the units that contain LAMP_TUNING code
 HEADERS = [os.path.join(CSRC, 'lamp_kernels.h'), os.path.join(HERE, '..', 'include', 'lamp_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-fvisibility-inlines-hidden', '-Wno-unused-result']
 

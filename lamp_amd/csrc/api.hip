@@ -114,6 +114,18 @@ static inline SeqPlan plan_from(int* ints, int64_t B, int T) {
 }
 static inline bool wide_heads(int dk, int dv) { return dk > 128 || dv > 128; }
 
+// The position-wise feed-forward block that follows an attention block in a decoder layer (lamp/Layers.py:35-36, :40-45):
+// handed to mha_core so that the attention's output projection, its LayerNorm and this block run as ONE launch
+// (chain.hip) when the shape allows.  `done` tells the caller whether that happened.
+struct FfnTail {
+    const lamp_ffn_weights* ffn;
+    int dff;
+    const float* w_out;   // fused read-out of the last decoder block (nullable), as in ffn_core
+    int n_labels;
+    float* logits;
+    bool done;
+};
+
 // MultiHeadAttention.forward (lamp/SubLayers.py:77-121).  `xq_shared`: xq is ONE [lq, d] block used
 // by every sample (decoder layer 0: the label embeddings) -- its projection is then
 // computed once, and the residual is read modulo lq.  `out` may alias xq unless xq_shared.
@@ -122,7 +134,7 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
                     int dv, const lamp_mha_weights& w, const lamp_mask* mask, float* out, float* attn,
                     const MhaScratch& sc, hipStream_t s, bool kv_ready = false,
                     const float* q_ready = nullptr, int P_batch = 0, int P_b0 = 0, const SeqPlan* keys = nullptr,
-                    bool keys_packed = false, const float* xkv_dense = nullptr) {
+                    bool keys_packed = false, const float* xkv_dense = nullptr, FfnTail* tail = nullptr) {
     // keys: per-sample key extents of a key-token mask (ragged batches); keys_packed: xkv holds the packed token rows
     // (keys->rows[0] of them, counted on the device) instead of [B, lk, d]
     const int h = w.n_head;
@@ -208,6 +220,13 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
 
     const int64_t M = int64_t(B) * lq;
     const int64_t r_mod = xq_shared ? lq : 0;
+    if (tail) tail->done = false;
+    if (h > 1 && tail && tail->ffn && chain_applies(M, d, hdv, tail->dff, true)) {
+        // fc (+ residual) -> LayerNorm -> W1 -> W2 (+ residual) -> LayerNorm in one launch over 16-row panels (same bits)
+        tail->done = true;
+        return launch_chain(sc.A, hdv, hdv, xq, r_mod, M, d, w.fc, w.ln_g, w.ln_b, tail->ffn, tail->dff,
+                            tail->w_out ? nullptr : out, tail->w_out, tail->n_labels, tail->logits, s);
+    }
     if (h > 1) {
         const float* W[1] = {w.fc};
         float* C[1] = {out};
@@ -683,26 +702,33 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             }
             // input->label messages (lamp/Layers.py:35); layer 0's query is the label table itself (its LayerNorm
             // kernel adds the shared residual)
+            // the feed-forward block behind each attention block rides in the attention's tail launch when the shape
+            // allows (chain.hip: same bits either way); pos_ffn2 follows the self-attention, or pos_ffn1 when there is none
+            const bool last = i + 1 == m->n_layers_dec;
+            FfnTail t1{&l.pos_ffn1, dff, nullptr, 0, nullptr, false};
+            FfnTail t2{&l.pos_ffn2, dff, last ? m->w_out : nullptr, L, last ? logits + b0 * L : nullptr, false};
             if (i == 0)
                 LAMP_CK(mha_core(m->tgt_word_emb, true, xk, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s,
-                                 ahead, m->dec0_query, B, int(b0), &sp, packed, x));
+                                 ahead, m->dec0_query, B, int(b0), &sp, packed, x, &t1));
             else
                 LAMP_CK(mha_core(Y, false, xk, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s, ahead, nullptr,
-                                 B, int(b0), &sp, packed, x));
-            LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn1, Y, H, s));  // lamp/Layers.py:36
+                                 B, int(b0), &sp, packed, x, &t1));
+            if (!t1.done) LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn1, Y, H, s));  // lamp/Layers.py:36
             if (has_slf) {
                 LAMP_CK(int_pred());  // dec_output_int, lamp/Decoders.py:149-151
                 // label->label messages over the label graph (lamp/Layers.py:40)
                 LAMP_CK(mha_core(Y, false, Y, nb, L, L, d, dk, dv, l.slf_attn, &label_mask, Y, Pslf, sc, s, false, nullptr,
-                                 B, int(b0)));
+                                 B, int(b0), nullptr, false, nullptr, &t2));
             }
-            if (i + 1 < m->n_layers_dec) {
-                LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn2, Y, H, s));  // lamp/Layers.py:45
-                LAMP_CK(int_pred());                                     // all but the last (lamp/Models.py:130)
-            } else {
-                // last layer: the read-out (lamp/Models.py:124-126) is fused into this LayerNorm
-                LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn2, Y, H, s, m->w_out, L, logits + b0 * L));
+            if (!t2.done) {
+                if (!last) {
+                    LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn2, Y, H, s));  // lamp/Layers.py:45
+                } else {
+                    // last layer: the read-out (lamp/Models.py:124-126) is fused into this LayerNorm
+                    LAMP_CK(ffn_core(Y, Md, d, dff, l.pos_ffn2, Y, H, s, m->w_out, L, logits + b0 * L));
+                }
             }
+            if (!last) LAMP_CK(int_pred());                                 // all but the last (lamp/Models.py:130)
         }
     }
     return 0;

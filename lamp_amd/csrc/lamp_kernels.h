@@ -125,6 +125,13 @@ int launch_layernorm(const float* x, int64_t M, int d, const float* g, const flo
                      int n_labels = 0, float* logits = nullptr,  // w_out: fused read-out, y may then be NULL
                      const DropoutSpec* drop = nullptr, const int* m_dev = nullptr, const SeqPlan* scatter = nullptr,
                      int T = 0, float* y_flat = nullptr);
+// chain.hip: the row-local tail of a decoder block -- attention output projection (+ residual) -> LayerNorm [-> FFN ->
+// LayerNorm] -- as ONE launch over 16-row panels, bit-identical to the separate launches.  chain_applies: shape limits
+// (LDS residency, tiling) and the row-count heuristic (at most one panel per CU).
+bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn);
+int launch_chain(const float* A, int64_t lda, int k_h, const float* res, int64_t r_mod, int64_t M, int d, const float* w_fc,
+                 const float* ln1_g, const float* ln1_b, const lamp_ffn_weights* ffn, int dff, float* y, const float* w_out,
+                 int n_labels, float* logits, hipStream_t s);
 size_t layernorm_bwd_workspace_bytes(int64_t M, int d);
 int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_t M, int d, const float* g, float eps,
                          const DropoutSpec* drop, const float* dy, float* dz, float* dz_drop, float* dgamma, float* dbeta,
@@ -215,6 +222,38 @@ __device__ __forceinline__ float wave64_sum(float v) {
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
     const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
     return (r0 + r1) + (r2 + r3);
+}
+
+// LayerNorm arithmetic of ONE row held by one wave as NV float4 per lane (lane l: float4 columns l + 64 i; nv = d / 4 of them
+// are real, the rest zeros).  Shared by layernorm_kernel (pointwise.hip) and the fused decoder chain (chain.hip), with
+// floating-point contraction OFF: what is written is what is computed, in every kernel that inlines it -- the two routes
+// give the same bits (hipcc's fma-contraction choices otherwise differ between instantiations of the same source).
+template <int NV>
+__device__ __forceinline__ void ln_row_stats(const float4 (&v)[NV], int lane, int nv, int d, float eps, float& mean,
+                                             float& rstd) {
+#pragma clang fp contract(off)
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    mean = wave64_sum(s) / float(d);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (lane + i * 64 < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+            ss += (a * a + b * b) + (cc * cc + dd * dd);
+        }
+    }
+    rstd = 1.0f / sqrtf(wave64_sum(ss) / float(d) + eps);
+}
+__device__ __forceinline__ float4 ln_row_apply(float4 v, float mean, float rstd, float4 gg, float4 bb) {
+#pragma clang fp contract(off)
+    return make_float4((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y,
+                       (v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
+}
+__device__ __forceinline__ float dot4_nocontract(float4 o, float4 w) {
+#pragma clang fp contract(off)
+    return (o.x * w.x + o.y * w.y) + (o.z * w.z + o.w * w.w);
 }
 
 // Workgroup id -> work-item id such that each XCD (workgroup b runs on XCD b % 8) gets a CONTIGUOUS range

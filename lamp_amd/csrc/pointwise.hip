@@ -197,7 +197,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     load_row(row);
     const float4* rr = res ? reinterpret_cast<const float4*>(res + (r_mod > 0 ? row % r_mod : row) * d) : nullptr;
-    float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
@@ -206,19 +205,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const float4 w = rr[c];
             v[i].x += w.x; v[i].y += w.y; v[i].z += w.z; v[i].w += w.w;
         }
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
-    const float mean = wave_sum(s) / float(d);
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
-            ss += (a * a + b * b) + (cc * cc + dd * dd);
-        }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(ss) / float(d) + eps);
+    float mean, rstd;
+    ln_row_stats<NV>(v, lane, nv, d, eps, mean, rstd);   // lamp_kernels.h: shared with chain.hip, contraction off
     float4* yr = (y && live) ? reinterpret_cast<float4*>(y + row * d) : nullptr;
     float4* yf = RG == 2 ? reinterpret_cast<float4*>(y2 + flat * d) : nullptr;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -230,15 +219,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            const float4 gg = g4[c], bb = b4[c];
-            const float4 o = make_float4((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
-                                         (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
+            const float4 o = ln_row_apply(v[i], mean, rstd, g4[c], b4[c]);
             if (yr) yr[c] = o;
             if constexpr (RG == 2) yf[c] = o;
-            if (w4) {
-                const float4 ww = w4[c];
-                dot += (o.x * ww.x + o.y * ww.y) + (o.z * ww.z + o.w * ww.w);
-            }
+            if (w4) dot += dot4_nocontract(o, w4[c]);
         }
     }
     if (w4) {

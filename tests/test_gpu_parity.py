@@ -437,6 +437,112 @@ def test_synthetic4096_micro_batched_share_bitwise(dev):
     assert torch.equal(pair, full[:2])
 
 
+@pytest.mark.parametrize('name,B,lengths', [
+    ('reuters_b32', 32, None),                      # the headline shape: 2880 rows = 180 full panels
+    ('reuters_b32_ragged', 32, 'cfg'),
+    ('reuters_fixed', 3, None),                     # 270 rows: 16 full panels and one of 14 rows
+    ('reuters_fixed', 1, None),                     # 90 rows: 5 full panels and one of 10 rows
+    ('inveye_8h', 3, [50, 1, 23]),                  # d_model 256 (one float4 per lane in the LayerNorm), 8 heads, 70 labels
+])
+def test_decoder_chain_launch_is_bit_identical(dev, tuning, monkeypatch, name, B, lengths):
+    """chain.hip: the attention output projection (+ residual), its LayerNorm and the position-wise feed-forward block of a
+    decoder layer as ONE launch over 16-row panels.  lamp_forward picks it from the row count alone, so it must give the
+    bits of the five separate launches: logits, intermediate read-outs and encoder rows with the chain forced on and
+    forced off (tuning build of the library), plus the oracle bar on the forced-on run."""
+    import ctypes
+    from lamp_amd import _native as N
+    cfg = list(CONFIGS[name])
+    cfg[8] = B
+    if lengths != 'cfg':
+        cfg[10] = lengths
+    m, sd, blocked, seq, spos, h = make_case(tuple(cfg), dev)
+    monkeypatch.setattr(N, '_lib', tuning)
+    force = tuning.lamp_debug_force_chain
+    force.argtypes = [ctypes.c_int]
+    force.restype = None
+    src = (seq.to(dev), spos.to(dev))
+    try:
+        force(0)
+        want, enc_want, ip_want = m(src, None, None, None, int_preds=True)
+        force(1)
+        for _ in range(3):   # a race between the W stream's LDS-DMA and the fragment reads would not repeat
+            got, enc_got, ip_got = m(src, None, None, None, int_preds=True)
+            assert torch.equal(got, want) and torch.equal(enc_got, enc_want)
+            assert all(torch.equal(a, b) for a, b in zip(ip_got, ip_want))
+        plain, _, _ = m(src, None, None, None)
+        assert torch.equal(plain, want)
+    finally:
+        force(-1)
+    with torch.no_grad():
+        ref, _, _ = R.forward(sd, seq, spos, h, blocked)
+    assert max_abs_diff(got, ref) < TOL_LOGIT
+
+
+@pytest.mark.parametrize('geometry', [1, 2, 3])
+def test_decoder_chain_every_geometry_is_bit_identical(dev, tuning, monkeypatch, geometry):
+    """The chain kernel's other geometries (waves x columns per wave, register sets of the W stream, LDS slots; tuning build):
+    same fragments, same k-order -- the bits of the separate launches, ragged batch with a partial last panel."""
+    import ctypes
+    from lamp_amd import _native as N
+    cfg = list(CONFIGS['reuters_ragged'])
+    cfg[8], cfg[10] = 5, [302, 20, 150, 77, 201]
+    m, sd, blocked, seq, spos, h = make_case(tuple(cfg), dev)
+    monkeypatch.setattr(N, '_lib', tuning)
+    force, geom = tuning.lamp_debug_force_chain, tuning.lamp_debug_chain_geometry
+    for f in (force, geom):
+        f.argtypes = [ctypes.c_int]
+        f.restype = None
+    src = (seq.to(dev), spos.to(dev))
+    try:
+        force(0)
+        want, _, _ = m(src, None, None, None)
+        force(1)
+        geom(geometry)
+        for _ in range(3):
+            got, _, _ = m(src, None, None, None)
+            assert torch.equal(got, want)
+    finally:
+        force(-1)
+        geom(0)
+
+
+def test_decoder_chain_without_self_attention_and_odd_batches(dev, tuning, monkeypatch):
+    """The chain behind the enc-dec attention of a decoder WITHOUT label self-attention (no_dec_self_att: pos_ffn2 follows
+    pos_ffn1 directly and stays a launch of its own), and the row-count rule of the product library: a batch just below and
+    just above 256 panels gives every sample the same bits."""
+    import ctypes
+    from lamp_amd import _native as N
+    from lamp_amd.Models import LAMP
+    V, L, T, d, dff, h = 500, 90, 40, 512, 512, 4
+    sd = R.make_state_dict(V, L, T, d, dff, h, 2, 2, pos_emb=True, seed=3, no_dec_self_att=True)
+    adj = R.make_adjacency(L, 0.1, 3)
+    m = LAMP(V, L, T, L, n_layers_enc=2, n_layers_dec=2, n_head=h, n_head2=h, d_word_vec=d, d_model=d, d_inner_hid=dff,
+             d_k=d // h, d_v=d // h, encoder='graph', decoder='graph', no_dec_self_att=True,
+             label_adj_matrix=adj.clone(), label_mask='prior', dec_dropout2=False)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    seq, spos = R.make_batch(50, V, T, lengths=[40, 7, 33, 12, 1] * 10, seed=3)
+    seq, spos = seq.to(dev), spos.to(dev)
+    big, _, _ = m((seq, spos), None, None, None)            # 4500 rows = 282 panels: separate launches
+    small, _, _ = m((seq[:45], spos[:45]), None, None, None)  # 4050 rows = 254 panels: the chain
+    assert torch.equal(small, big[:45])
+    monkeypatch.setattr(N, '_lib', tuning)
+    force = tuning.lamp_debug_force_chain
+    force.argtypes = [ctypes.c_int]
+    force.restype = None
+    try:
+        force(0)
+        off, _, _ = m((seq, spos), None, None, None)
+        force(1)
+        on, _, _ = m((seq, spos), None, None, None)
+    finally:
+        force(-1)
+    assert torch.equal(on, off) and torch.equal(on, big)
+    with torch.no_grad():
+        ref, _, _ = R.forward(sd, seq[:4].cpu(), spos[:4].cpu(), h, R.label_block_mask(adj, 'prior', L))
+    assert max_abs_diff(big[:4], ref) < TOL_LOGIT
+
+
 def test_requested_maps_do_not_change_logits(dev):
     """Requested maps come from the same single-pass kernels (scores + row log-sum-exp written on the side): the
     logits do not change by a bit when maps or intermediate predictions are asked for, nor under micro-batching."""

@@ -319,6 +319,88 @@ def attn():
             print('%-20s mode=%02x mask=%-10s %9.1f us  %6.1f TFLOP/s' % (name, mode, mname, us, fl / us / 1e6))
 
 
+def chain():
+    """The decoder chain launch (chain.hip) on its own against the five launches it replaces, same operands: median us of
+    both, and the per-workgroup phase timeline of the chain (tuning build: wall_clock64 stamps after the row load, fc,
+    LayerNorm 1, W1, W2, LayerNorm 2).  argv[2]: rows (default 2880 = reuters batch 32)."""
+    import statistics
+    lib = N.lib()
+    dev = torch.device('cuda:0')
+    M = int(sys.argv[2]) if len(sys.argv) > 2 else 2880
+    d = dff = 512
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(dev)  # noqa: E731
+    A, Y = rnd(M, d), rnd(M, d)
+    wfc, w1, w2 = rnd(d, d) / d ** 0.5, rnd(dff, d) / d ** 0.5, rnd(d, dff) / dff ** 0.5
+    b1, b2 = rnd(dff), rnd(d)
+    g1, be1, g2, be2 = rnd(d), rnd(d), rnd(d), rnd(d)
+    out = torch.empty(M, d, device=dev)
+    H = torch.empty(M, dff, device=dev)
+    tmp = torch.empty(M, d, device=dev)
+    fnc = lib.lamp_debug_launch_chain
+    fnc.restype = ctypes.c_int
+    fnc.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
+                    ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    hook = lib.lamp_debug_set_chain_trace
+    hook.argtypes = [ctypes.c_void_p]
+    hook.restype = None
+
+    def fused():
+        N.check(fnc(A.data_ptr(), d, d, Y.data_ptr(), 0, M, d, wfc.data_ptr(), g1.data_ptr(), be1.data_ptr(), w1.data_ptr(),
+                    b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), g2.data_ptr(), be2.data_ptr(), dff, out.data_ptr(), N.stream()), 'chain')
+
+    def separate():
+        st = N.stream()
+        N.check(lib.lamp_linear_fwd(A.data_ptr(), M, d, d, wfc.data_ptr(), d, d, None, Y.data_ptr(), d, 0, tmp.data_ptr(), d, st), 'fc')
+        N.check(lib.lamp_layernorm_fwd(tmp.data_ptr(), M, d, g1.data_ptr(), be1.data_ptr(), 1e-5, tmp.data_ptr(), st), 'ln1')
+        N.check(lib.lamp_linear_fwd(tmp.data_ptr(), M, d, d, w1.data_ptr(), dff, d, b1.data_ptr(), None, 0, 1, H.data_ptr(), dff, st), 'w1')
+        N.check(lib.lamp_linear_fwd(H.data_ptr(), M, dff, dff, w2.data_ptr(), d, dff, b2.data_ptr(), tmp.data_ptr(), d, 0, tmp.data_ptr(), d, st), 'w2')
+        N.check(lib.lamp_layernorm_fwd(tmp.data_ptr(), M, d, g2.data_ptr(), be2.data_ptr(), 1e-5, tmp.data_ptr(), st), 'ln2')
+    geom = lib.lamp_debug_chain_geometry
+    geom.argtypes = [ctypes.c_int]
+    geom.restype = None
+    GEOMS = {0: '8 waves x 64 cols, 2 reg sets, 1 slot', 1: '8 x 32, 4 sets, 2 slots', 2: '8 x 32, 2 sets, 2 slots',
+             3: '8 x 32, 4 sets, 1 slot'}
+    separate()
+    for gi in sorted(GEOMS):
+        geom(gi)
+        out.zero_()
+        fused()
+        torch.cuda.synchronize()
+        print('# geometry %d (%s): bitwise equal to the five launches: %s' % (gi, GEOMS[gi], torch.equal(out, tmp)))
+    b = [time_fn(separate, iters=20, warm=3) for _ in range(9)]
+    print('five launches %.1f us' % statistics.median(b))
+    for _ in range(2):
+        for gi in sorted(GEOMS):
+            geom(gi)
+            print('chain launch, geometry %d (%s): %.1f us' % (gi, GEOMS[gi], statistics.median(time_fn(fused, iters=20, warm=3) for _ in range(7))))
+    geom(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+    n_wg = (M + 15) // 16
+    buf = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
+    for _ in range(5):
+        fused()
+    hook(buf.data_ptr())
+    fused()
+    torch.cuda.synchronize()
+    hook(None)
+    t = buf.cpu().view(n_wg, 8).double()
+    t0 = t[:, 0].min()
+    ghz = (t[:, 6] / ((t[:, 5] - t[:, 0]) * 10.0)).median().item()
+    print('# shader clock during the chain (s_memtime cycles / wall_clock64 time, median over workgroups): %.3f GHz' % ghz)
+    names = ['rows in LDS', 'fc', 'LayerNorm 1', 'W1', 'W2', 'LayerNorm 2 / exit']
+    q = lambda v, f: sorted(v.tolist())[min(len(v) - 1, int(f * len(v)))]  # noqa: E731
+    print('# per-workgroup timeline (us, wall_clock64): time of the stamp since the first workgroup\'s first stamp, and phase length')
+    prev = None
+    for i, nm in enumerate(names):
+        at = (t[:, i] - t0) * 0.01
+        line = '%-20s at p50 %6.2f max %6.2f' % (nm, q(at, 0.5), at.max().item())
+        if prev is not None:
+            ph = (t[:, i] - prev) * 0.01
+            line += '   phase p50 %6.2f max %6.2f' % (q(ph, 0.5), ph.max().item())
+        print(line)
+        prev = t[:, i]
+
+
 def attn_lib_ab(rounds=9):
     """A/B of BUILDS of the library (argv[2:]: paths) on the attention shapes of the forwards, heuristic variant, the
     masks the forward uses (bit-packed label graph for self-attention, none for enc-dec: the padding mask of a full-length
@@ -590,4 +672,4 @@ def gemm_clock():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
     {'gemm': gemm, 'gemm_ab': gemm_ab, 'lib_ab': lib_ab, 'walk': walk, 'walk_pmc': walk_pmc, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
-     'gemm_trace': gemm_trace, 'gemm_clock': gemm_clock, 'attn_lib_ab': attn_lib_ab, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency}[which]()
+     'gemm_trace': gemm_trace, 'gemm_clock': gemm_clock, 'attn_lib_ab': attn_lib_ab, 'chain': chain, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency}[which]()
