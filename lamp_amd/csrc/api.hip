@@ -110,7 +110,7 @@ struct MhaScratch {
 };
 static inline size_t plan_int_count(int64_t B, int T) { return size_t(3) * size_t(B) + 3 + size_t(B) * size_t((T + 31) / 32); }
 static inline SeqPlan plan_from(int* ints, int64_t B, int T) {
-    return SeqPlan{ints, ints + B, ints + 2 * B, ints + 3 * B + 1, reinterpret_cast<unsigned*>(ints + 3 * B + 3), (T + 31) / 32};
+    return SeqPlan{ints, ints + B, ints + 2 * B, ints + 3 * B + 1, reinterpret_cast<unsigned*>(ints + 3 * B + 3), (T + 31) / 32, nullptr};
 }
 static inline bool wide_heads(int dk, int dv) { return dk > 128 || dv > 128; }
 
@@ -571,6 +571,9 @@ static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
     // FFN hidden buffer for it, and the SeqPlan's 3 mb + 3 ints
     pl->per_sample_floats += size_t(T) * m->d_model + 3 + size_t((T + 31) / 32);
     pl->fixed_floats += size_t(m->d_model) + size_t(m->d_inner) + 64 * 3 + 4;
+    // the plan's hand-off granules inside the merged plan + gather launch: 2 mb + 2 eight-byte words
+    pl->per_sample_floats += 4;
+    pl->fixed_floats += 4 + 64;
     // K/V of all decoder layers' enc-attention, projected together right after the encoder when the batch fits
     pl->side_kv_floats = size_t(m->n_layers_dec) * T * (pl->hdk + pl->hdv);
     return 0;
@@ -609,6 +612,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
     const int Rq = want_enc_attn ? pl.R : L;
     float *H = nullptr, *Y = nullptr, *Xp = nullptr;
     int* plan_ints = nullptr;
+    unsigned long long* granules = nullptr;
     float* Kahead[MAX_AHEAD_LAYERS] = {};
     float* Vahead[MAX_AHEAD_LAYERS] = {};
     MhaScratch sc{};
@@ -624,6 +628,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         Y = c.take(size_t(mb) * L * d);
         Xp = c.take(size_t(mb) * T * d + d);
         plan_ints = reinterpret_cast<int*>(c.take(plan_int_count(mb, T)));
+        granules = reinterpret_cast<unsigned long long*>(c.take(size_t(4) * mb + 4));
         for (int i = 0; i < n_ahead; ++i) {
             Kahead[i] = c.take(size_t(mb) * T * pl.hdk);
             Vahead[i] = c.take(size_t(mb) * T * pl.hdv);
@@ -639,17 +644,20 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         const int64_t* pos = src_pos ? src_pos + b0 * T : nullptr;
         float* x = enc_output + b0 * int64_t(T) * d;  // the padded encoder output of this micro-batch
         const int64_t Me = int64_t(nb) * T;
-        const SeqPlan sp = plan_from(plan_ints, nb, T);
-        // (one launch of its own: folding the plan into every workgroup of the embedding gather measured slower -- 21.9 us
-        // against 6.6 + 10.5 -- and a dependent launch costs 5-7 us on this chain however little it does)
-        LAMP_CK(launch_seq_plan(seq, m->position_enc ? pos : nullptr, nb, T, T, packed, sp, s));
+        SeqPlan sp = plan_from(plan_ints, nb, T);
+        sp.granules = packed ? granules : nullptr;
+        // Packed layout: the plan rides in the first workgroups of the embedding gather's launch and hands its results to the
+        // gather through 8-byte granules (pointwise.hip: embed_plan_kernel; round 3 had it as a launch of its own -- a
+        // dependent launch costs 5-8 us on this chain however little it does -- after folding it into EVERY workgroup of
+        // the gather had measured slower, 21.9 us against 6.6 + 10.5).  Padded layout: the plan kernel on its own.
+        if (!packed) LAMP_CK(launch_seq_plan(seq, m->position_enc ? pos : nullptr, nb, T, T, packed, sp, s));
 
         // ---- GraphEncoder.forward (lamp/Encoders.py:64-110) ----
         lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq, T, 0, nullptr, 0};
         const float* xk = x;  // what the decoder's K / V projections read
         if (packed) {
-            LAMP_CK(launch_embed_packed(seq, pos, nb, T, m->src_word_emb, m->n_src_vocab, m->position_enc, m->n_position, d,
-                                        sp, Xp, s));
+            LAMP_CK(launch_embed_plan(seq, pos, m->position_enc != nullptr, nb, T, m->src_word_emb, m->n_src_vocab,
+                                      m->position_enc, m->n_position, d, sp, granules, Xp, s));
             for (int i = 0; i < m->n_layers_enc; ++i) {
                 const bool last = i + 1 == m->n_layers_enc;
                 LAMP_CK(ffn_core(Xp, Me + 1, d, dff, m->enc_layers[i].pos_ffn, Xp, H, s, nullptr, 0, nullptr, sp.rows + 1,

@@ -111,11 +111,17 @@ struct SeqPlan {
     int* rows;  // [2]      n_tok, and n_tok + 1 when the shared PAD row (row n_tok) is live
     unsigned* padbits;  // [nb][words] bit-packed key mask: bit j of word j / 32 set = position j holds a PAD token
     int words;          // (T + 31) / 32
+    unsigned long long* granules;   // nullable: the 2 nb + 2 hand-off words of embed_plan_kernel, zeroed again by the last encoder
+                                    // LayerNorm of the forward (a replayed HIP graph repeats the launch's epoch: no stale match)
 };
 int launch_seq_plan(const int64_t* seq, const int64_t* pos, int nb, int T, int64_t seq_stride, bool packed,
                     const SeqPlan& sp, hipStream_t s);
 int launch_embed_packed(const int64_t* seq, const int64_t* pos, int nb, int T, const float* emb, int n_vocab,
                         const float* pos_table, int n_position, int d, const SeqPlan& sp, float* out, hipStream_t s);
+// the two above (packed layout) as ONE launch; granules: 2 * nb + 2 unsigned 64-bit words of workspace, any content
+int launch_embed_plan(const int64_t* seq, const int64_t* pos, bool plan_uses_pos, int nb, int T, const float* emb, int n_vocab,
+                      const float* pos_table, int n_position, int d, const SeqPlan& sp, unsigned long long* granules, float* out,
+                      hipStream_t s);
 
 // y = LayerNorm(dropout(x) + residual[row % r_mod or row])   (residual nullable; r_mod 0 = per-row residual; drop nullable)
 // m_dev: live row count in device memory (M sizes the launch).  scatter (+ T, y_flat): the last LayerNorm of the packed

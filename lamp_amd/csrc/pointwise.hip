@@ -1,5 +1,7 @@
 // Bandwidth-bound pieces of the path: embedding gather (+ position add), LayerNorm, diagonal
 // label read-out.  One 64-lane wave per row, 16-byte accesses per lane, four rows per workgroup.
+#include <atomic>
+
 #include "lamp_kernels.h"
 
 namespace lamp {
@@ -33,6 +35,42 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
     }
 }
 
+// One sample's extents, by one wave (see seq_plan_kernel): kl = 1 + its last non-PAD token, pl >= kl additionally covers the
+// positions that carry a position index; writes the sample's bit-packed key mask.  The sample's 64-position chunks are
+// fetched eight at a time -- sixteen loads in flight before the first ballot, from clamped addresses (a guarded load compiles
+// to a branch plus a full s_waitcnt per element, which would serialise the round trips again) -- so a sample of up to 512
+// positions costs ONE memory round trip.
+__device__ __forceinline__ void plan_scan_sample(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos, int b, int T,
+                                                 int64_t seq_stride, const SeqPlan& sp, int lane, int& kl, int& pl) {
+    constexpr int GROUP = 8;
+    const int64_t* pos_or_seq = pos ? pos : seq;   // always a loadable address: no branch around the load
+    const int64_t row0 = int64_t(b) * seq_stride;
+    kl = 0;
+    pl = 0;
+    for (int base = 0; base < T; base += 64 * GROUP) {
+        int64_t tok[GROUP], ps[GROUP];
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) {
+            const int j = base + 64 * u + lane;
+            const int64_t at = row0 + (j < T ? j : 0);
+            tok[u] = seq[at];
+            ps[u] = pos_or_seq[at];
+        }
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) {
+            const int c0 = base + 64 * u, j = c0 + lane;
+            const bool t = j < T && tok[u] != 0;
+            const bool a = t || (pos && j < T && ps[u] != 0);
+            const unsigned long long mt = __ballot(t), ma = __ballot(a);
+            if (mt) kl = c0 + 64 - __builtin_clzll(mt);
+            if (ma) pl = c0 + 64 - __builtin_clzll(ma);
+            // bit-packed key mask of this sample (bit = PAD token = blocked key; positions past T count as PAD)
+            if (lane < 2 && c0 / 32 + lane < sp.words)
+                sp.padbits[int64_t(b) * sp.words + c0 / 32 + lane] = ~unsigned(mt >> (32 * lane));
+        }
+    }
+}
+
 // Per-sample extents of a (possibly ragged) token batch, counted on the device -- no host round trip (SeqPlan,
 // lamp_kernels.h).  klen[b] = 1 + the last position whose token is not PAD: keys past it are exactly masked
 // (lamp/utils.py:26-34), so the enc-dec attention stops there.  plen[b] >= klen[b] additionally covers every position
@@ -45,37 +83,10 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
 // tokens (LAMP_MASK_BITS_U32 with a zero query stride).  ONE workgroup: a wave per sample, then a wave-level prefix sum.
 __global__ __launch_bounds__(1024) void seq_plan_kernel(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
                                                         int nb, int T, int64_t seq_stride, int packed, SeqPlan sp) {
-    // A wave per sample; the sample's 64-position chunks are fetched eight at a time -- sixteen loads in flight before the
-    // first ballot, from clamped addresses (a guarded load compiles to a branch plus a full s_waitcnt per element, which
-    // would serialise the round trips again) -- so a sample of up to 512 positions costs ONE memory round trip.
-    constexpr int GROUP = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    const int64_t* pos_or_seq = pos ? pos : seq;   // always a loadable address: no branch around the load
     for (int b = wave; b < nb; b += nwave) {
-        const int64_t row0 = int64_t(b) * seq_stride;
-        int kl = 0, pl = 0;
-        for (int base = 0; base < T; base += 64 * GROUP) {
-            int64_t tok[GROUP], ps[GROUP];
-#pragma unroll
-            for (int u = 0; u < GROUP; ++u) {
-                const int j = base + 64 * u + lane;
-                const int64_t at = row0 + (j < T ? j : 0);
-                tok[u] = seq[at];
-                ps[u] = pos_or_seq[at];
-            }
-#pragma unroll
-            for (int u = 0; u < GROUP; ++u) {
-                const int c0 = base + 64 * u, j = c0 + lane;
-                const bool t = j < T && tok[u] != 0;
-                const bool a = t || (pos && j < T && ps[u] != 0);
-                const unsigned long long mt = __ballot(t), ma = __ballot(a);
-                if (mt) kl = c0 + 64 - __builtin_clzll(mt);
-                if (ma) pl = c0 + 64 - __builtin_clzll(ma);
-                // bit-packed key mask of this sample (bit = PAD token = blocked key; positions past T count as PAD)
-                if (lane < 2 && c0 / 32 + lane < sp.words)
-                    sp.padbits[int64_t(b) * sp.words + c0 / 32 + lane] = ~unsigned(mt >> (32 * lane));
-            }
-        }
+        int kl, pl;
+        plan_scan_sample(seq, pos, b, T, seq_stride, sp, lane, kl, pl);
         if (lane == 0) {
             sp.klen[b] = kl;
             sp.plen[b] = packed ? pl : T;
@@ -144,6 +155,168 @@ __global__ __launch_bounds__(256) void embed_packed_kernel(const int64_t* __rest
     }
 }
 
+// The sequence plan AND the packed embedding gather in ONE launch (round 4: a dependent launch costs 5-8 us on this chain
+// whatever it does -- the one-workgroup plan kernel was 7.9 us in front of a 10.7 us gather).
+//   * workgroups 0 .. n_plan - 1 are the plan: a wave per sample computes (klen, plen, key-mask bits) exactly as
+//     seq_plan_kernel and publishes plen[b] as an 8-byte granule {plen, epoch} with ONE agent-scope atomic store; wave 0 of
+//     workgroup 0 then collects the granules, takes the prefix sum and publishes {off[b], epoch} the same way (and writes the
+//     plain SeqPlan arrays the LATER kernels read).
+//   * every other workgroup is four positions of the gather, as embed_packed_kernel: it requests its token first, then
+//     polls the two granules of its sample (relaxed agent-scope 8-byte loads: no fence, no flag -- the tag IS the data's
+//     validity; MI355X_MICROARCH.md "handoff-1to1"), and goes on with plen / off.  `epoch` is unique per launch, so a
+//     granule left in the workspace by an earlier launch (or by nothing at all) never matches.
+// Workgroups are dispatched in index order, so the plan is resident before any gather workgroup can wait for it; should a
+// granule not arrive within ~1 s of polling, the wave computes what it needs itself (plan_scan_sample over the samples up
+// to its own): slow, correct, and independent of any dispatch order.
+struct PlanGranules {
+    unsigned long long* plen;   // [nb]
+    unsigned long long* off;    // [nb + 2]: off[b]; [nb] = n_tok; [nb + 1] = 1 when some position is skipped
+    unsigned epoch;
+};
+__device__ __forceinline__ void granule_put(unsigned long long* g, unsigned v, unsigned epoch) {
+    __hip_atomic_store(g, (static_cast<unsigned long long>(epoch) << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// -> true and v when the granule carries this launch's epoch
+__device__ __forceinline__ bool granule_try(const unsigned long long* g, unsigned epoch, unsigned& v) {
+    const unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = unsigned(x);
+    return unsigned(x >> 32) == epoch;
+}
+
+__global__ __launch_bounds__(256) void embed_plan_kernel(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
+                                                         const int64_t* __restrict__ plan_pos, int nb, int T,
+                                                         const float* __restrict__ emb, int n_vocab,
+                                                         const float* __restrict__ pos_table, int n_position, int d,
+                                                         SeqPlan sp, PlanGranules gr, int n_plan, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (int(blockIdx.x) < n_plan) {
+        for (int b = int(blockIdx.x) * 4 + wave; b < nb; b += n_plan * 4) {
+            int kl, pl;
+            plan_scan_sample(seq, plan_pos, b, T, T, sp, lane, kl, pl);
+            if (lane == 0) {
+                sp.klen[b] = kl;
+                sp.plen[b] = pl;
+                granule_put(gr.plen + b, unsigned(pl), gr.epoch);
+            }
+        }
+        if (blockIdx.x != 0 || wave != 0) return;
+        // the prefix sum over the samples' rows, 64 samples at a time
+        int carry = 0;
+        bool skipped = false;
+        for (int base = 0; base < nb; base += 64) {
+            const int b = base + lane;
+            unsigned v = 0;
+            bool ok = b >= nb;
+            while (!__all(ok)) {
+                if (!ok) ok = granule_try(gr.plen + b, gr.epoch, v);
+                if (!ok) __builtin_amdgcn_s_sleep(1);
+            }
+            const int pl = b < nb ? int(v) : 0;
+            skipped = skipped || (b < nb && pl < T);
+            int incl = pl;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const int u = __shfl_up(incl, dd, 64);
+                if (lane >= dd) incl += u;
+            }
+            if (b < nb) {
+                sp.off[b] = carry + incl - pl;
+                granule_put(gr.off + b, unsigned(carry + incl - pl), gr.epoch);
+            }
+            carry += __shfl(incl, 63, 64);
+        }
+        const bool any_skipped = __any(skipped);
+        if (lane == 0) {
+            sp.off[nb] = carry;
+            sp.rows[0] = carry;
+            sp.rows[1] = carry + (any_skipped ? 1 : 0);
+            granule_put(gr.off + nb, unsigned(carry), gr.epoch);
+            granule_put(gr.off + nb + 1, any_skipped ? 1u : 0u, gr.epoch);
+        }
+        return;
+    }
+    const int nwg = int(gridDim.x) - n_plan;
+    const int64_t flat = int64_t(xcd_remap(int(blockIdx.x) - n_plan, nwg)) * 4 + wave;
+    const int64_t n_flat = int64_t(nb) * T;
+    if (flat > n_flat) return;
+    const bool pad_row = flat == n_flat;
+    const int b = pad_row ? 0 : int(flat / T), j = pad_row ? 0 : int(flat - int64_t(b) * T);
+    // the token first (its round trip overlaps the wait for the plan), then this sample's granules
+    int64_t tok = pad_row ? 0 : seq[flat];
+    int64_t ps = (pos_table && !pad_row) ? pos[flat] : 0;
+    const unsigned long long* ga = pad_row ? gr.off + nb + 1 : gr.plen + b;   // plen[b]  | any position skipped
+    const unsigned long long* gb = pad_row ? gr.off + nb : gr.off + b;        // off[b]   | n_tok
+    unsigned va = 0, vb = 0;
+    bool ok = false;
+    {
+        // Dense batch?  Every sample whose LAST position holds a token (or a position index) has plen = T; if that is all of
+        // them nothing is skipped, off[b] = b T, and the gather needs nothing from the plan -- the fixed-length case pays
+        // one more load beside the token's instead of the hand-off's round trips.
+        bool dense = true;
+        for (int base = 0; base < nb; base += 64) {
+            const int bb = base + lane;
+            const int64_t at = int64_t(bb < nb ? bb : 0) * T + (T - 1);
+            const int64_t lt = seq[at], lp = plan_pos ? plan_pos[at] : 0;
+            dense = dense && __all(bb >= nb || lt != 0 || lp != 0);
+        }
+        if (dense) {
+            va = pad_row ? 0u : unsigned(T);
+            vb = pad_row ? unsigned(n_flat) : unsigned(b) * unsigned(T);
+            ok = true;
+        }
+    }
+    for (int spin = 0; spin < (1 << 20) && !ok; ++spin) {
+        unsigned ta = 0, tb = 0;
+        bool ka = false, kb = false;
+        if (lane == 0) {
+            ka = granule_try(ga, gr.epoch, ta);
+            kb = granule_try(gb, gr.epoch, tb);
+        }
+        ok = __builtin_amdgcn_readfirstlane(int(ka && kb)) != 0;
+        va = unsigned(__builtin_amdgcn_readfirstlane(int(ta)));
+        vb = unsigned(__builtin_amdgcn_readfirstlane(int(tb)));
+        if (!ok) __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok) {
+        // no plan in sight (never observed; see the header): this wave's own count of what it needs
+        int sum = 0, mine = 0;
+        bool skipped = false;
+        const int upto = pad_row ? nb : b + 1;
+        SeqPlan scratch = sp;
+        for (int bb = 0; bb < upto; ++bb) {
+            int kl, pl;
+            plan_scan_sample(seq, plan_pos, bb, T, T, scratch, lane, kl, pl);   // (rewrites the same key-mask words: benign)
+            if (bb == b) mine = pl;
+            if (bb < upto - (pad_row ? 0 : 1)) sum += pl;
+            skipped = skipped || pl < T;
+        }
+        va = pad_row ? (skipped ? 1u : 0u) : unsigned(mine);
+        vb = unsigned(sum);
+    }
+    int64_t dst;
+    if (pad_row) {
+        if (va == 0) return;   // no position skipped: no PAD row
+        dst = int64_t(vb);
+    } else {
+        if (j >= int(va)) return;
+        dst = int64_t(vb) + j;
+    }
+    const bool okt = tok >= 0 && tok < n_vocab && ps >= 0 && (!pos_table || ps < n_position);
+    const float4* e = reinterpret_cast<const float4*>(emb + (okt ? tok : 0) * d);
+    const float4* q = pos_table ? reinterpret_cast<const float4*>(pos_table + (okt ? ps : 0) * d) : nullptr;
+    float4* o = reinterpret_cast<float4*>(out + dst * d);
+    const float nan = __builtin_nanf("");
+    for (int c = lane; c < d / 4; c += 64) {
+        float4 v = e[c];
+        if (q) {
+            const float4 w = q[c];
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        if (!okt) v = make_float4(nan, nan, nan, nan);
+        o[c] = v;
+    }
+}
+
 // y = (x - mean) / sqrt(var_biased + eps) * g + b over the last dim.  Two-pass (mean, then centred
 // sum of squares) on a register-resident row; NV float4 per lane.
 // RG (ragged encoder, packed rows -- see seq_plan_kernel):  0 = plain rows 0 .. M-1.  1 = the row count comes from device
@@ -184,6 +357,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         row = int64_t(xcd_remap(blockIdx.x, nblk)) * 4 + (threadIdx.x >> 6);
         if (row >= Mrt) return;
     } else if constexpr (RG == 2) {
+        if (sp.granules && blockIdx.x == 0)   // embed_plan_kernel's hand-off words: spent, back to "no epoch"
+            for (int i = threadIdx.x; i < 2 * int(M / T) + 2; i += 256) sp.granules[i] = 0ull;
         flat = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);
         if (flat >= M) return;
         const int b = int(flat / T), j = int(flat - int64_t(b) * T);
@@ -394,6 +569,30 @@ int launch_embed_packed(const int64_t* seq, const int64_t* pos, int nb, int T, c
     ProfScope prof(LAMP_K_EMBED, 0.0, double(n_tok) * (16.0 + 4.0 * d * (pos_table ? 3 : 2)), s);
     hipLaunchKernelGGL(embed_packed_kernel, dim3(g), dim3(256), 0, s, seq, pos, nb, T, emb, n_vocab, pos_table,
                        n_position, d, sp, out);
+    return int(hipGetLastError());
+}
+
+// Plan + packed gather in one launch (embed_plan_kernel).  `granules`: 2 * nb + 2 unsigned 64-bit words of workspace, any content.
+int launch_embed_plan(const int64_t* seq, const int64_t* pos, bool plan_uses_pos, int nb, int T, const float* emb, int n_vocab,
+                      const float* pos_table, int n_position, int d, const SeqPlan& sp, unsigned long long* granules, float* out,
+                      hipStream_t s) {
+    if (nb <= 0 || T <= 0 || d <= 0 || n_vocab <= 0) return LAMP_E_DIMS;
+    if (d & 3) return LAMP_E_UNSUPPORTED;
+    if (!seq || !emb || !out || !granules || (pos_table && !pos) || (plan_uses_pos && !pos)) return LAMP_E_NULL;
+    if (!aligned16(emb) || !aligned16(out) || (pos_table && !aligned16(pos_table)) || (reinterpret_cast<uintptr_t>(granules) & 7u))
+        return LAMP_E_ALIGN;
+    if (!sp.klen || !sp.plen || !sp.off || !sp.rows || !sp.padbits) return LAMP_E_NULL;
+    unsigned g;
+    const int64_t n_tok = int64_t(nb) * T;
+    if (int e = grid4(n_tok + 1, &g)) return e;
+    const int n_plan = nb <= 4 ? 1 : (nb + 3) / 4 < 64 ? (nb + 3) / 4 : 64;   // a wave per sample up to 256 samples, then several each
+    static std::atomic<unsigned> epoch_counter{0x5eed0001u};
+    unsigned epoch = epoch_counter.fetch_add(1, std::memory_order_relaxed);
+    if (epoch == 0) epoch = epoch_counter.fetch_add(1, std::memory_order_relaxed);
+    PlanGranules gr{granules, granules + nb, epoch};
+    ProfScope prof(LAMP_K_EMBED, 0.0, double(n_tok) * (32.0 + 4.0 * d * (pos_table ? 3 : 2)), s);
+    hipLaunchKernelGGL(embed_plan_kernel, dim3(g + unsigned(n_plan)), dim3(256), 0, s, seq, pos, plan_uses_pos ? pos : nullptr, nb, T, emb,
+                       n_vocab, pos_table, n_position, d, sp, gr, n_plan, out);
     return int(hipGetLastError());
 }
 
