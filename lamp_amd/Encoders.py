@@ -4,8 +4,10 @@ GraphEncoder (lamp/Encoders.py:31-110) is the hot path: token (+ sinusoid positi
 EncoderLayers on the HIP kernels.  ``enc_transform`` pooling (:96-105) is a cheap reduction of its output, done in
 PyTorch on the device.  MLPEncoder (:16-27) and RNNEncoder (:112-137) are the reference's baseline models (SURVEY.md
 8f n4): plain PyTorch modules with the reference's parameter names and shapes, so every ``main.py -encoder`` choice
-constructs and reference checkpoints load; they run wherever their tensors live.  The genomics one-hot/conv branch
-and the per-sample ``adj`` branch stay outside the scope (they raise).
+constructs and reference checkpoints load; they run wherever their tensors live.  Per-sample input graphs (``adj``,
+:81-85) only shape the encoder's attention maps -- its attention OUTPUT is dead compute -- and are served as a generic
+uint8 mask on the module-by-module route when maps are requested (logits identical either way).  The genomics
+one-hot/conv branch stays outside the scope (it raises at construction).
 """
 import torch
 import torch.nn as nn

@@ -51,8 +51,12 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // 2 the raw scaled scores (log2 domain, -inf where blocked) into the map buffer plus each row's log2-sum-exp --
 // the single-pass kernel at full speed; softmax_from_scores_kernel then turns the scores into probabilities in
 // place (training forward: the maps are needed for the backward pass).
+// Two waves per SIMD for the variants that fit 240 registers.  The map-writing variants need the registers for their
+// addresses, and the key-token variant (MK = LAMP_MASK_KEY_TOKENS_I64: 32 raw token registers per tile; only bare
+// lamp_sdpa_fwd callers reach it -- lamp_forward and lamp_mha_fwd hand the kernels the plan's bit-packed copy) spilled
+// 13-18 instructions to scratch under that bound through round 3: both are built for one wave per SIMD, spill-free.
 template <int DP, int KSPLIT, int PM, int MK>
-__global__ __launch_bounds__(256, PM == 0 ? 2 : 1) void attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (PM == 0 && MK != LAMP_MASK_KEY_TOKENS_I64) ? 2 : 1) void attn_kernel(AttnParams p) {
     constexpr bool WRITE_P = PM == 1;
     static_assert(!WRITE_P || KSPLIT == 1, "probability write-out uses unsplit keys");
     constexpr int DKC = DP / 8, DVB = DP / 32, QB = 4 / KSPLIT, QS = DP + 4;

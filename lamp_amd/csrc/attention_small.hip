@@ -23,6 +23,14 @@
 
 namespace lamp {
 
+// LDS row padding of the Q block / K tiles: 8 floats.  With 4 (rounds 2-3) the sixteen lanes ds_read_b128 serves together
+// -- rows 0-3 and 12-15 at one k-quad, rows 4-11 at the next (MI355X_MICROARCH.md, LDS lane groups) -- met two by two on a
+// 16-byte slot: 29 % of the kernel's LDS cycles were bank conflicts (profiles/r02_attn_ta_pmc.txt); with 8 none do.
+#ifndef LAMP_LDS_PAD16
+#define LAMP_LDS_PAD16 8
+#endif
+constexpr int ATTN16_PAD = LAMP_LDS_PAD16;
+
 namespace {
 // Exchange across the four lane groups of a query (lanes l, l^16, l^32, l^48) with gfx950's row-swap instructions instead
 // of __shfl_xor (= ds_bpermute through the LDS crossbar, ~100 cycles a step):
@@ -66,7 +74,7 @@ template <int DP, int QB, int KSPLIT, int PM, int MK>
 __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p) {
     constexpr int DKC = DP / 16;   // 16-wide k chunks of the QK^T product (one b128 fragment each)
     constexpr int DV8 = DP / 16;   // floats of a V row per lane = number of 16-row blocks of O^T
-    constexpr int QS = DP + 4;     // LDS row stride of the Q block (floats)
+    constexpr int QS = DP + ATTN16_PAD;   // LDS row stride of the Q block and the K tiles (floats)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -388,13 +396,14 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
         }
     }
 #ifdef LAMP_TUNING
-    if (p.trace && tid == 0) {   // wave 0 (key share 0 of the first query block): entry, loop start, loop end, exit
+    if (p.trace && tid == 0) {   // wave 0: entry, loop start, loop end, exit -- its ROLE (key share, query block) rotates with the
+                                 // workgroup when keys are ragged, so the role goes into word 7 for the analysis to split on
         unsigned long long* t = p.trace + size_t(blockIdx.x) * 8;
         t[0] = t_entry; t[1] = t_loop; t[2] = t_merge; t[3] = wall_clock64();
         t[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
         t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
         t[6] = unsigned(item);
-        t[7] = 0;
+        t[7] = unsigned(ks) | (unsigned(qb) << 8);
     }
 #endif
 }
@@ -402,7 +411,7 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
 template <int DP, int QB, int KSPLIT, int PM, int MK>
 static int launch_small_mk(const AttnParams& p, hipStream_t s) {
     constexpr int NW = QB * KSPLIT;
-    constexpr size_t lds_q = size_t(QB + NW) * 16 * (DP + 4) * sizeof(float);   // Q blocks + one K tile per wave
+    constexpr size_t lds_q = size_t(QB + NW) * 16 * (DP + ATTN16_PAD) * sizeof(float);   // Q blocks + one K tile per wave
     constexpr size_t lds_c = KSPLIT > 1 ? size_t(NW) * (DP / 16 * 4 + 4) * 64 * sizeof(float) : 0;
     constexpr size_t lds = lds_q > lds_c ? lds_q : lds_c;
     auto kern = attn16_kernel<DP, QB, KSPLIT, PM, MK>;
@@ -455,7 +464,10 @@ static int launch_small_dp(const AttnParams& p, int qb, int ksplit, hipStream_t 
 // single-pass map write-out.  The exact two-pass maps and map-only calls stay in attention.hip.
 // With ragged keys (kv_len) lk is only the PADDED length of the batch: the choice then rests on lq alone, so that a sample's
 // bits do not depend on how far its batch was padded (the fuzz campaign found the <= 64-key rule switching kernels between
-// a 300-label sample run alone and the same sample inside a longer batch).
+// a 300-label sample run alone and the same sample inside a longer batch).  lamp_forward and lamp_mha_fwd always bring
+// per-sample key counts for key-token masks, so on the product path the <= 64-key rule serves only calls without one
+// (bare lamp_sdpa_fwd, shared masks): delicious' enc-dec attention (983 labels x 40 tokens) runs in attention.hip at
+// 135 us instead of 121 us here -- 28 us of a 15.6 ms forward, the price of padding-invariant bits.
 bool attn_small_applies(const AttnParams& p, bool any_lq) {
     const bool few_keys = p.lk <= 64 && !p.kv_len;
     return (p.lq <= 256 || few_keys || any_lq) && p.V && p.O && (!p.P || p.lse) && p.dk <= 128 && p.dv <= 128;
