@@ -81,4 +81,9 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    try:
+        print(build(force='--force' in sys.argv, verbose=True))
+    except RuntimeError as e:   # the LAST lines must say so (callers pipe this through tail)
+        print(str(e)[-4000:], file=sys.stderr)
+        print('BUILD FAILED')
+        sys.exit(1)

@@ -504,8 +504,9 @@ static int chain_geom_index() {
 }
 
 // Shapes the fused chain takes: widths that tile the passes and the swizzles, everything resident in 160 KiB of LDS, and
-// (the heuristic part -- results do not depend on it) no more panels than CUs: beyond that the separate launches, which
-// spread a GEMM's tiles over all CUs, are the faster route.
+// (the heuristic part -- results do not depend on it) a row count for which it is the faster route: no more panels than
+// CUs (beyond that the separate launches, which spread a GEMM's tiles over all CUs, win), and enough of them that the
+// separate launches are no longer at their latency floor.
 bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn) {
 #ifdef LAMP_NO_CHAIN   // A/B builds (tools/build_variant.sh with EXTRA=-DLAMP_NO_CHAIN=1): always the separate launches
     return false;
@@ -520,7 +521,10 @@ bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn) {
     if (g_chain_mode == 0) return false;
     if (g_chain_mode == 1) return true;
 #endif
-    return (M + ROWS - 1) / ROWS <= 256;
+    // Measured window (profiles/r04_chain.txt, d = d_ff = 512): the chain takes ~60 us whatever the row count up to one
+    // panel per CU; the five launches take 37 us at 720 rows, 52 at 1920, 64 at 2400, 66 at 2880, 77-82 at 3360-4096.
+    const int64_t panels = (M + ROWS - 1) / ROWS;
+    return panels >= 144 && panels <= 256;
 }
 
 template <int NV, int WAVES, int WCOLS, int DEPTH, int NSLOT>
