@@ -27,6 +27,11 @@ python tools/bench_kernels.py gemm 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles_
 python tools/bench_kernels.py attn 2>&1 | grep -v amdgpu.ids > "$OUT/attn_variants.txt"
 python tools/bench_kernels.py sparse 2>&1 | grep -v amdgpu.ids > "$OUT/sparse_label_attention.txt"
 python tools/bench_kernels.py gemm_trace 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_trace.txt"
+python tools/bench_kernels.py gemm_clock 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_clock.txt"
+python tools/bench_kernels.py chain 2>&1 | grep -v amdgpu.ids > "$OUT/chain.txt"
+tools/probes/mfma_issue 20 > "$OUT/mfma_issue.txt" 2>&1
+LAMP_BENCH_BACKEND=gloo python bench.py --gpus 8 --steps 20 --warmup 5 --no-pipelined > "$OUT/bench_eight_ranks_one_gpu_gloo.json" 2>/dev/null
+LAMP_BENCH_BACKEND=gloo python bench.py --gpus 8 --ragged --steps 20 --warmup 5 --no-pipelined > "$OUT/bench_eight_ranks_one_gpu_gloo_ragged.json" 2>/dev/null
 BENCH="python $PWD/bench.py --no-cpu-baseline --no-pipelined --no-extra-workloads"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o p -f csv -- $BENCH --steps 100 --warmup 10 > "$OUT/bench_under_rocprof.json" 2>/dev/null )
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats_ragged" -o p -f csv -- $BENCH --ragged --steps 100 --warmup 10 > "$OUT/bench_ragged_under_rocprof.json" 2>/dev/null )
