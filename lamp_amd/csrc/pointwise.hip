@@ -165,9 +165,9 @@ __global__ __launch_bounds__(256) void embed_packed_kernel(const int64_t* __rest
 //     polls the two granules of its sample (relaxed agent-scope 8-byte loads: no fence, no flag -- the tag IS the data's
 //     validity; MI355X_MICROARCH.md "handoff-1to1"), and goes on with plen / off.  `epoch` is unique per launch, so a
 //     granule left in the workspace by an earlier launch (or by nothing at all) never matches.
-// Workgroups are dispatched in index order, so the plan is resident before any gather workgroup can wait for it; should a
-// granule not arrive within ~1 s of polling, the wave computes what it needs itself (plan_scan_sample over the samples up
-// to its own): slow, correct, and independent of any dispatch order.
+// Nothing here DEPENDS on dispatch order or placement: a wave polls a granule a few times (microseconds) and then computes what
+// is missing itself (plan_prefix).  In the ordinary case -- one process on the GPU -- the plan workgroups are the launch's
+// first and the granules are there at the first or second poll.
 struct PlanGranules {
     unsigned long long* plen;   // [nb]
     unsigned long long* off;    // [nb + 2]: off[b]; [nb] = n_tok; [nb + 1] = 1 when some position is skipped
@@ -181,6 +181,63 @@ __device__ __forceinline__ bool granule_try(const unsigned long long* g, unsigne
     const unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     v = unsigned(x);
     return unsigned(x >> 32) == epoch;
+}
+
+// The prefix sum over the samples' row counts by ONE wave, from the plan waves' granules -- and, for a granule that has not
+// arrived after a few polls, from this wave's own scan of that sample (plan_scan_sample: same values, also rewrites the same
+// key-mask words).  No wave of this launch ever waits on another for longer than those few polls: a plan workgroup that has
+// not been dispatched yet (a busy XCD, other processes sharing the GPU) costs its consumers one sample scan each, not a stall.
+//   want >= 0: -> plen[want] in `mine`, off[want] in `off_mine` (samples 0 .. want are visited)
+//   want <  0: all nb samples: -> total rows in `off_mine`, `any_skipped`; with `publish` the SeqPlan arrays and the off granules
+__device__ __forceinline__ void plan_prefix(const int64_t* __restrict__ seq, const int64_t* __restrict__ plan_pos, int nb, int T,
+                                            const SeqPlan& sp, const PlanGranules& gr, int lane, int want, bool publish,
+                                            int polls, int& mine, int& off_mine, bool& any_skipped) {
+    const int upto = want >= 0 ? want + 1 : nb;
+    int carry = 0;
+    bool skipped = false;
+    mine = 0;
+    off_mine = 0;
+    for (int base = 0; base < upto; base += 64) {
+        const int l = base + lane;
+        const bool valid = l < upto;
+        unsigned v = 0;
+        bool have = !valid;
+        for (int t = 0; t < polls && !__all(have); ++t) {
+            if (!have) have = granule_try(gr.plen + l, gr.epoch, v);
+            if (!__all(have)) {
+                const int naps = t < 5 ? (1 << t) : 32;
+                for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        unsigned long long missing = __ballot(!have);
+        while (missing) {   // this wave's own count of a sample whose plan wave has not delivered
+            const int i = __builtin_ctzll(missing);
+            int kl, pl;
+            plan_scan_sample(seq, plan_pos, base + i, T, T, sp, lane, kl, pl);
+            if (lane == i) v = unsigned(pl);
+            missing &= missing - 1;
+        }
+        const int pl = valid ? int(v) : 0;
+        skipped = skipped || (valid && pl < T);
+        int incl = pl;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const int u = __shfl_up(incl, dd, 64);
+            if (lane >= dd) incl += u;
+        }
+        const int off = carry + incl - pl;
+        if (publish && valid) {
+            sp.off[l] = off;
+            granule_put(gr.off + l, unsigned(off), gr.epoch);
+        }
+        if (want >= 0 && want >= base && want < base + 64) {
+            mine = __shfl(pl, want - base, 64);
+            off_mine = __shfl(off, want - base, 64);
+        }
+        carry += __shfl(incl, 63, 64);
+    }
+    any_skipped = __any(skipped);
+    if (want < 0) off_mine = carry;
 }
 
 __global__ __launch_bounds__(256) void embed_plan_kernel(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
@@ -200,37 +257,15 @@ __global__ __launch_bounds__(256) void embed_plan_kernel(const int64_t* __restri
             }
         }
         if (blockIdx.x != 0 || wave != 0) return;
-        // the prefix sum over the samples' rows, 64 samples at a time
-        int carry = 0;
-        bool skipped = false;
-        for (int base = 0; base < nb; base += 64) {
-            const int b = base + lane;
-            unsigned v = 0;
-            bool ok = b >= nb;
-            while (!__all(ok)) {
-                if (!ok) ok = granule_try(gr.plen + b, gr.epoch, v);
-                if (!ok) __builtin_amdgcn_s_sleep(1);
-            }
-            const int pl = b < nb ? int(v) : 0;
-            skipped = skipped || (b < nb && pl < T);
-            int incl = pl;
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const int u = __shfl_up(incl, dd, 64);
-                if (lane >= dd) incl += u;
-            }
-            if (b < nb) {
-                sp.off[b] = carry + incl - pl;
-                granule_put(gr.off + b, unsigned(carry + incl - pl), gr.epoch);
-            }
-            carry += __shfl(incl, 63, 64);
-        }
-        const bool any_skipped = __any(skipped);
+        // the scanner: prefix sum over all samples, the plain SeqPlan arrays for the LATER kernels, the off granules for this one
+        int mine, total;
+        bool any_skipped;
+        plan_prefix(seq, plan_pos, nb, T, sp, gr, lane, -1, true, 12, mine, total, any_skipped);
         if (lane == 0) {
-            sp.off[nb] = carry;
-            sp.rows[0] = carry;
-            sp.rows[1] = carry + (any_skipped ? 1 : 0);
-            granule_put(gr.off + nb, unsigned(carry), gr.epoch);
+            sp.off[nb] = total;
+            sp.rows[0] = total;
+            sp.rows[1] = total + (any_skipped ? 1 : 0);
+            granule_put(gr.off + nb, unsigned(total), gr.epoch);
             granule_put(gr.off + nb + 1, any_skipped ? 1u : 0u, gr.epoch);
         }
         return;
@@ -265,7 +300,9 @@ __global__ __launch_bounds__(256) void embed_plan_kernel(const int64_t* __restri
             ok = true;
         }
     }
-    for (int spin = 0; spin < (1 << 20) && !ok; ++spin) {
+    // The scanner's two granules of this sample, polled a few times with a doubling interval (thousands of resident waves
+    // polling every hundred cycles are a load of their own on the L2s) ...
+    for (int spin = 0; spin < 10 && !ok; ++spin) {
         unsigned ta = 0, tb = 0;
         bool ka = false, kb = false;
         if (lane == 0) {
@@ -275,23 +312,19 @@ __global__ __launch_bounds__(256) void embed_plan_kernel(const int64_t* __restri
         ok = __builtin_amdgcn_readfirstlane(int(ka && kb)) != 0;
         va = unsigned(__builtin_amdgcn_readfirstlane(int(ta)));
         vb = unsigned(__builtin_amdgcn_readfirstlane(int(tb)));
-        if (!ok) __builtin_amdgcn_s_sleep(2);
+        if (!ok) {
+            const int naps = 1 << (spin < 5 ? spin : 5);
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(4);   // 256 cycles per nap: ~0.1 us .. 3.4 us
+        }
     }
     if (!ok) {
-        // no plan in sight (never observed; see the header): this wave's own count of what it needs
-        int sum = 0, mine = 0;
-        bool skipped = false;
-        const int upto = pad_row ? nb : b + 1;
-        SeqPlan scratch = sp;
-        for (int bb = 0; bb < upto; ++bb) {
-            int kl, pl;
-            plan_scan_sample(seq, plan_pos, bb, T, T, scratch, lane, kl, pl);   // (rewrites the same key-mask words: benign)
-            if (bb == b) mine = pl;
-            if (bb < upto - (pad_row ? 0 : 1)) sum += pl;
-            skipped = skipped || pl < T;
-        }
-        va = pad_row ? (skipped ? 1u : 0u) : unsigned(mine);
-        vb = unsigned(sum);
+        // ... then this wave's own prefix sum over the plan waves' granules (plan_prefix: what is missing there it counts itself).
+        // Seen when several PROCESSES share the GPU: the scanner, or a plan workgroup, queues behind other kernels' waves.
+        int mine, off_mine;
+        bool any_skipped;
+        plan_prefix(seq, plan_pos, nb, T, sp, gr, lane, pad_row ? -1 : b, false, 4, mine, off_mine, any_skipped);
+        va = pad_row ? (any_skipped ? 1u : 0u) : unsigned(mine);
+        vb = unsigned(off_mine);
     }
     int64_t dst;
     if (pad_row) {
