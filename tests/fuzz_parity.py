@@ -18,7 +18,9 @@ its own input and output gradient, agreed with fp64 to 3e-7).
 """
 import sys, random, torch, traceback
 import torch.nn.functional as F
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 from oracle import lamp_ref as R
 from lamp_amd.Models import LAMP
 dev = torch.device('cuda:0')

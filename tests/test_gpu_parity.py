@@ -506,6 +506,49 @@ def test_decoder_chain_every_geometry_is_bit_identical(dev, tuning, monkeypatch,
         geom(0)
 
 
+@pytest.mark.parametrize('seed', range(10))
+def test_decoder_chain_random_models_bit_identical(dev, tuning, monkeypatch, seed):
+    """Random chain-eligible models (d_model 512; d_ff 512 or 1024 -- the latter fills the 160 KiB of LDS exactly; 4 or 8 heads;
+    1-3 decoder layers with or without label self-attention; any label count, batch and ragged lengths, i.e. any number of
+    panels incl. a partial last one): chain forced on == chain forced off, bit for bit, and within the north-star bar of the
+    oracle."""
+    import ctypes
+    import random
+    from lamp_amd import _native as N
+    from lamp_amd.Models import LAMP
+    rng = random.Random(900 + seed)
+    d, dff, h = 512, rng.choice([512, 1024]), rng.choice([4, 8])
+    L, T, B = rng.choice([7, 16, 33, 90, 159]), rng.choice([9, 40, 77]), rng.randint(1, 9)
+    n_dec, no_slf, mask, pos = rng.randint(1, 3), rng.random() < 0.3, rng.choice(['prior', 'none', 'inveye']), rng.random() < 0.5
+    V = 300
+    sd = R.make_state_dict(V, L, T, d, dff, h, 1, n_dec, pos_emb=pos, seed=seed, no_dec_self_att=no_slf)
+    adj = R.make_adjacency(L, 0.2, seed) if mask == 'prior' else None
+    lengths = [rng.randint(1, T) for _ in range(B)]
+    lengths[rng.randrange(B)] = T
+    seq, spos = R.make_batch(B, V, T, lengths=lengths, seed=seed)
+    m = LAMP(V, L, T, L, n_layers_enc=1, n_layers_dec=n_dec, n_head=h, n_head2=h, d_word_vec=d, d_model=d, d_inner_hid=dff,
+             d_k=d // h, d_v=d // h, encoder='graph', decoder='graph', no_enc_pos_embedding=not pos, no_dec_self_att=no_slf,
+             label_adj_matrix=adj.clone() if adj is not None else None, label_mask=mask, dec_dropout2=False)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    monkeypatch.setattr(N, '_lib', tuning)
+    force = tuning.lamp_debug_force_chain
+    force.argtypes = [ctypes.c_int]
+    force.restype = None
+    src = (seq.to(dev), spos.to(dev))
+    try:
+        force(0)
+        want, enc_want, _ = m(src, None, None, None)
+        force(1)
+        got, enc_got, _ = m(src, None, None, None)
+    finally:
+        force(-1)
+    assert torch.equal(got, want) and torch.equal(enc_got, enc_want), (d, dff, h, L, T, B, n_dec, no_slf)
+    with torch.no_grad():
+        ref, _, _ = R.forward(sd, seq, spos, h, R.label_block_mask(adj, mask, L))
+    assert max_abs_diff(got, ref) < TOL_LOGIT
+
+
 def test_decoder_chain_without_self_attention_and_odd_batches(dev, tuning, monkeypatch):
     """The chain behind the enc-dec attention of a decoder WITHOUT label self-attention (no_dec_self_att: pos_ffn2 follows
     pos_ffn1 directly and stays a launch of its own), and the row-count rule of the product library: a batch just below and
