@@ -17,7 +17,8 @@ namespace lamp {
 namespace {
 
 constexpr int GK = 16;        // k-tile
-constexpr int S_ROW = GK + 4;  // LDS row stride of a row operand   [rows][20]
+constexpr int S_ROW = GK + 8;  // LDS row stride of a row operand   [rows][24]: conflict-free b128 fragment reads under the real
+                               // ds_read_b128 lane groups (gemm.hip: GemmTile::LDS_STRIDE); 20 was 2-way
 // Block tiles (4 waves): 64 x 64 as 2 x 2 waves of 32 x 32 (2 x 2 MFMA blocks), and -- for the M = B*L shapes that
 // would leave SIMDs idle, exactly as in the forward menu -- 32 x 64 as 1 x 4 waves of 32 x 16 (2 x 1 blocks).
 // A column operand of R rows is staged as [16][R + 4].
