@@ -27,8 +27,11 @@ Rank 0 prints ONE JSON line with, besides the contract fields,
                           mismatch).  Under "nccl" rank 0 also requires one physical device per rank (exit 5),
   roofline      the dominant kernel class (fp32-MFMA GEMM): algorithmic FLOPs of its launches divided
                 by their HIP-event durations (events recorded by liblamp_hip.so on the launch stream,
-                in an instrumented replay of the same K steps right after the timed region); `traffic`
-                = HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes
+                in an instrumented replay of the same K steps right after the timed region);
+                `frac_kernel_only` = the same FLOPs over kernel-only durations from a `rocprofv3 --kernel-trace
+                --stats` sub-run of this invocation (N = 1; `kernel_trace` holds its per-kernel table;
+                --no-kernel-trace or a missing profiler falls back to the committed profile, and says so);
+                `traffic` = HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes
                 (profiles/hbm_traffic.json, written by tools/summarize_profiles.py),
   forward       whole-forward achieved fraction of the fp32 MFMA roof with F_live of SURVEY.md 8d,
   workloads     (N = 1) the other GPU configurations of BASELINE.json -- bibtex, delicious, synthetic4096 --
@@ -67,6 +70,76 @@ WORKLOADS = {
 # PER-GPU SHARE of BASELINE.json configs[4] (batch 8192 over 8 GPUs = 1024 samples per GPU, micro-batched inside
 # lamp_forward): ~3 s per step, so one warm-up step, two timed, one instrumented.
 EXTRA_WORKLOADS = (('bibtex', 32, 100, 10), ('delicious', 32, 20, 3), ('synthetic4096', 1024, 2, 1))
+
+
+KERNEL_TRACE_STEPS = 60         # forwards of the rocprofv3 --kernel-trace --stats sub-run behind roofline.frac_kernel_only
+KERNEL_TRACE_TIMEOUT_S = 150
+
+
+def under_profiler():
+    """True when this process was itself started by rocprofv3 / rocprof (no nested profiler then)."""
+    return any(k.startswith(('ROCPROF', 'ROCP_TOOL', 'ROCPROFILER')) for k in os.environ) or \
+        'rocprofiler' in os.environ.get('LD_PRELOAD', '')
+
+
+def live_kernel_trace(args):
+    """Kernel-only durations measured IN THIS INVOCATION: `rocprofv3 --kernel-trace --stats` around a short run of this
+    same script on the same workload (no counters: tracing only, the mode the MI355X guide's profiling recipe starts
+    with), read back from its p_kernel_stats.csv.  -> dict, or a dict with only 'skipped' when the profiler is absent, this
+    process already runs under it, or the sub-run fails / times out (the bench line then falls back to the committed
+    profile's durations, marked as such).  The GPU is idle in this process while the sub-run holds it."""
+    import csv
+    import shutil
+    import tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return {'skipped': 'rocprofv3 not found'}
+    if under_profiler():
+        return {'skipped': 'this process already runs under the profiler'}
+    out = tempfile.mkdtemp(prefix='lamp_bench_trace_', dir='/tmp')
+    cmd = [exe, '--kernel-trace', '--stats', '-d', out, '-o', 'p', '-f', 'csv', '--', sys.executable,
+           os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--batch', str(args.batch),
+           '--steps', str(KERNEL_TRACE_STEPS), '--warmup', '10', '--no-cpu-baseline', '--no-extra-workloads', '--no-pipelined',
+           '--no-kernel-trace']
+    env = dict(os.environ, TMPDIR='/tmp', LAMP_BENCH_INNER='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'LAMP_BENCH_SPAWNED'):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                           timeout=KERNEL_TRACE_TIMEOUT_S)
+        path = os.path.join(out, 'p_kernel_stats.csv')
+        if r.returncode != 0 or not os.path.exists(path):
+            return {'skipped': 'rocprofv3 sub-run failed (exit %d)' % r.returncode}
+        with open(path) as f:
+            rows = list(csv.DictReader(f))
+    except subprocess.TimeoutExpired:
+        return {'skipped': 'rocprofv3 sub-run exceeded %d s' % KERNEL_TRACE_TIMEOUT_S}
+    except (OSError, ValueError, KeyError) as e:
+        return {'skipped': 'rocprofv3 sub-run: %s' % e}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    # one embed launch per forward (per micro-batch for the large batches: then per-forward figures are per micro-batch)
+    fwd = sum(int(r['Calls']) for r in rows if 'embed_plan_kernel' in r['Name'] or 'embed_packed_kernel' in r['Name']
+              or 'embed_kernel' in r['Name'])
+    if not fwd:
+        return {'skipped': 'no lamp_forward launches in the trace'}
+    lamp = [r for r in rows if 'lamp::' in r['Name']]
+    short = lambda n: n.split('(')[0].replace('void lamp::', '').replace('lamp::', '')
+    is_gemm = lambda n: 'gemm_nt_kernel' in n or 'chain_kernel' in n
+    by_kernel = {}
+    for r in sorted(lamp, key=lambda r: -float(r['TotalDurationNs'])):
+        by_kernel[short(r['Name'])] = {'launches_per_forward': int(r['Calls']) / fwd,
+                                       'avg_us': float(r['AverageNs']) / 1e3,
+                                       'us_per_forward': float(r['TotalDurationNs']) / fwd / 1e3}
+    return {
+        'command': 'rocprofv3 --kernel-trace --stats -- python bench.py --workload %s --batch %d --steps %d ... (this '
+                   'invocation, %.0f s)' % (args.workload, args.batch, KERNEL_TRACE_STEPS, time.perf_counter() - t0),
+        'forwards_traced': fwd,
+        'gemm_class_us_per_forward': sum(float(r['TotalDurationNs']) for r in lamp if is_gemm(r['Name'])) / fwd / 1e3,
+        'all_kernels_us_per_forward': sum(float(r['TotalDurationNs']) for r in lamp) / fwd / 1e3,
+        'by_kernel': by_kernel,
+    }
 
 
 def f_live(w, n_enc=2, n_dec=2):
@@ -209,7 +282,7 @@ def profile_steps(N, step, n_steps):
     return prof, kernels
 
 
-def roofline_of(prof, n_steps, workload):
+def roofline_of(prof, n_steps, workload, live=None, chain_gflop=None):
     gemm = prof['gemm']
     tf = gemm['flops'] / (gemm['ms'] * 1e-3) / 1e12 if gemm['ms'] > 0 else 0.0
     tr = load_traffic(workload)
@@ -225,18 +298,41 @@ def roofline_of(prof, n_steps, workload):
     }
     out['timing'] = ('HIP events recorded by the library around every GEMM launch in an INSTRUMENTED replay of the timed '
                      'steps (the event pairs perturb the stream: conservative); frac_kernel_only = the same FLOPs over '
-                     'the rocprofv3 --kernel-trace durations of the committed profile')
+                     'rocprofv3 --kernel-trace durations -- of a sub-run of this invocation when kernel_only_source says '
+                     '"live", else of the committed profile')
     fresh = bool(tr) and tr.get('csrc_fingerprint') == csrc_fingerprint()
-    if tr and tr.get('gemm_kernel_only_us_per_step') and n_steps:
+    if live and live.get('gemm_class_us_per_forward') and n_steps:
+        # kernel-only: this run's FLOPs over the kernel durations of the rocprofv3 --kernel-trace sub-run of THIS invocation
+        ko = gemm['flops'] / n_steps / (live['gemm_class_us_per_forward'] * 1e-6) / 1e12
+        out['achieved_kernel_only'] = ko
+        out['frac_kernel_only'] = ko / PEAK_FP32_MFMA_TFLOPS
+        out['kernel_only_source'] = 'live: ' + live['command']
+        chain_us = sum(k['us_per_forward'] for n, k in live['by_kernel'].items() if 'chain_kernel' in n)
+        if chain_us and chain_gflop:
+            # the decoder chain launch holds three GEMMs AND their two LayerNorms / residual adds: split the class so that
+            # neither hides behind the other (the class figure above stays the conservative sum)
+            nt_us = live['gemm_class_us_per_forward'] - chain_us
+            nt_gf = gemm['flops'] / n_steps / 1e9 - chain_gflop
+            out['kernel_only_split'] = {
+                'gemm_nt_kernel': {'us_per_forward': nt_us, 'gflop': nt_gf, 'tflops': nt_gf / nt_us * 1e-3,
+                                   'frac': nt_gf / nt_us * 1e-3 / PEAK_FP32_MFMA_TFLOPS},
+                'chain_kernel': {'us_per_forward': chain_us, 'gflop': chain_gflop, 'tflops': chain_gflop / chain_us * 1e-3,
+                                 'frac': chain_gflop / chain_us * 1e-3 / PEAK_FP32_MFMA_TFLOPS,
+                                 'note': 'output projection + residual, LayerNorm, FFN (two GEMMs), LayerNorm in one launch: '
+                                         'the time includes the LayerNorms, the FLOPs do not'}}
+    elif tr and tr.get('gemm_kernel_only_us_per_step') and n_steps:
         # this run's FLOPs over the committed profile's kernel durations: only meaningful while the kernels are the ones
         # that profile ran on
         if fresh:
             ko = gemm['flops'] / n_steps / (tr['gemm_kernel_only_us_per_step'] * 1e-6) / 1e12
             out['achieved_kernel_only'] = ko
             out['frac_kernel_only'] = ko / PEAK_FP32_MFMA_TFLOPS
+            out['kernel_only_source'] = 'committed profile (profiles/hbm_traffic.json), same kernel sources'
         else:
             out['achieved_kernel_only'] = out['frac_kernel_only'] = None
             out['kernel_only_stale'] = True
+    if live and live.get('skipped'):
+        out['kernel_trace_skipped'] = live['skipped']
     if tr and tr.get('gemm_launches'):
         out['traffic'] = (tr['gemm_fetch_bytes'] + tr['gemm_write_bytes']) / tr['gemm_launches']
         out['traffic_stale'] = not fresh
@@ -370,6 +466,8 @@ def main():
                     help='skip the bounded bibtex / delicious / synthetic4096 runs reported beside the headline (N = 1)')
     ap.add_argument('--ragged', action='store_true',
                     help='sequence lengths U{lo..hi} padded to the batch maximum (SURVEY.md 8d variant ii) instead of fixed T')
+    ap.add_argument('--no-kernel-trace', action='store_true',
+                    help='skip the rocprofv3 --kernel-trace --stats sub-run behind roofline.frac_kernel_only (N = 1)')
     ap.add_argument('--mask', default=None, choices=['prior', 'none', 'inveye'], help='override the workload label mask')
     args = ap.parse_args()
 
@@ -493,7 +591,14 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     fl = f_live(w)
     plain = not (args.ragged or args.mask)
-    roof = roofline_of(prof, prof_steps, args.workload if plain else None)
+    live = None
+    if n_gpus == 1 and world == 1 and plain and not args.graph and not args.no_kernel_trace and args.batch <= 64:
+        live = live_kernel_trace(args)
+    # FLOPs of the decoder chain launches of one forward (lamp_amd/csrc/chain.hip; two per decoder layer, each the
+    # d x d output projection and the d -> d_ff -> d FFN over the B*L label rows)
+    rows_dec = args.batch * w['L']
+    chain_gflop = 2 * 2 * (2.0 * rows_dec * w['d'] * w['d'] + 4.0 * rows_dec * w['d'] * w['dff']) / 1e9
+    roof = roofline_of(prof, prof_steps, args.workload if plain else None, live, chain_gflop)
     if args.ragged and prof['gemm']['ms'] > 0:
         # the launchers count the padded upper bound of the packed encoder's rows: use the real token count
         gf = gemm_flops_per_step(w, args.batch, n_tok)
@@ -539,6 +644,7 @@ def main():
                                 'under profiles/',
         },
         'kernels': kernels,
+        'kernel_trace': live,
         'pipelined_batches_in_flight': pipelined,
     }
 

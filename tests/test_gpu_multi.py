@@ -42,7 +42,7 @@ def _bench(args, env_extra=None):
 
 
 def test_bench_spawns_its_own_ranks(dev):
-    common = ['--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--no-pipelined', '--no-extra-workloads']
+    common = ['--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--no-pipelined', '--no-extra-workloads', '--no-kernel-trace']
     r1, one = _bench(['--gpus', '1'] + common)
     assert r1.returncode == 0, r1.stderr[-2000:]
     assert one['n_gpus'] == 1 and one['ranks_seen'] == [0] and len(one['per_rank']) == 1
@@ -80,11 +80,27 @@ def test_bench_spawns_its_own_ranks(dev):
     assert r4.returncode != 0
 
 
+def test_bench_kernel_only_fraction_is_measured_in_the_run(dev):
+    """roofline.frac_kernel_only comes from a rocprofv3 --kernel-trace --stats sub-run of the same invocation (N = 1), not
+    from a committed file: the trace must be there, count every forward, and its GEMM-class time must be below the
+    instrumented HIP-event time the plain `frac` uses."""
+    r, out = _bench(['--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-pipelined', '--no-extra-workloads'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    kt, roof = out['kernel_trace'], out['roofline']
+    assert kt and 'skipped' not in kt, kt
+    assert kt['forwards_traced'] >= 60 and 100.0 < kt['gemm_class_us_per_forward'] < 2000.0
+    assert any('gemm_nt_kernel' in k for k in kt['by_kernel']) and any('attn' in k for k in kt['by_kernel'])
+    assert roof['kernel_only_source'].startswith('live:') and 'kernel_only_stale' not in roof
+    assert 0.97 * roof['frac'] <= roof['frac_kernel_only'] < 1.0
+    assert abs(roof['achieved_kernel_only'] - roof['algorithmic_gflop_per_step'] / kt['gemm_class_us_per_forward'] * 1e-3) \
+        < 1e-6 * roof['achieved_kernel_only']
+
+
 def test_bench_and_eval_with_eight_ranks_on_one_device(dev, tmp_path):
     """The rank count the driver's scaling run uses (batch shards over 8 GPUs), as far as one GPU allows:
     eight self-spawned ranks over gloo sharing this box's device -- every rank reports, rank 0 recomputes the first samples
     of ranks 1..7 bit for bit (fixed and ragged batches), and the aggregate is all samples over the slowest rank."""
-    common = ['--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--no-pipelined', '--no-extra-workloads']
+    common = ['--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--no-pipelined', '--no-extra-workloads', '--no-kernel-trace']
     for extra in ([], ['--ragged']):
         r, out = _bench(['--gpus', '8'] + extra + common, {'LAMP_BENCH_BACKEND': 'gloo'})
         assert r.returncode == 0, r.stderr[-2000:]
