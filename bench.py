@@ -314,10 +314,10 @@ def roofline_of(prof, n_steps, workload, live=None, chain_gflop=None):
             nt_us = live['gemm_class_us_per_forward'] - chain_us
             nt_gf = gemm['flops'] / n_steps / 1e9 - chain_gflop
             out['kernel_only_split'] = {
-                'gemm_nt_kernel': {'us_per_forward': nt_us, 'gflop': nt_gf, 'tflops': nt_gf / nt_us * 1e-3,
-                                   'frac': nt_gf / nt_us * 1e-3 / PEAK_FP32_MFMA_TFLOPS},
-                'chain_kernel': {'us_per_forward': chain_us, 'gflop': chain_gflop, 'tflops': chain_gflop / chain_us * 1e-3,
-                                 'frac': chain_gflop / chain_us * 1e-3 / PEAK_FP32_MFMA_TFLOPS,
+                'gemm_nt_kernel': {'us_per_forward': nt_us, 'gflop': nt_gf, 'tflops': nt_gf / nt_us * 1e3,
+                                   'frac': nt_gf / nt_us * 1e3 / PEAK_FP32_MFMA_TFLOPS},
+                'chain_kernel': {'us_per_forward': chain_us, 'gflop': chain_gflop, 'tflops': chain_gflop / chain_us * 1e3,
+                                 'frac': chain_gflop / chain_us * 1e3 / PEAK_FP32_MFMA_TFLOPS,
                                  'note': 'output projection + residual, LayerNorm, FFN (two GEMMs), LayerNorm in one launch: '
                                          'the time includes the LayerNorms, the FLOPs do not'}}
     elif tr and tr.get('gemm_kernel_only_us_per_step') and n_steps:

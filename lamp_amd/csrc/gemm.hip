@@ -166,6 +166,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;               // [2][BM][S]                    (DMA: stage s = smem + s * (BM + BN) * BK, A then W rows)
     float* Bs = smem + 2 * BM * S;  // [2][BN][S]
+    // DMA = 3 (experiment): the W fragments come straight from global memory in MFMA layout (a lane's b128 = the four
+    // consecutive k of ITS weight row: exactly its fragment of an NT product) -- no LDS pass for W at all; A is staged as ever.
+    constexpr bool WDIR = DMA == 3;
+    constexpr int LDMA = WDIR ? 0 : DMA;   // the LDS-DMA mode proper
     static_assert(!DMA || (T::DMA_OK && !KTAIL), "direct-to-LDS staging: whole 1 KiB pieces per wave, K a multiple of BK");
 
     const int tid = threadIdx.x;
@@ -270,6 +274,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
     // does not cover an L2/MALL round trip).
     float4 ra0[T::A_LD], rb0[T::B_LD], ra1[T::A_LD], rb1[T::B_LD];
     unsigned voa[T::A_LD], vob[T::B_LD];  // byte offsets of this thread's float4s inside the tile
+    constexpr int NWF = WDIR ? (BK / KCH) * T::NI : 1;
+    float4 wf0[NWF], wf1[NWF];            // WDIR: W fragments of the even / odd k-step, [chunk][block]
+    unsigned vow[NWF];
+    if constexpr (WDIR) {
+#pragma unroll
+        for (int c = 0; c < BK / KCH; ++c)
+#pragma unroll
+            for (int j = 0; j < T::NI; ++j) vow[c * T::NI + j] = unsigned((wn * T::WTN + j * MF + l31) * ldw + c * KCH + hi * 4) * 4u;
+    }
+    auto wload = [&](int k0, float4 (&wf)[NWF]) {
+        const unsigned so = unsigned(k0) * 4u;
+#pragma unroll
+        for (int x = 0; x < NWF; ++x) wf[x] = bload4(rsW, vow[x], so);
+    };
 #pragma unroll
     for (int i = 0; i < T::A_LD; ++i) {
         const int idx = tid + i * T::NT;
@@ -300,8 +318,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
             const unsigned so = unsigned(k0) * 4u;  // uniform -> soffset
 #pragma unroll
             for (int i = 0; i < T::A_LD; ++i) ra[i] = bload4(rsA, voa[i], so);
+            if constexpr (!WDIR) {
 #pragma unroll
-            for (int i = 0; i < T::B_LD; ++i) rb[i] = bload4(rsW, vob[i], so);
+                for (int i = 0; i < T::B_LD; ++i) rb[i] = bload4(rsW, vob[i], so);
+            }
         }
     };
     auto lstore = [&](int buf, const float4 (&ra)[T::A_LD], const float4 (&rb)[T::B_LD]) {
@@ -313,11 +333,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
             const int row = idx / C4, c4 = idx - row * C4;
             *reinterpret_cast<float4*>(a + row * S + c4 * 4) = ra[i];
         }
+        if constexpr (!WDIR) {
 #pragma unroll
-        for (int i = 0; i < T::B_LD; ++i) {
-            const int idx = tid + i * T::NT;
-            const int row = idx / C4, c4 = idx - row * C4;
-            *reinterpret_cast<float4*>(b + row * S + c4 * 4) = rb[i];
+            for (int i = 0; i < T::B_LD; ++i) {
+                const int idx = tid + i * T::NT;
+                const int row = idx / C4, c4 = idx - row * C4;
+                *reinterpret_cast<float4*>(b + row * S + c4 * 4) = rb[i];
+            }
         }
     };
     auto mfma_chunk = [&](const float4 (&fa)[T::MI], const float4 (&fb)[T::NI]) {
@@ -344,7 +366,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
         __builtin_amdgcn_s_setprio(0);
 #endif
     };
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, const float4 (&wf)[NWF]) {
         const float* a = As + buf * BM * S + (wm * T::WTM + l31) * S + hi * 4;
         const float* b = Bs + buf * BN * S + (wn * T::WTN + l31) * S + hi * 4;
 #pragma unroll
@@ -353,7 +375,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
 #pragma unroll
             for (int i = 0; i < T::MI; ++i) fa[i] = *reinterpret_cast<const float4*>(a + i * MF * S + c * KCH);
 #pragma unroll
-            for (int j = 0; j < T::NI; ++j) fb[j] = *reinterpret_cast<const float4*>(b + j * MF * S + c * KCH);
+            for (int j = 0; j < T::NI; ++j) {
+                if constexpr (WDIR) fb[j] = wf[c * T::NI + j];
+                else fb[j] = *reinterpret_cast<const float4*>(b + j * MF * S + c * KCH);
+            }
             mfma_chunk(fa, fb);
         }
     };
@@ -361,9 +386,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
     // ---- direct-to-LDS staging (DMA) ----
     constexpr int STAGE = (BM + BN) * BK;   // floats per LDS stage
     constexpr int PW = T::A_PW + T::B_PW;   // LDS-DMA instructions per wave and k-step
-    unsigned dva[DMA ? T::A_PW : 1], dvb[DMA ? T::B_PW : 1];   // source byte offsets of this lane's quads inside the tile
+    unsigned dva[LDMA ? T::A_PW : 1], dvb[LDMA ? T::B_PW : 1];   // source byte offsets of this lane's quads inside the tile
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    if constexpr (DMA) {
+    if constexpr (LDMA) {
         const int prow = lane / T::QPR, pq = lane % T::QPR;   // row inside a piece, LDS slot inside the row
 #pragma unroll
         for (int i = 0; i < T::A_PW; ++i) {
@@ -391,7 +416,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
     for (int c = 0; c < BK / KCH; ++c) qoff[c] = ((c * KQ + hi) ^ dma_swz<BK>(l31 & 15)) << 2;
     constexpr int NCH = BK / KCH;
     // DMA = 1: all fragments of a stage into registers (ordinary loads), then -- by the caller -- the next request, then the MFMAs
-    float4 fra[DMA == 1 ? NCH : 1][T::MI], frb[DMA == 1 ? NCH : 1][T::NI];
+    float4 fra[LDMA == 1 ? NCH : 1][T::MI], frb[LDMA == 1 ? NCH : 1][T::NI];
     auto dma_read = [&](int st) {
         const float* a = smem + st * STAGE + (wm * T::WTM + l31) * BK;
         const float* b = smem + st * STAGE + BM * BK + (wn * T::WTN + l31) * BK;
@@ -435,7 +460,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
     };
 
     const int nk = (p.K + BK - 1) / BK;
-    if constexpr (!DMA) gload(0, ra0, rb0);
+    if constexpr (!LDMA) gload(0, ra0, rb0);
+    if constexpr (WDIR) {
+        wload(0, wf0);
+        if (nk > 1) wload(BK, wf1);
+    }
 
     // Epilogue operands.  The products are issued TRANSPOSED -- W fragment as the MFMA's A operand, activation fragment as
     // its B operand -- so the accumulator block holds C^T: lane (m = lane & (MF-1), hi) owns, for ITS output row m, four
@@ -480,11 +509,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
             }
     }
 
-    if constexpr (DMA) {
+    if constexpr (LDMA) {
         // after the epilogue operands' loads: vector-memory operations retire in order, and the counted wait of step 0 must
         // not have younger register loads between itself and tile 0
         dma_stage(0, 0);
-        if (DMA == 2 && nk > 1) dma_stage(1, 1);
+        if (LDMA == 2 && nk > 1) dma_stage(1, 1);
     } else {
         lstore(0, ra0, rb0);
         if (nk > 1) gload(BK, ra0, rb0);      // tile 1 -> set 0
@@ -496,7 +525,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
     const unsigned long long c_loop = p.trace ? __builtin_readcyclecounter() : 0ull;   // shader-clock cycles (s_memtime)
 #endif
 
-    if constexpr (DMA == 1) {
+    if constexpr (LDMA == 1) {
         for (int kt = 0; kt < nk; ++kt) {
             wait_vmcnt<0>();                 // tile kt has landed (this wave's pieces; the barrier makes it everyone's)
             __builtin_amdgcn_s_barrier();    // ... and every wave is past its reads of tile kt - 1, whose stage is refilled below
@@ -506,7 +535,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
 #pragma unroll
             for (int c = 0; c < NCH; ++c) mfma_chunk(fra[c], frb[c]);
         }
-    } else if constexpr (DMA == 2) {
+    } else if constexpr (LDMA == 2) {
         // step kt: tile kt in stage kt % 3 (requested two steps ago), tile kt + 1 in flight, tile kt + 2 requested here --
         // into the stage tile kt - 1 was read from: every wave is past those reads once it has passed this step's barrier
         // (its MFMAs of step kt - 1 consumed them).  Loads retire in order, so "at most one tile's pieces outstanding" =
@@ -523,15 +552,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
     } else
     for (int kt = 0; kt < nk; kt += 2) {
         // even step: tile kt in LDS[0]; tile kt+1 in set 0, tile kt+2 in set 1
-        compute(0);
+        compute(0, wf0);
         if (kt + 1 < nk) lstore(1, ra0, rb0);
         if (kt + 3 < nk) gload((kt + 3) * BK, ra0, rb0);
+        if constexpr (WDIR) { if (kt + 2 < nk) wload((kt + 2) * BK, wf0); }   // into the set this step's MFMAs have read
         __syncthreads();
         if (kt + 1 >= nk) break;
         // odd step: tile kt+1 in LDS[1]; tile kt+2 in set 1, tile kt+3 in set 0
-        compute(1);
+        compute(1, wf1);
         if (kt + 2 < nk) lstore(0, ra1, rb1);
         if (kt + 4 < nk) gload((kt + 4) * BK, ra1, rb1);
+        if constexpr (WDIR) { if (kt + 3 < nk) wload((kt + 3) * BK, wf1); }
         __syncthreads();
     }
 #ifdef LAMP_TUNING
@@ -597,7 +628,7 @@ static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
     constexpr bool RPRE = T::MI * T::NI * (MF == 32 ? 16 : 4) <= 16;
     auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC, DMA>;
-    size_t LDS = DMA ? T::DMA_STAGE_BYTES * (DMA == 1 ? 2 : 3) : T::LDS_BYTES;
+    size_t LDS = (DMA == 1 || DMA == 2) ? T::DMA_STAGE_BYTES * (DMA == 1 ? 2 : 3) : T::LDS_BYTES;
     static AttrOnce once;
 #ifdef LAMP_TUNING
     LDS += g_extra_lds;   // residency experiments: more LDS per workgroup = fewer workgroups per CU
@@ -722,6 +753,10 @@ int launch_gemm(const GemmParams& p_in, hipStream_t s) {
         case 27: return launch_cfg<128, 128, 32, 2, 2, 32, 2>(p, s);
         case 28: return launch_cfg<32, 64, 64, 1, 4, 16, 2>(p, s);
         case 29: return launch_cfg<64, 64, 64, 2, 2, 16, 2>(p, s);
+        case 30: return launch_cfg<64, 64, 16, 2, 2, 16, 3>(p, s);     // W fragments straight from global memory
+        case 31: return launch_cfg<64, 64, 32, 2, 2, 16, 3>(p, s);
+        case 32: return launch_cfg<32, 64, 32, 1, 4, 16, 3>(p, s);
+        case 33: return launch_cfg<128, 64, 16, 2, 2, 16, 3>(p, s);
         case 40: return launch_cfg<32, 64, 32, 1, 4, 16, 1>(p, s);
         case 41: return launch_cfg<64, 64, 16, 2, 2, 16, 1>(p, s);
         case 42: return launch_cfg<64, 64, 32, 2, 2, 16, 1>(p, s);

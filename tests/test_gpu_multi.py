@@ -92,8 +92,10 @@ def test_bench_kernel_only_fraction_is_measured_in_the_run(dev):
     assert any('gemm_nt_kernel' in k for k in kt['by_kernel']) and any('attn' in k for k in kt['by_kernel'])
     assert roof['kernel_only_source'].startswith('live:') and 'kernel_only_stale' not in roof
     assert 0.97 * roof['frac'] <= roof['frac_kernel_only'] < 1.0
-    assert abs(roof['achieved_kernel_only'] - roof['algorithmic_gflop_per_step'] / kt['gemm_class_us_per_forward'] * 1e-3) \
+    assert abs(roof['achieved_kernel_only'] - roof['algorithmic_gflop_per_step'] / kt['gemm_class_us_per_forward'] * 1e3) \
         < 1e-6 * roof['achieved_kernel_only']
+    split = roof['kernel_only_split']
+    assert split['chain_kernel']['frac'] < roof['frac_kernel_only'] < split['gemm_nt_kernel']['frac'] < 1.0
 
 
 def test_bench_and_eval_with_eight_ranks_on_one_device(dev, tmp_path):

@@ -53,7 +53,8 @@ def test_linear_vs_torch_fp64(dev, M, K, N_):
     assert max_abs_diff(N.linear(x.to(dev), w.to(dev)), ref2) < 2e-5
 
 
-GEMM_DMA_CFGS = list(range(20, 30)) + list(range(40, 50))   # direct-to-LDS staging: inline-asm reads / compiler reads
+GEMM_DMA_CFGS = list(range(20, 34)) + list(range(40, 50))   # direct-to-LDS staging: inline-asm reads / compiler reads;
+                                                             # 30-33: W fragments straight from global memory
 
 
 @pytest.mark.parametrize('cfg', list(range(1, 19)) + GEMM_DMA_CFGS)

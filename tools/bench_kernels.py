@@ -25,6 +25,8 @@ _DMA = {0: 'm16:32x64x32', 1: 'm16:64x64x16', 2: 'm16:64x64x32', 3: 'm16:128x64x
 for _i, _n in _DMA.items():   # direct-to-LDS staging: 20-29 inline-asm reads + counted vmcnt, 40-49 compiler-scheduled reads
     TILES[20 + _i] = 'A:' + _n.replace('m16:', '')
     TILES[40 + _i] = 'C:' + _n.replace('m16:', '')
+# W fragments straight from global memory (no LDS pass for W), A staged as ever
+TILES.update({30: 'W:64x64x16', 31: 'W:64x64x32', 32: 'W:32x64x32', 33: 'W:128x64x16'})
 
 
 def time_fn(fn, iters=30, warm=5):
