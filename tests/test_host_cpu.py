@@ -214,3 +214,50 @@ def test_bench_refuses_to_run_without_a_gpu_and_its_spawner_does_not_hang():
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1'] + extra, capture_output=True,
                            text=True, env=env, timeout=300)
         assert r.returncode != 0 and 'needs an MI355X' in r.stderr and r.stdout.strip() == ''
+
+
+def test_bench_kernel_trace_parsing_and_roofline_split(monkeypatch, tmp_path):
+    """bench.py's kernel-only figures come from a rocprofv3 --kernel-trace --stats sub-run: the reading of its
+    p_kernel_stats.csv (per-forward normalisation by the gather launches, GEMM class = gemm_nt_kernel + chain_kernel) and
+    the roofline split are host logic -- checked here against a hand-written trace, with the profiler call replaced."""
+    import argparse
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    rows = [('void lamp::chain_kernel<2, 8, 64, 2, 1>(lamp::ChainParams)', 40, 60000.0),
+            ('void lamp::gemm_nt_kernel<64, 64, 16, 2, 2, false, 16, true, true, 0>(lamp::GemmParams, int)', 40, 45000.0),
+            ('void lamp::gemm_nt_kernel<128, 64, 16, 2, 2, false, 16, false, true, 0>(lamp::GemmParams, int)', 10, 158000.0),
+            ('void lamp::attn16_kernel<128, 1, 4, 0, 3>(lamp::AttnParams)', 20, 25000.0),
+            ('lamp::embed_plan_kernel(long const*, long const*)', 10, 12000.0),
+            ('__amd_rocclr_copyBuffer', 3, 4000.0)]
+
+    def fake_run(cmd, **kw):
+        assert cmd[1:3] == ['--kernel-trace', '--stats'] and '--pmc' not in cmd and '--no-kernel-trace' in cmd
+        out = cmd[cmd.index('-d') + 1]
+        with open(os.path.join(out, 'p_kernel_stats.csv'), 'w') as f:
+            f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n')
+            for name, calls, avg in rows:
+                f.write('"%s",%d,%d,%f,1.0,1,1,0.0\n' % (name, calls, int(calls * avg), avg))
+        return subprocess.CompletedProcess(cmd, 0, b'', b'')
+
+    monkeypatch.setattr(bench.subprocess, 'run', fake_run)
+    monkeypatch.setattr('shutil.which', lambda exe: '/opt/rocm/bin/rocprofv3')
+    for k in [k for k in os.environ if k.startswith(('ROCPROF', 'ROCP_TOOL'))]:
+        monkeypatch.delenv(k)
+    args = argparse.Namespace(workload='reuters', batch=32)
+    live = bench.live_kernel_trace(args)
+    assert live['forwards_traced'] == 10
+    assert abs(live['gemm_class_us_per_forward'] - (4 * 60.0 + 4 * 45.0 + 158.0)) < 1e-9
+    assert abs(live['all_kernels_us_per_forward'] - (578.0 + 2 * 25.0 + 12.0)) < 1e-9   # the runtime's copy kernel is not ours
+    assert list(live['by_kernel'])[0].startswith('chain_kernel') and live['by_kernel']['embed_plan_kernel']['launches_per_forward'] == 1.0
+    # 10 steps of 69.2 GFLOP in the GEMM class, 18.1 of them in the chain launches
+    prof = {'gemm': {'flops': 69.2e9 * 10, 'ms': 7.0, 'launches': 120, 'bytes': 1e9}}
+    roof = bench.roofline_of(prof, 10, None, live, 18.1)
+    assert abs(roof['achieved_kernel_only'] - 69.2 / 578.0 * 1e3) < 1e-9 and roof['kernel_only_source'].startswith('live:')
+    sp = roof['kernel_only_split']
+    assert abs(sp['chain_kernel']['tflops'] - 18.1 / 240.0 * 1e3) < 1e-9
+    assert abs(sp['gemm_nt_kernel']['tflops'] - 51.1 / 338.0 * 1e3) < 1e-6
+    # a profiled parent never starts a nested profiler
+    monkeypatch.setenv('ROCPROFILER_TOOL', '1')
+    assert 'skipped' in bench.live_kernel_trace(args)
