@@ -22,13 +22,18 @@
 //   H  [16][max(h d_v, d_ff)]  the attention output rows, then the FFN hidden rows (A operand of fc and W2)
 //        both row-major, unpadded, the 16-byte quad q of row r stored in slot q ^ r: the A fragments (16 rows x one quad
 //        per lane group) are then conflict-free b128 reads, and the LDS-DMA that fills them applies the XOR on its source side
-//   ring: per WAVE two slots of a [32 W rows][32 k] tile (4 KiB), written by the wave itself from the registers its W stream
-//        arrives in (the image and swizzle of gemm.hip's DMA = 2) -- a wave multiplies the panel with ITS OWN 32 output
-//        columns' weights, so the k loop has no barrier at all: the eight waves drift apart and cover each other's waits.
-// A GEMM step walks N in passes of 8 x 32 columns; a wave's W stream runs on across pass and segment boundaries (the next
-// pass's first tiles are requested while the last of this one are multiplied).  W is streamed once per panel: 180 x 1 MiB per
-// GEMM out of the L2s (all panels are at the same step at the same time), ~75 GB/s per CU -- whole 128-byte lines per row
-// (BK = 32): 64-byte pieces would halve the L1 rate (profiles/r02_rejected_experiments.txt #9).
+//   ring: per WAVE one slot (NSLOT; two in one of the tuning geometries) of a [WCOLS W rows][32 k] stage -- production geometry:
+//        64 rows, 8 KiB -- written by the wave itself from the registers its W stream arrives in (the image and swizzle of
+//        gemm.hip's DMA = 2).  A wave multiplies the panel with ITS OWN output columns' weights, so the k loop has no barrier at
+//        all: the eight waves drift apart and cover each other's waits.  (One slot is enough: a wave's LDS queue is in order, the
+//        next stage's writes follow this stage's fragment reads without a wait.)
+// A GEMM step walks N in passes of WAVES x WCOLS columns (8 x 64 = 512: one pass per segment at d = 512); a wave's W stream runs
+// on across pass and segment boundaries (the next pass's first stages are requested while the last of this one are multiplied).
+// W is streamed once per panel: 180 x 1 MiB per GEMM out of the L2s (all panels are at the same step at the same time),
+// ~60-75 GB/s per CU -- whole 128-byte lines per row (BK = 32): 64-byte pieces would halve the L1 rate
+// (profiles/r02_rejected_experiments.txt #9).  Why the stream goes through registers and not by LDS-DMA: DEPTH stages must be in
+// flight to ride the L2 latency, and with 64 KiB of X and H resident the LDS has room for 1.5 stages per wave, the registers
+// for two to four (profiles/r04_rejected_experiments.txt #4, v1).
 //
 // All LDS traffic of this kernel is inline assembly (explicit lgkmcnt waits): the row loads at the start are LDS-DMA, and
 // hipcc orders every ds_read / ds_write it can see behind ALL earlier LDS-DMA with a full vmcnt(0) drain (gemm.hip, DMA = 1).
