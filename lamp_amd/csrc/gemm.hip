@@ -150,11 +150,11 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC, int DMA = 0>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, MF))) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
-                                                                          int tiles_n, int tiles_m,
-                                                                          int panel_split, FastDiv fd_group,
-                                                                          FastDiv fd_seg) {
+// The whole tile program.  EXPL = false: the tile is derived from blockIdx (gemm_nt_kernel: one tile per workgroup);
+// EXPL = true: the caller names the tile (x_tm, x_tn) -- a persistent workgroup running one tile after another (gemm_pair_kernel).
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC, int DMA, bool EXPL>
+__device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, int tiles_n, int tiles_m, int panel_split,
+                                          FastDiv fd_group, FastDiv fd_seg, int x_tm, int x_tn) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
     // lane -> (row within an MFMA block, which group of 4 consecutive k this lane's b128 read covers)
     constexpr int KQ = 64 / MF;             // 2 for 32x32x2, 4 for 16x16x4
@@ -203,7 +203,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
         const int nwg = tiles_m * tiles_n, pan_xcd = (tiles_m + 7) >> 3;
         panel_split = tiles_m >= 16 && (pan_xcd * tiles_n + 31) / 32 <= ((nwg + 7) / 8 + 31) / 32;
     }
-    int item, pan0, pan1;
+    int item = 0, pan0 = 0, pan1 = tiles_m;
+    int tn_all = x_tn, tm = x_tm;
+    if constexpr (!EXPL) {
     if (panel_split) {
         const int q = tiles_m >> 3, r = tiles_m & 7, xcd = blockIdx.x & 7;
         pan0 = xcd * q + (xcd < r ? xcd : r);
@@ -217,7 +219,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
         pan0 = 0;
         pan1 = tiles_m;
     }
-    int tn_all, tm;
     if (p.walk_gn > 0) {
         // (4) W-resident walk, for weight matrices that crowd the 4 MiB L2 on their own (delicious' 8 MB FFN weights):
         // groups of walk_gn COLUMN panels (~2 MiB of W), and inside a group row-panel by row-panel -- the group's W
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
         tn_all = div_1_to_8(in_grp, gm);
         tm = first_m + (in_grp - tn_all * gm);
     }
+    }   // !EXPL
     const int seg = fdiv(tn_all, fd_seg);       // tn_all / tiles_n_seg
     const int tn = tn_all - seg * tiles_n_seg;
     const int64_t m0 = int64_t(tm) * BM;
@@ -614,6 +616,152 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, 
     }
 #endif
 }
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC, int DMA = 0>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, MF))) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
+                                                                          int tiles_n, int tiles_m,
+                                                                          int panel_split, FastDiv fd_group,
+                                                                          FastDiv fd_seg) {
+    gemm_body<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC, DMA, false>(p, tiles_n_seg, tiles_n, tiles_m, panel_split, fd_group,
+                                                                            fd_seg, 0, 0);
+}
+
+#ifdef LAMP_TUNING
+// ---- EXPERIMENT (tuning build): two dependent GEMMs in ONE launch, row-panel-local hand-off through counters ----
+//   H = act(X . W1^T + b1)   then   Y = H . W2^T + b2 (+ R)        (the encoder's FFN pair, lamp/SubLayers.py:133-142 before the LayerNorm)
+// Persistent workgroups (at most the resident capacity), one task queue per XCD: row-panel tm belongs to XCD tm % 8 -- a workgroup
+// reads its XCD from HW_REG_XCC_ID and only ever takes that XCD's tasks, so a panel's H rows are written and read through ONE L2
+// (no cross-XCD coherence traffic: the producer waits for its stores' acknowledgements, vmcnt(0), and bumps the panel's counter;
+// the consumer sees the counter reach the panel's tile count, invalidates its L1 and reads).  Queue order per XCD: all stage-0
+// tiles (panel-major), then all stage-1 tiles in the same panel order -- when a stage-1 tile is taken every stage-0 tile of that XCD
+// has been taken by a running workgroup that waits for nothing: no deadlock, whatever the residency.  The tiles are the ordinary
+// tile program (gemm_body): same products, same k-order, same bits as two launches.
+#ifndef PAIR_POLL_SLEEP
+#define PAIR_POLL_SLEEP 32   // x 64 cycles between two looks at a panel counter
+#endif
+struct PairParams {
+    const GemmParams* g;   // [2] in device memory (a kernarg array indexed at run time would be copied to scratch)
+    int* queue;            // [8] task cursors + [8] = workgroups that have left: the last one out zeroes the cursors for the next launch
+    int* done;             // [tiles_m] stage-0 tiles finished per row-panel, one counter per 128-byte line (640 pollers on two lines
+                           // slowed every tile 3x); zeroed by the last workgroup out, like the cursors
+    int tiles_m, tiles_n0, tiles_n1;
+    FastDiv fd0, fd1;      // / tiles_n0, / tiles_n1
+    unsigned long long* trace;   // nullable: per workgroup [wait cycles, tasks, first task start, last task end]
+};
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF, bool RPRE, bool TRACE, int OCC>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, OCC) void gemm_pair_kernel(PairParams q) {
+    __shared__ int task_s;
+    const int tid = threadIdx.x;
+    const int xcc = __builtin_amdgcn_readfirstlane(int(__builtin_amdgcn_s_getreg((31 << 11) | 20)) & 7);
+    const int npan = (q.tiles_m - xcc + 7) >> 3;          // row-panels xcc, xcc + 8, ...
+    const int n0 = npan * q.tiles_n0, n1 = npan * q.tiles_n1;
+    const FastDiv fd0 = q.fd0, fd1 = q.fd1;
+    const int want = q.tiles_n0;
+    unsigned long long waited = 0, t_first = 0, t_last = 0;
+    int ntask = 0;
+    // Loop shape (matters): ONE single-thread region per iteration, between two workgroup barriers, and nothing divergent next to
+    // the back edge.  With the panel counter's increment as a second `if (tid == 0)` at the END of the body hipcc merged it with the
+    // next iteration's task fetch across the back edge and let the other lanes run ahead into the next barrier -- wave 0 then
+    // arrives at that s_barrier twice per iteration and the workgroup hangs.
+    int finished_tm = -1;   // stage-0 tile whose stores the closing barrier of the last iteration has seen complete
+    for (;;) {
+        if (tid == 0) {
+            if (finished_tm >= 0) __hip_atomic_fetch_add(q.done + finished_tm * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            task_s = __hip_atomic_fetch_add(q.queue + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const int task = __builtin_amdgcn_readfirstlane(task_s);
+        if (task >= n0 + n1) break;
+        const int stage = task >= n0 ? 1 : 0;
+        const int t = stage ? task - n0 : task;
+        const int tn_per = stage ? q.tiles_n1 : q.tiles_n0;
+        const int pl = fdiv(t, stage ? fd1 : fd0);
+        const int tn = t - pl * tn_per, tm = pl * 8 + xcc;
+        if (stage) {
+            if (tid == 0) {
+                const unsigned long long c0 = TRACE ? __builtin_readcyclecounter() : 0ull;
+                // (bounded: a broken hand-off must show up as a wrong result in the experiment's check, not as a hung GPU)
+                for (int spin = 0; spin < (1 << 16) && __hip_atomic_load(q.done + tm * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spin)
+                    __builtin_amdgcn_s_sleep(PAIR_POLL_SLEEP);
+                if constexpr (TRACE) waited += __builtin_readcyclecounter() - c0;
+            }
+            __syncthreads();
+            asm volatile("buffer_inv sc0" ::: "memory");   // L1 only (H lines this CU may hold from an earlier launch / layer); producer and consumer share the L2
+        }
+        if constexpr (TRACE) { if (tid == 0 && ntask == 0) t_first = wall_clock64(); }
+        const GemmParams& gp = q.g[stage];
+        gemm_body<BM, BN, BK, WAVES_M, WAVES_N, false, MF, RPRE, true, 0, true>(gp, tn_per, tn_per, q.tiles_m, 0, fd0, stage ? fd1 : fd0, tm, tn);
+        finished_tm = stage ? -1 : tm;
+        if constexpr (TRACE) {
+            ++ntask;
+            if (tid == 0) t_last = wall_clock64();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's stores are in the L2 ...
+        __syncthreads();                                    // ... everyone's are; and the next tile's staging may overwrite the LDS
+    }
+    if constexpr (TRACE) {
+        if (tid == 0) {
+            unsigned long long* tr = q.trace + size_t(blockIdx.x) * 4;
+            tr[0] = waited; tr[1] = unsigned(ntask); tr[2] = t_first; tr[3] = t_last;
+        }
+    }
+    // last workgroup out: every cursor and counter has been read for the last time -- zero them for the next launch
+    if (tid == 0) task_s = __hip_atomic_fetch_add(q.queue + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (task_s == int(gridDim.x) - 1) {
+        for (int i = tid; i < q.tiles_m; i += int(blockDim.x)) __hip_atomic_store(q.done + i * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 9) __hip_atomic_store(q.queue + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// scratch (device, 256-byte aligned, zeroed ONCE by the caller): [0, 1024) two GemmParams, [1024, 1088) cursors, [2048, ...) panel counters
+extern "C" __attribute__((visibility("default"))) int lamp_debug_ffn_pair_prepare(
+    const float* x, long long M, int d, const float* w1, const float* b1, int dff, const float* w2, const float* b2, const float* r,
+    float* H, float* Y, void* scratch, void* stream) {
+    static_assert(2 * sizeof(GemmParams) <= 1024, "scratch layout");
+    GemmParams g[2] = {};
+    g[0].A = x; g[0].lda = d; g[0].M = M; g[0].K = d; g[0].N = dff; g[0].nseg = 1; g[0].W[0] = w1; g[0].ldw = d; g[0].bias[0] = b1;
+    g[0].C[0] = H; g[0].ldc = dff; g[0].relu = 1; g[0].vec_epilogue = 1;
+    g[1].A = H; g[1].lda = dff; g[1].M = M; g[1].K = dff; g[1].N = d; g[1].nseg = 1; g[1].W[0] = w2; g[1].ldw = dff; g[1].bias[0] = b2;
+    g[1].C[0] = Y; g[1].ldc = d; g[1].R = r; g[1].ldr = d; g[1].vec_epilogue = 1;
+    if (int e = int(hipMemsetAsync(scratch, 0, 2048 + 128 * size_t((M + 31) / 32), hipStream_t(stream)))) return e;
+    if (int e = int(hipMemcpyAsync(scratch, g, sizeof g, hipMemcpyHostToDevice, hipStream_t(stream)))) return e;
+    return int(hipStreamSynchronize(hipStream_t(stream)));
+}
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int OCC>
+static int launch_pair(long long M, int d, int dff, void* scratch, int wg_per_cu, unsigned long long* trace, hipStream_t s) {
+    using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, 16>;
+    constexpr bool RPRE = T::MI * T::NI * 4 <= 16;
+    auto kern = trace ? gemm_pair_kernel<BM, BN, BK, WAVES_M, WAVES_N, 16, RPRE, true, OCC> : gemm_pair_kernel<BM, BN, BK, WAVES_M, WAVES_N, 16, RPRE, false, OCC>;
+    static AttrOnce once, once_t;
+    if (int e = (trace ? once_t : once).set(reinterpret_cast<const void*>(kern), T::LDS_BYTES)) return e;
+    PairParams q{};
+    q.g = reinterpret_cast<const GemmParams*>(scratch);
+    q.queue = reinterpret_cast<int*>(static_cast<char*>(scratch) + 1024);
+    q.done = reinterpret_cast<int*>(static_cast<char*>(scratch) + 2048);
+    q.tiles_m = int((M + BM - 1) / BM);
+    q.tiles_n0 = (dff + BN - 1) / BN;
+    q.tiles_n1 = (d + BN - 1) / BN;
+    q.fd0 = make_fastdiv(unsigned(q.tiles_n0));
+    q.fd1 = make_fastdiv(unsigned(q.tiles_n1));
+    q.trace = trace;
+    hipLaunchKernelGGL(kern, dim3(unsigned(256 * wg_per_cu)), dim3(T::NT), T::LDS_BYTES, s, q);
+    return int(hipGetLastError());
+}
+// tile: 0 = 64x64x16 (the encoder FFN's tile; 5 waves per SIMD, a few spilled dwords), 3 = the same at 4 waves, 1 = 32x64x32, 2 = 128x64x16.  K must be a multiple of the tile's BK, N of 4.
+extern "C" __attribute__((visibility("default"))) int lamp_debug_ffn_pair_launch(long long M, int d, int dff, void* scratch, int tile,
+                                                                              int wg_per_cu, unsigned long long* trace, void* stream) {
+    hipStream_t s = hipStream_t(stream);
+    if ((d % 32) || (dff % 32)) return LAMP_E_UNSUPPORTED;
+    switch (tile) {
+        case 0: return launch_pair<64, 64, 16, 2, 2, 5>(M, d, dff, scratch, wg_per_cu, trace, s);
+        case 1: return launch_pair<32, 64, 32, 1, 4, 4>(M, d, dff, scratch, wg_per_cu, trace, s);
+        case 2: return launch_pair<128, 64, 16, 2, 2, 3>(M, d, dff, scratch, wg_per_cu, trace, s);
+        case 3: return launch_pair<64, 64, 16, 2, 2, 4>(M, d, dff, scratch, wg_per_cu, trace, s);
+    }
+    return LAMP_E_UNSUPPORTED;
+}
+#endif
 
 #ifdef LAMP_TUNING
 static int g_force_walk = -1;   // -1 = heuristic; 0 = row-panel groups; n > 0 = W-resident walk with n column panels per group

@@ -103,6 +103,43 @@ def test_linear_direct_to_lds_staging_is_bit_identical(dev, tuning, cfg):
         force(0)
 
 
+@pytest.mark.parametrize('tile,wg', [(0, 5), (3, 4), (1, 4), (2, 3)])
+def test_ffn_pair_in_one_persistent_launch_is_bit_identical(dev, tuning, tile, wg):
+    """Experiment kept in the tuning build (gemm.hip: gemm_pair_kernel, profiles/r04_rejected_experiments.txt #11): two
+    dependent GEMMs -- the FFN pair before its LayerNorm -- in one persistent launch with per-row-panel counters run the same
+    tile program as two launches, so H and Y must come out bit for bit; repeated launches reuse the counters (the last
+    workgroup out resets them)."""
+    import ctypes
+    from lamp_amd import _native as N
+    prep, launch = tuning.lamp_debug_ffn_pair_prepare, tuning.lamp_debug_ffn_pair_launch
+    prep.restype = launch.restype = ctypes.c_int
+    prep.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                     ctypes.c_void_p]
+    launch.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                       ctypes.c_void_p, ctypes.c_void_p]
+    for M, d, dff in ((2880, 512, 512), (1000, 256, 1024), (70, 512, 256)):
+        g = torch.Generator().manual_seed(M + tile)
+        x = torch.randn(M, d, generator=g).to(dev)
+        w1 = (torch.randn(dff, d, generator=g) / d ** 0.5).to(dev)
+        b1 = torch.randn(dff, generator=g).to(dev)
+        w2 = (torch.randn(d, dff, generator=g) / dff ** 0.5).to(dev)
+        b2 = torch.randn(d, generator=g).to(dev)
+        h_want = N.linear(x, w1, b1, relu=True, _lib=tuning)
+        y_want = N.linear(h_want, w2, b2, residual=x, _lib=tuning)
+        h, y = torch.empty_like(h_want), torch.empty_like(y_want)
+        scratch = torch.zeros(4096 + 32 * ((M + 31) // 32) + 64, dtype=torch.int32, device=dev)
+        N.check(prep(x.data_ptr(), M, d, w1.data_ptr(), b1.data_ptr(), dff, w2.data_ptr(), b2.data_ptr(), x.data_ptr(),
+                     h.data_ptr(), y.data_ptr(), scratch.data_ptr(), N.stream()), 'pair prepare')
+        for _ in range(3):
+            h.zero_()
+            y.zero_()
+            N.check(launch(M, d, dff, scratch.data_ptr(), tile, wg, None, N.stream()), 'pair launch')
+            torch.cuda.synchronize()
+            assert torch.equal(h, h_want) and torch.equal(y, y_want), (tile, M, d, dff)
+        assert int(scratch[256:265].abs().sum()) == 0   # cursors back at zero
+
+
 def test_linear_detects_transposed_or_shifted_tiles(dev):
     """Asymmetric operands: a swapped row/column mapping in the MFMA epilogue cannot pass."""
     from lamp_amd import _native as N
