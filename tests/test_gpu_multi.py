@@ -91,7 +91,7 @@ def test_bench_kernel_only_fraction_is_measured_in_the_run(dev):
     assert kt['forwards_traced'] >= 60 and 100.0 < kt['gemm_class_us_per_forward'] < 2000.0
     assert any('gemm_nt_kernel' in k for k in kt['by_kernel']) and any('attn' in k for k in kt['by_kernel'])
     assert roof['kernel_only_source'].startswith('live:') and 'kernel_only_stale' not in roof
-    assert 0.97 * roof['frac'] <= roof['frac_kernel_only'] < 1.0
+    assert 0.90 * roof['frac'] <= roof['frac_kernel_only'] < 1.0   # separate process: allow for clock differences
     assert abs(roof['achieved_kernel_only'] - roof['algorithmic_gflop_per_step'] / kt['gemm_class_us_per_forward'] * 1e3) \
         < 1e-6 * roof['achieved_kernel_only']
     split = roof['kernel_only_split']
