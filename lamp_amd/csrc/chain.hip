@@ -17,17 +17,17 @@
 //   * LayerNorm: ln_row_stats / ln_row_apply of lamp_kernels.h (one wave per row, the lane -> column assignment and the
 //     reduction tree of layernorm_kernel, contraction off).
 //
-// Layout in LDS (160 KiB, one workgroup of 8 waves per CU):
+// Layout in LDS (160 KiB, one workgroup of 16 waves per CU):
 //   X  [16][d]              the state rows (residual source, A operand of W1, LayerNorm in place)
 //   H  [16][max(h d_v, d_ff)]  the attention output rows, then the FFN hidden rows (A operand of fc and W2)
 //        both row-major, unpadded, the 16-byte quad q of row r stored in slot q ^ r: the A fragments (16 rows x one quad
 //        per lane group) are then conflict-free b128 reads, and the LDS-DMA that fills them applies the XOR on its source side
 //   ring: per WAVE one slot (NSLOT; two in one of the tuning geometries) of a [WCOLS W rows][32 k] stage -- production geometry:
-//        64 rows, 8 KiB -- written by the wave itself from the registers its W stream arrives in (the image and swizzle of
+//        32 rows, 4 KiB -- written by the wave itself from the registers its W stream arrives in (the image and swizzle of
 //        gemm.hip's DMA = 2).  A wave multiplies the panel with ITS OWN output columns' weights, so the k loop has no barrier at
-//        all: the eight waves drift apart and cover each other's waits.  (One slot is enough: a wave's LDS queue is in order, the
+//        all: the sixteen waves drift apart and cover each other's waits.  (One slot is enough: a wave's LDS queue is in order, the
 //        next stage's writes follow this stage's fragment reads without a wait.)
-// A GEMM step walks N in passes of WAVES x WCOLS columns (8 x 64 = 512: one pass per segment at d = 512); a wave's W stream runs
+// A GEMM step walks N in passes of WAVES x WCOLS columns (16 x 32 = 512: one pass per segment at d = 512); a wave's W stream runs
 // on across pass and segment boundaries (the next pass's first stages are requested while the last of this one are multiplied).
 // W is streamed once per panel: 180 x 1 MiB per GEMM out of the L2s (all panels are at the same step at the same time),
 // ~60-75 GB/s per CU -- whole 128-byte lines per row (BK = 32): 64-byte pieces would halve the L1 rate
@@ -483,11 +483,13 @@ static int g_chain_geom = 0;    // 0 = production geometry, else index into the 
 extern "C" __attribute__((visibility("default"))) void lamp_debug_chain_geometry(int idx) { g_chain_geom = idx; }
 #endif
 
-// Geometries (waves, columns per wave and pass, register sets, LDS slots per wave).  Production = the first one.
+// Geometries (waves, columns per wave and pass, register sets, LDS slots per wave).  Production = the first one: SIXTEEN waves
+// (a 1024-thread workgroup, four waves per SIMD) of 32 columns each -- 57.4 us against 59.8-60.1 for eight waves x 64 columns
+// (profiles/r04_chain.txt): twice the waves to cover each other's LDS / memory waits for twice the A-fragment reads.
 // (Four waves x 128 columns -- one wave per SIMD, 430 registers -- was tried and is gone: the allocator parks part of the
 // W stream's registers in AGPRs and copies them right behind the untracked loads, before the data has landed: wrong
 // results, and 92 us.  The inline-assembly loads are only safe while their destination registers stay put.)
-#define LAMP_CHAIN_GEOMS(X) X(0, 8, 64, 2, 1) X(1, 8, 32, 4, 2) X(2, 8, 32, 2, 2) X(3, 8, 32, 4, 1)
+#define LAMP_CHAIN_GEOMS(X) X(0, 16, 32, 2, 1) X(1, 8, 32, 4, 2) X(2, 8, 32, 2, 2) X(3, 8, 32, 4, 1) X(4, 8, 64, 2, 1)
 struct ChainGeomInfo {
     int waves, pass_cols, ring_floats;
 };
@@ -580,7 +582,7 @@ int launch_chain(const float* A, int64_t lda, int k_h, const float* res, int64_t
         LAMP_CHAIN_GEOMS(X)
 #undef X
 #else
-        case 0: return nv <= 1 ? launch_chain_geom<1, 8, 64, 2, 1>(p, lds, grid, s) : launch_chain_geom<2, 8, 64, 2, 1>(p, lds, grid, s);
+        case 0: return nv <= 1 ? launch_chain_geom<1, 16, 32, 2, 1>(p, lds, grid, s) : launch_chain_geom<2, 16, 32, 2, 1>(p, lds, grid, s);
 #endif
         default: return LAMP_E_UNSUPPORTED;
     }
