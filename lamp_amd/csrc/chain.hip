@@ -164,7 +164,7 @@ struct ChainGeom {
     static constexpr int NOPS = NLD + NRD + NLD + 1;         // intake operations per step, one per MFMA gap
     static constexpr int RING_FLOATS = WAVES * NSLOT * STAGE_FLOATS;
     static constexpr int RPW = ROWS / WAVES;                 // LayerNorm rows per wave
-    static_assert(NOPS <= NMF && ROWS % WAVES == 0 && (DEPTH == 2 || DEPTH == 4) && (NSLOT == 1 || NSLOT == 2), "geometry");
+    static_assert(NOPS <= NMF && ROWS % WAVES == 0 && (DEPTH == 2 || DEPTH == 4) && NSLOT >= 0 && NSLOT <= 2, "geometry");
 };
 
 template <int NV, int WAVES, int WCOLS, int DEPTH, int NSLOT>
@@ -242,6 +242,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(ChainParam
         }
         f32x4 R[DEPTH][NLD];
         unsigned p_so = 0;
+        // NSLOT == 0 ("W direct"): no LDS pass for W at all.  A wave is the ONLY consumer of its output columns' weights, and a
+        // lane's 16-byte load of four consecutive k of W row (col0 + 16 j + l15) IS its MFMA fragment: the stream goes global ->
+        // fragment registers, DEPTH stages deep (stage t + DEPTH - 1 is requested, into the set stage t - 1 was multiplied from,
+        // in the gaps between the MFMAs of stage t).  Per instruction the lanes touch 16 rows x 64 bytes; the other half of each
+        // 128-byte line is the next chunk's load, issued right behind it.
+        constexpr bool WDIR = NSLOT == 0;
+        constexpr int NL = 2 * NB;                 // fragment loads per stage
+        f32x4 F[WDIR ? DEPTH : 1][2][NB];
+        unsigned f_voff[2][NB];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) f_voff[c][j] = unsigned((16 * j + l15) * ldw + c * 16 + hi * 4) * 4u;
         auto part_write = [&](f32x4 (&regs)[NLD], int set, int i) {   // registers -> LDS slot
             const unsigned st_b = ring_b + unsigned((NSLOT == 2 ? set : 0) * STAGE_FLOATS) * 4u;
 #if !(defined(CHAIN_ABL) && (CHAIN_ABL & 4))
@@ -275,6 +288,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(ChainParam
             if (item == 0) fa[set][c] = lds_read16(src_b + unsigned(kt >> 1) * 256u + a_off[set][c]);   // kt & 1 == stage & 1
             else fw[set][c][item - 1] = lds_read16(st_b + w_off[c] + unsigned((item - 1) * 16 * BK * 4));
         };
+        if constexpr (WDIR) {
+            // prologue: stages 0 .. DEPTH - 2 requested; A fragments of stage 0
+            static_for<0, DEPTH - 1>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int jb = 0; jb < NB; ++jb) F[j][c][jb] = buffer_read16_untracked(rsW, f_voff[c][jb], p_so);
+                part_book();
+            });
+#pragma unroll
+            for (int c = 0; c < 2; ++c) fa[0][c] = lds_read16(src_b + a_off[0][c]);
+        } else {
         // prologue: DEPTH stages requested, stage 0 through LDS into fragment set 0
         static_for<0, DEPTH>([&](auto J) {
             constexpr int j = decltype(J)::value;
@@ -289,6 +315,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(ChainParam
         for (int i = 0; i < NLD; ++i) part_load(R[0], i);
         part_book();
         static_for<0, G::NRD>([&](auto Rr) { part_read(0, 0, decltype(Rr)::value); });
+        }
 
         for (int seg = 0; seg < g.nseg; ++seg) {
             for (int pass = 0; pass < npass; ++pass) {
@@ -314,6 +341,26 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(ChainParam
                         // One step = the MFMAs of stage t (fragment set `set`, complete: requested during the previous step) with
                         // the intake of stage t + 1 spread over the gaps between them, one operation per gap -- a wave's own LDS /
                         // memory instructions then issue in the shadow of its own MFMAs.  sched_barrier pins the written order.
+                        if constexpr (WDIR) {
+                            // stage t (set j) has landed when at most the DEPTH - 2 younger stages are outstanding
+                            wait_vmcnt<(DEPTH - 2) * NL>();
+                            wait_lgkmcnt<0>();
+                            constexpr int jl = (j + DEPTH - 1) % DEPTH;   // the set stage t - 1 was multiplied from
+                            static_for<0, G::NMF>([&](auto I) {
+                                constexpr int i = decltype(I)::value, c = i / (4 * NB), comp = (i % (4 * NB)) / NB, jb = i % NB;
+                                acc[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(F[j][c][jb][comp], fa[set][c][comp], acc[jb], 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if constexpr (i < NL) {                    // stage t + DEPTH - 1 -> set jl
+                                    F[jl][i / NB][i % NB] = buffer_read16_untracked(rsW, f_voff[i / NB][i % NB], p_so);
+                                } else if constexpr (i < NL + 2) {         // A fragments of stage t + 1
+                                    fa[setn][i - NL] = lds_read16(src_b + unsigned(ktn >> 1) * 256u + a_off[setn][i - NL]);
+                                } else if constexpr (i == NL + 2) {
+                                    part_book();
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            });
+                            return;
+                        }
                         wait_lgkmcnt<0>();
                         static_for<0, G::NMF>([&](auto I) {
                             constexpr int i = decltype(I)::value, c = i / (4 * NB), comp = (i % (4 * NB)) / NB, jb = i % NB;
@@ -489,7 +536,8 @@ extern "C" __attribute__((visibility("default"))) void lamp_debug_chain_geometry
 // (Four waves x 128 columns -- one wave per SIMD, 430 registers -- was tried and is gone: the allocator parks part of the
 // W stream's registers in AGPRs and copies them right behind the untracked loads, before the data has landed: wrong
 // results, and 92 us.  The inline-assembly loads are only safe while their destination registers stay put.)
-#define LAMP_CHAIN_GEOMS(X) X(0, 16, 32, 2, 1) X(1, 8, 32, 4, 2) X(2, 8, 32, 2, 2) X(3, 8, 32, 4, 1) X(4, 8, 64, 2, 1)
+#define LAMP_CHAIN_GEOMS(X) X(0, 16, 32, 2, 1) X(1, 8, 32, 4, 2) X(2, 8, 32, 2, 2) X(3, 8, 32, 4, 1) X(4, 8, 64, 2, 1) \
+    X(5, 16, 32, 2, 0) X(6, 8, 64, 4, 0)
 struct ChainGeomInfo {
     int waves, pass_cols, ring_floats;
 };

@@ -516,7 +516,7 @@ def test_decoder_chain_launch_is_bit_identical(dev, tuning, monkeypatch, name, B
     assert max_abs_diff(got, ref) < TOL_LOGIT
 
 
-@pytest.mark.parametrize('geometry', [1, 2, 3, 4])
+@pytest.mark.parametrize('geometry', [1, 2, 3, 4, 5, 6])
 def test_decoder_chain_every_geometry_is_bit_identical(dev, tuning, monkeypatch, geometry):
     """The chain kernel's other geometries (waves x columns per wave, register sets of the W stream, LDS slots; tuning build):
     same fragments, same k-order -- the bits of the separate launches, ragged batch with a partial last panel."""

@@ -362,7 +362,8 @@ def chain():
     geom.argtypes = [ctypes.c_int]
     geom.restype = None
     GEOMS = {0: '16 waves x 32 cols, 2 reg sets, 1 slot', 1: '8 x 32, 4 sets, 2 slots', 2: '8 x 32, 2 sets, 2 slots',
-             3: '8 x 32, 4 sets, 1 slot', 4: '8 waves x 64 cols, 2 sets, 1 slot'}
+             3: '8 x 32, 4 sets, 1 slot', 4: '8 waves x 64 cols, 2 sets, 1 slot',
+             5: 'W direct: 16 x 32, 2 sets', 6: 'W direct: 8 x 64, 4 sets'}
     separate()
     for gi in sorted(GEOMS):
         geom(gi)
