@@ -96,7 +96,10 @@ def live_kernel_trace(args):
         return {'skipped': 'rocprofv3 not found'}
     if under_profiler():
         return {'skipped': 'this process already runs under the profiler'}
-    out = tempfile.mkdtemp(prefix='lamp_bench_trace_', dir='/tmp')
+    try:
+        out = tempfile.mkdtemp(prefix='lamp_bench_trace_', dir='/tmp' if os.path.isdir('/tmp') else None)
+    except OSError as e:
+        return {'skipped': 'no scratch directory for the profiler output: %s' % e}
     cmd = [exe, '--kernel-trace', '--stats', '-d', out, '-o', 'p', '-f', 'csv', '--', sys.executable,
            os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--batch', str(args.batch),
            '--steps', str(KERNEL_TRACE_STEPS), '--warmup', '10', '--no-cpu-baseline', '--no-extra-workloads', '--no-pipelined',
