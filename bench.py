@@ -35,7 +35,8 @@ Rank 0 prints ONE JSON line with, besides the contract fields,
                 (profiles/hbm_traffic.json, written by tools/summarize_profiles.py),
   forward       whole-forward achieved fraction of the fp32 MFMA roof with F_live of SURVEY.md 8d,
   workloads     (N = 1) the other GPU configurations of BASELINE.json -- bibtex, delicious, synthetic4096 --
-                each for a bounded number of steps: value, ms_per_step, GEMM roofline, attention TFLOP/s,
+                each for a bounded number of steps: value, ms_per_step, GEMM roofline, attention TFLOP/s; and
+                reuters_ragged, the headline model on lengths U{20..302} (SURVEY.md 8d variant ii),
   cpu_baseline  the oracle (a port of the reference's op sequence, `as_written`, autograd graph
                 built as the reference's test loop does) timed on this host's cores on a bounded
                 sample (N = 1 only).
@@ -678,6 +679,22 @@ def main():
             }
             me.clear()
             torch.cuda.empty_cache()
+        # SURVEY.md 8d variant (ii) of the headline configuration: the same model, sequence lengths U{20..302} padded to the batch
+        # maximum (the real-data shape; `python bench.py --ragged` is the full line) -- bounded like the others
+        import argparse as _ap
+        ra = _ap.Namespace(ragged=True, workload='reuters', batch=32)
+        wr, len_r = batch_of_rank(ra, WORKLOADS['reuters'], 0)
+        mr = measure(N, 'reuters', wr, 32, 200, 20, device, 0, lambda: None, lengths=len_r, n_max=RAGGED['reuters'][1])
+        vr = 32 * 200 / mr['elapsed']
+        extra['reuters_ragged'] = {
+            'value': vr, 'unit': 'samples/s', 'batch': 32, 'steps': 200, 'warmup': 20, 'ms_per_step': mr['elapsed'] / 200 * 1e3,
+            'config': 'lengths U{%d..%d} padded to the batch maximum %d (%d real tokens), otherwise the headline model' %
+                      (RAGGED['reuters'] + (wr['T'], int(sum(len_r)))),
+            'forward_frac_of_fp32_mfma_peak': vr * f_live(wr) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            'note': 'F_live counts the padded length; the kernels do not compute on the padding (DESIGN.md 3b)',
+        }
+        mr.clear()
+        torch.cuda.empty_cache()
         result['workloads'] = extra
         m.update(sd=sd_h, adj=adj_h, seq=seq_h, pos=pos_h)
 
