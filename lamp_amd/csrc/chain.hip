@@ -576,10 +576,11 @@ bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn) {
     if (g_chain_mode == 0) return false;
     if (g_chain_mode == 1) return true;
 #endif
-    // Measured window (profiles/r04_chain.txt, d = d_ff = 512): the chain takes ~60 us whatever the row count up to one
-    // panel per CU; the five launches take 37 us at 720 rows, 52 at 1920, 64 at 2400, 66 at 2880, 77-82 at 3360-4096.
+    // Measured window (profiles/r04_chain.txt, d = d_ff = 512): the chain takes 57-58 us whatever the row count (62 at one
+    // panel per CU); the five launches take 37 us at 720 rows, 52 at 1920-2048, then -- the 32 x 64 tiles of a 512-column GEMM
+    // no longer fit two per CU -- 62 from 2112 rows on, 65 at 2880, 77-82 at 3360-4096.
     const int64_t panels = (M + ROWS - 1) / ROWS;
-    return panels >= 144 && panels <= 256;
+    return panels > 128 && panels <= 256;
 }
 
 template <int NV, int WAVES, int WCOLS, int DEPTH, int NSLOT>
