@@ -83,6 +83,11 @@ def under_profiler():
         'rocprofiler' in os.environ.get('LD_PRELOAD', '')
 
 
+def is_chain_kernel(name):
+    """The decoder chain launch in any of its forms (chain.hip: chain_kernel, chain_packed_kernel, chain_rows4_kernel)."""
+    return 'chain_' in name and 'kernel' in name and 'pack_weight' not in name
+
+
 def live_kernel_trace(args):
     """Kernel-only durations measured IN THIS INVOCATION: `rocprofv3 --kernel-trace --stats` around a short run of this
     same script on the same workload (no counters: tracing only, the mode the MI355X guide's profiling recipe starts
@@ -130,7 +135,7 @@ def live_kernel_trace(args):
         return {'skipped': 'no lamp_forward launches in the trace'}
     lamp = [r for r in rows if 'lamp::' in r['Name']]
     short = lambda n: n.split('(')[0].replace('void lamp::', '').replace('lamp::', '')
-    is_gemm = lambda n: 'gemm_nt_kernel' in n or 'chain_kernel' in n
+    is_gemm = lambda n: 'gemm_nt_kernel' in n or is_chain_kernel(n)
     by_kernel = {}
     for r in sorted(lamp, key=lambda r: -float(r['TotalDurationNs'])):
         by_kernel[short(r['Name'])] = {'launches_per_forward': int(r['Calls']) / fwd,
@@ -311,7 +316,7 @@ def roofline_of(prof, n_steps, workload, live=None, chain_gflop=None):
         out['achieved_kernel_only'] = ko
         out['frac_kernel_only'] = ko / PEAK_FP32_MFMA_TFLOPS
         out['kernel_only_source'] = 'live: ' + live['command']
-        chain_us = sum(k['us_per_forward'] for n, k in live['by_kernel'].items() if 'chain_kernel' in n)
+        chain_us = sum(k['us_per_forward'] for n, k in live['by_kernel'].items() if is_chain_kernel(n))
         if chain_us and chain_gflop:
             # the decoder chain launch holds three GEMMs AND their two LayerNorms / residual adds: split the class so that
             # neither hides behind the other (the class figure above stays the conservative sum)
@@ -472,6 +477,8 @@ def main():
                     help='sequence lengths U{lo..hi} padded to the batch maximum (SURVEY.md 8d variant ii) instead of fixed T')
     ap.add_argument('--no-kernel-trace', action='store_true',
                     help='skip the rocprofv3 --kernel-trace --stats sub-run behind roofline.frac_kernel_only (N = 1)')
+    ap.add_argument('--no-chain-packs', action='store_true',
+                    help='A/B switch: run the decoder chain launch from the native weight layouts (no weights-only repack)')
     ap.add_argument('--mask', default=None, choices=['prior', 'none', 'inveye'], help='override the workload label mask')
     args = ap.parse_args()
 
@@ -499,6 +506,9 @@ def main():
 
     from lamp_amd import _native as N
     N.lib()
+    if args.no_chain_packs:
+        from lamp_amd.Models import LAMP
+        LAMP.use_chain_packs = False
     w_base = dict(WORKLOADS[args.workload])
     if args.mask:
         w_base['mask'] = args.mask
@@ -600,8 +610,13 @@ def main():
         live = live_kernel_trace(args)
     # FLOPs of the decoder chain launches of one forward (lamp_amd/csrc/chain.hip; two per decoder layer, each the
     # d x d output projection and the d -> d_ff -> d FFN over the B*L label rows)
+    # one chain per attention block of the decoder: n_layers_dec x (enc-dec attention + label self-attention unless
+    # no_dec_self_att); each = the (h d_v) -> d output projection and the d -> d_ff -> d FFN over the B * L label rows
     rows_dec = args.batch * w['L']
-    chain_gflop = 2 * 2 * (2.0 * rows_dec * w['d'] * w['d'] + 4.0 * rows_dec * w['d'] * w['dff']) / 1e9
+    dec = model.decoder.layer_stack
+    n_chains = sum(2 if hasattr(l, 'slf_attn') else 1 for l in dec)
+    hdv = dec[0].enc_attn.n_head * dec[0].enc_attn.d_v
+    chain_gflop = n_chains * (2.0 * rows_dec * hdv * w['d'] + 4.0 * rows_dec * w['d'] * w['dff']) / 1e9
     roof = roofline_of(prof, prof_steps, args.workload if plain else None, live, chain_gflop)
     if args.ragged and prof['gemm']['ms'] > 0:
         # the launchers count the padded upper bound of the packed encoder's rows: use the real token count

@@ -18,8 +18,9 @@
  *   - every call only enqueues work on `stream` (asynchronous w.r.t. the host) and is re-entrant and
  *     thread-safe for distinct streams / devices (one host thread per device, as nn.DataParallel runs
  *     its replicas, works); the device is the one current for the calling thread.
- *   - no mutable library state: the only process-wide data are lazily initialised, immutable per-device
- *     kernel attributes and -- for diagnostics, mutex-protected -- the lamp_prof_* event records.
+ *   - no library state that results depend on: the process-wide data are lazily initialised, immutable per-device
+ *     kernel attributes, one atomic launch counter (the tag of lamp_forward's plan hand-off granules: it only has
+ *     to differ from launch to launch) and -- for diagnostics, mutex-protected -- the lamp_prof_* event records.
  *   - return value: 0 = ok, > 0 = a hipError_t from a launch, < 0 = lamp_status below.  Nothing
  *     throws or aborts across the boundary.  NaN produced by fully masked attention rows is data,
  *     not an error (reference behaviour).
@@ -38,7 +39,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define LAMP_HIP_ABI_VERSION 2
+#define LAMP_HIP_ABI_VERSION 3
 
 typedef void* lamp_stream_t; /* hipStream_t */
 
@@ -126,6 +127,19 @@ typedef struct lamp_dec_layer {  /* lamp/Layers.py:22-48 */
     lamp_ffn_weights pos_ffn2;
 } lamp_dec_layer;
 
+/* Optional, weights-only: the three weight matrices of one decoder sub-chain -- the attention's output projection `fc`
+ * (lamp/SubLayers.py:110) and the feed-forward block's w_1 / w_2 that follows it (lamp/SubLayers.py:133-142) -- rearranged
+ * by lamp_pack_weight into the order the fused chain launch streams them.  Like dec0_query below they depend on weights
+ * only: a caller may build them once per weight version.  Results are bit-identical with and without them. */
+typedef struct lamp_chain_pack {
+    const float* fc;  /* lamp_pack_weight(fc [d_model, n_head*d_v], format 0) */
+    const float* w1;  /* lamp_pack_weight(w_1 [d_inner, d_model], format 0) */
+    const float* w2;  /* lamp_pack_weight(w_2 [d_model, d_inner], format 0) */
+    const float* fc4; /* the same three in format 1 (panels of 4 / 8 / 12 rows: batches whose B * n_labels rows would */
+    const float* w14; /* leave CUs without a sixteen-row panel); either trio may be NULL */
+    const float* w24;
+} lamp_chain_pack;
+
 /* The whole graph-encoder / graph-decoder model (lamp/Models.py:18-94).  Host-side struct of
  * device pointers; enc_layers / dec_layers are host arrays. */
 typedef struct lamp_model {
@@ -149,6 +163,9 @@ typedef struct lamp_model {
      * 132-134), so a caller may compute it once per weight version (lamp_linear_fwd) and
      * pass it here; NULL = lamp_forward projects it on every call. */
     const float* dec0_query;
+    /* Optional: host array of 2 * n_layers_dec packs -- entry 2 i: layer i's (enc_attn.fc, pos_ffn1), entry 2 i + 1: its
+     * (slf_attn.fc, pos_ffn2); entries with NULL members, or a NULL array, leave that sub-chain on the native layouts. */
+    const lamp_chain_pack* chain_packs;
 } lamp_model;
 
 /* Optional extra outputs of lamp_forward (return_attns / int_preds, lamp/Models.py:127-135).
@@ -250,6 +267,13 @@ int lamp_sigmoid_bce_fwd(const float* logits, const float* targets, int64_t n_ro
  * Ids outside [0, L) are skipped (the reference would index out of range); validate on the host. */
 int lamp_prior_graph_build(const int64_t* label_ids, const int64_t* offsets, int64_t n_samples, int32_t L,
                            float* adj, uint8_t* blocked, lamp_stream_t stream);
+
+/* Weights-only repack for lamp_model.chain_packs: W [N, K] (leading dimension ldw; nn.Linear / Conv1d(k=1) layout) ->
+ * packed [N * K] floats in the order a chain kernel streams them (exact copy of the values, no arithmetic):
+ *   format 0: per block of 16 output rows and 32 k the 16x16x4 MFMA fragments lane by lane (N % 16 == 0, K % 32 == 0);
+ *   format 1: per block of 64 output rows and 16 k, four k per row and load (N % 64 == 0, K % 16 == 0).
+ * 16-byte aligned pointers. */
+int lamp_pack_weight(const float* W, int32_t N, int32_t K, int64_t ldw, int32_t format, float* packed, lamp_stream_t stream);
 
 /* ---- backward-pass building blocks (training through train.py:36-48) ------------------- */
 

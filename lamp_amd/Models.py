@@ -155,6 +155,14 @@ class LAMP(nn.Module):
             ffn(l.pos_ffn2)
         return out
 
+    def _chain_weights(self):
+        out = []
+        for l in self.decoder.layer_stack:
+            for att, ff in ((l.enc_attn, l.pos_ffn1), (getattr(l, 'slf_attn', None), l.pos_ffn2)):
+                if att is not None and getattr(att, 'fc', None) is not None:
+                    out += [att.fc.weight, ff.w_1.weight, ff.w_2.weight]
+        return out
+
     def _native_model(self):
         """Build (and cache, keyed on every weight's data_ptr) the lamp_model struct."""
         replica = getattr(self, '_is_replica', False)
@@ -169,11 +177,14 @@ class LAMP(nn.Module):
         tiles = self.decoder.label_tiles
         bits = self.decoder.label_mask_bits
         hoist = self.cache_layer0_query and not replica   # the hoisted projection needs a one-off stream sync
+        packs = self.use_chain_packs and not replica      # weights-only repacks: same one-off cost, same staleness rule
         key = tuple(p.data_ptr() for p in params) + (N.ptr(mask), N.ptr(bits), N.ptr(tiles), self.use_label_tiles,
-                                                      hoist, self.use_mask_bits)
+                                                      hoist, self.use_mask_bits, packs)
         if hoist:  # the hoisted projection below is stale once either operand changes
             l0 = self.decoder.layer_stack[0].enc_attn
             key += (self.decoder.tgt_word_emb.weight._version, l0.w_qs.weight._version)
+        if packs:
+            key += tuple(w._version for w in self._chain_weights())
         cache = None if replica else self._native_cache
         if cache is not None and cache[0] == key:
             return cache[1]
@@ -208,7 +219,27 @@ class LAMP(nn.Module):
             # forwards may be issued from several streams (evaluate.test_epoch(streams=2)); the cached
             # projection must be complete before any of them reads it -- a one-off sync per weight version
             torch.cuda.current_stream().synchronize()
-        built = (m, enc_arr, dec_arr, q0)
+        pack_arr = pack_keep = None
+        if packs and len(dec.layer_stack) > 0:
+            # the decoder sub-chains' weights in the order the fused chain launch streams them (lamp_pack_weight): weights
+            # only, rebuilt once per weight version like the hoisted query above; same bits with and without
+            pack_arr = (N.ChainPack * (2 * len(dec.layer_stack)))()
+            pack_keep = []
+            for i, l in enumerate(dec.layer_stack):
+                for j, (att, ff) in enumerate(((l.enc_attn, l.pos_ffn1), (getattr(l, 'slf_attn', None), l.pos_ffn2))):
+                    if att is None or getattr(att, 'fc', None) is None:
+                        continue
+                    ptrs = []
+                    for fmt in (0, 1):
+                        trio = [N.weight_pack(w, fmt) for w in (att.fc.weight, ff.w_1.weight, ff.w_2.weight)]
+                        if any(t is None for t in trio):
+                            trio = [None] * 3
+                        pack_keep.append(trio)
+                        ptrs += [N.ptr(t) for t in trio]
+                    pack_arr[2 * i + j] = N.ChainPack(*ptrs)
+            m.chain_packs = pack_arr
+            torch.cuda.current_stream().synchronize()
+        built = (m, enc_arr, dec_arr, q0, pack_arr, pack_keep)
         if not replica:
             self._native_cache = (key, built)
         return built
@@ -272,7 +303,7 @@ class LAMP(nn.Module):
         pos = src_pos.long().contiguous()
         B, T = seq.shape
         L, d = self.n_labels, self.d_model
-        model, enc_arr, dec_arr, _q0 = self._native_model()
+        model, enc_arr, dec_arr = self._native_model()[:3]
         Ne, Nd = model.n_layers_enc, model.n_layers_dec
 
         logits = torch.empty((B, L), dtype=torch.float32, device=dev)
@@ -322,6 +353,8 @@ class LAMP(nn.Module):
     workspace_limit_bytes = 8 << 30
     # Hoist decoder layer 0's (weights-only) query projection out of the per-batch path.
     cache_layer0_query = True
+    # Keep fragment-major copies of the decoder sub-chains' weight matrices (lamp_pack_weight) for the fused chain launch.
+    use_chain_packs = True
     # Skip fully blocked 32x32 tiles of the label graph in the label->label attention.
     use_label_tiles = True
     # Read the label mask bit-packed (one 32-bit word per 32-key tile and row) instead of as bytes.

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LAMP_HIP_LIBRARY') or os.path.join(_HERE, 'liblamp_hip.so')
 TUNING_LIB_PATH = os.path.join(_HERE, 'liblamp_hip_tuning.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 LAMP_MASK_NONE, LAMP_MASK_U8, LAMP_MASK_KEY_TOKENS_I64, LAMP_MASK_BITS_U32 = 0, 1, 2, 3
 K_EMBED, K_GEMM, K_ATTN, K_LAYERNORM, K_DIAG, K_COUNT = 0, 1, 2, 3, 4, 5
 KERNEL_CLASS_NAMES = ('embed', 'gemm', 'attention', 'layernorm', 'diag_readout')
@@ -61,13 +61,17 @@ class DecLayer(C.Structure):
                 ('pos_ffn2', FfnWeights)]
 
 
+class ChainPack(C.Structure):  # include/lamp_hip.h: lamp_chain_pack
+    _fields_ = [('fc', _vp), ('w1', _vp), ('w2', _vp), ('fc4', _vp), ('w14', _vp), ('w24', _vp)]
+
+
 class Model(C.Structure):
     _fields_ = [('n_src_vocab', C.c_int32), ('n_position', C.c_int32), ('n_labels', C.c_int32),
                 ('d_model', C.c_int32), ('d_inner', C.c_int32), ('d_k', C.c_int32), ('d_v', C.c_int32),
                 ('n_layers_enc', C.c_int32), ('n_layers_dec', C.c_int32), ('reserved', C.c_int32),
                 ('src_word_emb', _vp), ('position_enc', _vp), ('tgt_word_emb', _vp), ('w_out', _vp),
                 ('label_mask', _vp), ('label_mask_bits', _vp), ('label_tiles', _vp), ('enc_layers', C.POINTER(EncLayer)), ('dec_layers', C.POINTER(DecLayer)),
-                ('dec0_query', _vp)]
+                ('dec0_query', _vp), ('chain_packs', C.POINTER(ChainPack))]
 
 
 class GemmDesc(C.Structure):  # include/lamp_hip.h: lamp_gemm_desc
@@ -103,6 +107,7 @@ PROTOTYPES = {
     'lamp_ffn_fwd': (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(FfnWeights), _vp, _vp, _sz, _vp]),
     'lamp_embed_fwd': (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     'lamp_diag_logits_fwd': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'lamp_pack_weight': (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp]),
     'lamp_gemm_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'lamp_gemm': (C.c_int, [C.POINTER(GemmDesc), _vp, _sz, _vp]),
     'lamp_layernorm_residual_fwd': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _f, _f, C.c_uint32, _vp, _vp]),
@@ -136,12 +141,19 @@ def load_library(path):
             'lamp_amd: %s is missing -- build it with `python -m lamp_amd.build` '
             '(hipcc, gfx950).  There is no CPU or PyTorch fallback.' % path)
     handle = C.CDLL(path)
+    handle.lamp_version.restype = C.c_int
+    version = handle.lamp_version()
+    # A/B runs against a build of an earlier round (tools/build_variant.sh): ABI 2 is a prefix of ABI 3 -- lamp_model
+    # grew one trailing member an older library never reads, lamp_pack_weight is absent (weight_pack() then returns None)
+    old_ok = version == 2 and os.environ.get('LAMP_ALLOW_OLD_ABI') == '1'
+    if version != ABI_VERSION and not old_ok:
+        raise RuntimeError('lamp_amd: ABI version mismatch in ' + path)
     for name, (res, args) in PROTOTYPES.items():
+        if old_ok and not hasattr(handle, name):
+            continue
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args
-    if handle.lamp_version() != ABI_VERSION:
-        raise RuntimeError('lamp_amd: ABI version mismatch in ' + path)
     return handle
 
 
@@ -395,6 +407,21 @@ def embed(src_seq, src_pos, emb, pos_table):
                                ptr(f32c(pos_table)) if pos_table is not None else 0,
                                pos_table.size(0) if pos_table is not None else 0, d, ptr(out), stream()),
           'lamp_embed_fwd')
+    return out
+
+
+def weight_pack(w, fmt=0):
+    """lamp_pack_weight: a [N, K] weight (Conv1d(k=1) weights [N, K, 1] are read as [N, K]) in the order the fused decoder
+    chain streams it (format 0: 16x16x4 fragments, format 1: 64-column panels of the 4x4x1 kernel), or None when the shape
+    has no packed form or the library predates it."""
+    require_device(w)
+    w = f32c(w.detach())
+    n, k = w.size(0), w.size(1)
+    fn = getattr(lib(), 'lamp_pack_weight', None)
+    if fn is None or (n % 16 or k % 32 if fmt == 0 else n % 64 or k % 16):
+        return None
+    out = torch.empty(n * k, dtype=torch.float32, device=w.device)
+    check(fn(ptr(w), n, k, k, fmt, ptr(out), stream()), 'lamp_pack_weight')
     return out
 
 

@@ -124,6 +124,7 @@ struct FfnTail {
     int n_labels;
     float* logits;
     bool done;
+    const lamp_chain_pack* pk;   // nullable: weights-only packed copies of (fc, w1, w2) for the chain launch
 };
 
 // MultiHeadAttention.forward (lamp/SubLayers.py:77-121).  `xq_shared`: xq is ONE [lq, d] block used
@@ -221,11 +222,11 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     const int64_t M = int64_t(B) * lq;
     const int64_t r_mod = xq_shared ? lq : 0;
     if (tail) tail->done = false;
-    if (h > 1 && tail && tail->ffn && chain_applies(M, d, hdv, tail->dff, true)) {
+    if (h > 1 && tail && tail->ffn && chain_applies(M, d, hdv, tail->dff, true, tail->pk)) {
         // fc (+ residual) -> LayerNorm -> W1 -> W2 (+ residual) -> LayerNorm in one launch over 16-row panels (same bits)
         tail->done = true;
         return launch_chain(sc.A, hdv, hdv, xq, r_mod, M, d, w.fc, w.ln_g, w.ln_b, tail->ffn, tail->dff,
-                            tail->w_out ? nullptr : out, tail->w_out, tail->n_labels, tail->logits, s);
+                            tail->w_out ? nullptr : out, tail->w_out, tail->n_labels, tail->logits, s, tail->pk);
     }
     if (h > 1) {
         const float* W[1] = {w.fc};
@@ -445,6 +446,10 @@ int lamp_embed_fwd(const int64_t* src_seq, const int64_t* src_pos, int64_t n_tok
                    lamp_stream_t stream) {
     return launch_embed(src_seq, src_pos, n_tokens, emb, n_vocab, pos_table, n_position, d_model, out,
                         hipStream_t(stream));
+}
+
+int lamp_pack_weight(const float* W, int32_t N, int32_t K, int64_t ldw, int32_t format, float* packed, lamp_stream_t stream) {
+    return launch_pack_weight(W, N, K, ldw, format, packed, hipStream_t(stream));
 }
 
 int lamp_diag_logits_fwd(const float* y, const float* w_out, int32_t B, int32_t L, int32_t d_model,
@@ -713,8 +718,9 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             // the feed-forward block behind each attention block rides in the attention's tail launch when the shape
             // allows (chain.hip: same bits either way); pos_ffn2 follows the self-attention, or pos_ffn1 when there is none
             const bool last = i + 1 == m->n_layers_dec;
-            FfnTail t1{&l.pos_ffn1, dff, nullptr, 0, nullptr, false};
-            FfnTail t2{&l.pos_ffn2, dff, last ? m->w_out : nullptr, L, last ? logits + b0 * L : nullptr, false};
+            const lamp_chain_pack* pk = m->chain_packs ? m->chain_packs + 2 * i : nullptr;
+            FfnTail t1{&l.pos_ffn1, dff, nullptr, 0, nullptr, false, pk};
+            FfnTail t2{&l.pos_ffn2, dff, last ? m->w_out : nullptr, L, last ? logits + b0 * L : nullptr, false, pk ? pk + 1 : nullptr};
             if (i == 0)
                 LAMP_CK(mha_core(m->tgt_word_emb, true, xk, nb, L, T, d, dk, dv, l.enc_attn, &pad_mask, Y, Penc, sci, s,
                                  ahead, m->dec0_query, B, int(b0), &sp, packed, x, &t1));

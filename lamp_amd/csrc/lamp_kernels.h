@@ -134,10 +134,11 @@ int launch_layernorm(const float* x, int64_t M, int d, const float* g, const flo
 // chain.hip: the row-local tail of a decoder block -- attention output projection (+ residual) -> LayerNorm [-> FFN ->
 // LayerNorm] -- as ONE launch over 16-row panels, bit-identical to the separate launches.  chain_applies: shape limits
 // (LDS residency, tiling) and the row-count heuristic (at most one panel per CU).
-bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn);
+bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn, const lamp_chain_pack* pk = nullptr);
 int launch_chain(const float* A, int64_t lda, int k_h, const float* res, int64_t r_mod, int64_t M, int d, const float* w_fc,
                  const float* ln1_g, const float* ln1_b, const lamp_ffn_weights* ffn, int dff, float* y, const float* w_out,
-                 int n_labels, float* logits, hipStream_t s);
+                 int n_labels, float* logits, hipStream_t s, const lamp_chain_pack* pk = nullptr);
+int launch_pack_weight(const float* W, int N, int K, int64_t ldw, int format, float* out, hipStream_t s);
 size_t layernorm_bwd_workspace_bytes(int64_t M, int d);
 int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_t M, int d, const float* g, float eps,
                          const DropoutSpec* drop, const float* dy, float* dz, float* dz_drop, float* dgamma, float* dbeta,

@@ -516,10 +516,12 @@ def test_decoder_chain_launch_is_bit_identical(dev, tuning, monkeypatch, name, B
     assert max_abs_diff(got, ref) < TOL_LOGIT
 
 
-@pytest.mark.parametrize('geometry', [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('geometry', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_decoder_chain_every_geometry_is_bit_identical(dev, tuning, monkeypatch, geometry):
-    """The chain kernel's other geometries (waves x columns per wave, register sets of the W stream, LDS slots; tuning build):
-    same fragments, same k-order -- the bits of the separate launches, ragged batch with a partial last panel."""
+    """Every geometry of the chain launch (tuning build) -- waves x columns per wave, register sets of the W stream, LDS slots
+    (0-4), W fragments straight from the native layout (5, 6), from the packed weights (7-10), and the round-5 kernel on packed
+    weights with the LayerNorm / bias operands in LDS (11-14), panels of 4 / 8 / 12 rows on the 4x4x1 MFMA (15-17): same k-order -- the bits of the separate
+    launches, ragged batch with a partial last panel."""
     import ctypes
     from lamp_amd import _native as N
     cfg = list(CONFIGS['reuters_ragged'])
@@ -541,7 +543,7 @@ def test_decoder_chain_every_geometry_is_bit_identical(dev, tuning, monkeypatch,
             assert torch.equal(got, want)
     finally:
         force(-1)
-        geom(0)
+        geom(-1)
 
 
 @pytest.mark.parametrize('seed', range(10))
@@ -622,6 +624,112 @@ def test_decoder_chain_without_self_attention_and_odd_batches(dev, tuning, monke
     with torch.no_grad():
         ref, _, _ = R.forward(sd, seq[:4].cpu(), spos[:4].cpu(), h, R.label_block_mask(adj, 'prior', L))
     assert max_abs_diff(big[:4], ref) < TOL_LOGIT
+
+
+def test_weight_pack_formats_are_exact_rearrangements(dev):
+    """lamp_pack_weight (the weights-only repack behind lamp_model.chain_packs): both formats are pure gathers of W -- format 0
+    per 16 columns x 32 k the two 16x16x4 fragment chunks lane by lane, format 1 per 64 columns x 16 k the four k-quads column
+    by column -- checked element for element against index arithmetic (include/lamp_hip.h: lamp_pack_weight)."""
+    from lamp_amd import _native as N
+    g = torch.Generator().manual_seed(5)
+    for n, k in ((64, 32), (512, 512), (1024, 512), (128, 1024)):
+        w = torch.randn(n, k, generator=g)
+        p0 = N.weight_pack(w.to(dev), 0).cpu()
+        l = torch.arange(64)
+        want0 = w.view(n // 16, 16, k // 32, 2, 4, 4)          # [cb, row, kt, c, quad, j]
+        want0 = want0.permute(0, 2, 3, 4, 1, 5)                # [cb, kt, c, quad (= lane >> 4), row (= lane & 15), j]
+        assert torch.equal(p0, want0.reshape(-1)), (n, k)
+        p1 = N.weight_pack(w.to(dev), 1).cpu()
+        want1 = w.view(n // 64, 64, k // 16, 4, 4).permute(0, 2, 3, 1, 4)   # [cb, ch, quad, column (= lane), j]
+        assert torch.equal(p1, want1.reshape(-1)), (n, k)
+    assert N.weight_pack(torch.randn(24, 48).to(dev), 0) is None and N.weight_pack(torch.randn(32, 64).to(dev), 1) is None
+    with pytest.raises(N.LampError):   # misaligned source
+        big = torch.randn(64 * 32 + 1).to(dev)
+        out = torch.empty(64 * 32, device=dev)
+        N.check(N.lib().lamp_pack_weight(big.data_ptr() + 4, 64, 32, 32, 0, out.data_ptr(), N.stream()), 'lamp_pack_weight')
+
+
+def test_chain_routes_of_the_product_library_give_every_sample_the_same_bits(dev):
+    """PRODUCT library, no debug hook: the decoder's row-local tail runs, by row count, as five launches (< 512 rows, > 4096),
+    as panels of 4, 8 or 12 rows on the 4x4x1 MFMA (<= 1024 / 2048 / 3072 rows), or as sixteen-row panels (<= 4096) -- from packed
+    weights -- and from the native weight layouts (use_chain_packs = False: sixteen-row panels for 2049-4096 rows).  One pool
+    of samples through every route: each sample's logits, encoder rows and intermediate read-outs come out bit-identical
+    whatever batch it rides in, with and without the packs; a weight update through .data invalidates the packs."""
+    from lamp_amd.Models import LAMP
+    V, L, T, d, dff, h = 400, 90, 24, 512, 512, 4
+    sd = R.make_state_dict(V, L, T, d, dff, h, 1, 2, pos_emb=True, seed=11)
+    adj = R.make_adjacency(L, 0.1, 11)
+    m = LAMP(V, L, T, L, n_layers_enc=1, n_layers_dec=2, n_head=h, n_head2=h, d_word_vec=d, d_model=d, d_inner_hid=dff,
+             d_k=d // h, d_v=d // h, encoder='graph', decoder='graph', label_adj_matrix=adj.clone(), label_mask='prior',
+             dec_dropout2=False)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    B = 50
+    seq, spos = R.make_batch(B, V, T, lengths=[T, 3, 17, 9, 24] * 10, seed=11)
+    seq, spos = seq.to(dev), spos.to(dev)
+    assert m.use_chain_packs
+    ref, enc_ref, ip_ref = m((seq, spos), None, None, None, int_preds=True)       # 4500 rows: separate launches
+    packs = m._native_model()[4]
+    assert packs is not None and packs[0].fc and packs[0].fc4 and packs[3].w24
+    for b in (4, 8, 12, 20, 24, 32, 40, 45):   # 360 (separate), 720, 1080, 1800, 2160, 2880, 3600, 4050 rows
+        for lo in (0, B - b):
+            got, enc, ip = m((seq[lo:lo + b], spos[lo:lo + b]), None, None, None, int_preds=True)
+            assert torch.equal(got, ref[lo:lo + b]) and torch.equal(enc, enc_ref[lo:lo + b]), (b, lo)
+            assert all(torch.equal(a, w[lo:lo + b]) for a, w in zip(ip, ip_ref)), (b, lo)
+            plain, _, _ = m((seq[lo:lo + b], spos[lo:lo + b]), None, None, None)
+            assert torch.equal(plain, got), (b, lo)
+    try:
+        LAMP.use_chain_packs = False
+        m.invalidate_native_cache()
+        assert m._native_model()[4] is None
+        for b in (20, 32, 40):
+            got, _, ip = m((seq[:b], spos[:b]), None, None, None, int_preds=True)
+            assert torch.equal(got, ref[:b]) and all(torch.equal(a, w[:b]) for a, w in zip(ip, ip_ref)), b
+    finally:
+        LAMP.use_chain_packs = True
+        m.invalidate_native_cache()
+    # the packs follow the weights: an in-place update (what an optimiser does) must not leave a stale copy behind
+    with torch.no_grad():
+        m.decoder.layer_stack[1].pos_ffn2.w_2.weight.mul_(1.5)
+    m.invalidate_native_cache()
+    upd, _, _ = m((seq[:32], spos[:32]), None, None, None)
+    small, _, _ = m((seq[:4], spos[:4]), None, None, None)          # separate launches read the weights themselves
+    assert torch.equal(upd[:4], small) and not torch.equal(upd, ref[:32])
+
+
+def test_chain_launches_survive_a_busy_neighbour_stream(dev):
+    """The hand-scheduled chain kernels under contention: 300 back-to-back forwards at the headline decoder shape (2880 rows:
+    twelve-row panels) and 100 at 3600 rows (sixteen-row panels) while a second stream keeps the K/V-projection GEMM running on
+    the same device -- every result equals the first, bit for bit.  A load consumed before it landed would not repeat."""
+    from lamp_amd import _native as N
+    from lamp_amd.Models import LAMP
+    V, L, T, d, dff, h = 400, 90, 30, 512, 512, 4
+    sd = R.make_state_dict(V, L, T, d, dff, h, 2, 2, pos_emb=True, seed=2)
+    adj = R.make_adjacency(L, 0.1, 2)
+    m = LAMP(V, L, T, L, n_layers_enc=2, n_layers_dec=2, n_head=h, n_head2=h, d_word_vec=d, d_model=d, d_inner_hid=dff,
+             d_k=d // h, d_v=d // h, encoder='graph', decoder='graph', label_adj_matrix=adj.clone(), label_mask='prior',
+             dec_dropout2=False)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    seq, spos = R.make_batch(40, V, T, seed=2)
+    seq, spos = seq.to(dev), spos.to(dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(9664, 512, generator=g).to(dev)
+    w = (torch.randn(2048, 512, generator=g) / 512 ** 0.5).to(dev)
+    side = torch.cuda.Stream(device=dev)
+    for b, n in ((32, 300), (40, 100)):
+        src = (seq[:b], spos[:b])
+        first, enc_first, _ = m(src, None, None, None)
+        torch.cuda.synchronize()
+        outs = []
+        for i in range(n):
+            if i % 4 == 0:
+                with torch.cuda.stream(side):
+                    N.linear(x, w)
+            outs.append(m(src, None, None, None)[0])
+        torch.cuda.synchronize()
+        bad = [i for i, o in enumerate(outs) if not torch.equal(o, first)]
+        assert not bad, (b, bad[:10])
 
 
 def test_requested_maps_do_not_change_logits(dev):
@@ -944,7 +1052,7 @@ def test_errors_surface_as_status_codes_not_crashes(dev):
     assert max_abs_diff(o, ref_o) < 5e-5 and max_abs_diff(a, ref_a) < TOL_ATTN
     # workspace one byte short of a single sample: LAMP_E_WORKSPACE
     m, sd, blocked, seq, spos, h = make_case(CONFIGS['inveye_8h'], dev)
-    model, enc_arr, dec_arr, _q0 = m._native_model()
+    model, enc_arr, dec_arr = m._native_model()[:3]
     B, T = seq.shape
     need = lib.lamp_forward_workspace_bytes(ctypes.byref(model), 1, T, 0)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)

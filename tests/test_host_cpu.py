@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(N.PROTOTYPES) == names  # the ctypes binding covers the whole header
-    assert N.lib().lamp_version() == N.ABI_VERSION == 2
+    assert N.lib().lamp_version() == N.ABI_VERSION == 3
     # the product library exports no tuning / debug hook (those live in the -DLAMP_TUNING build only)
     exported = subprocess.run(['nm', '-D', '--defined-only', N.LIB_PATH], capture_output=True, text=True).stdout
     assert 'lamp_debug' not in exported and 'lamp_set_forward_streams' not in exported
@@ -55,7 +55,8 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(N.FfnWeights) == 48
     assert ctypes.sizeof(N.EncLayer) == 104
     assert ctypes.sizeof(N.DecLayer) == 208
-    assert ctypes.sizeof(N.Model) == 120
+    assert ctypes.sizeof(N.Model) == 128
+    assert ctypes.sizeof(N.ChainPack) == 48
     assert ctypes.sizeof(N.Aux) == 40
     assert ctypes.sizeof(N.GemmDesc) == 160
 
@@ -218,14 +219,14 @@ def test_bench_refuses_to_run_without_a_gpu_and_its_spawner_does_not_hang():
 
 def test_bench_kernel_trace_parsing_and_roofline_split(monkeypatch, tmp_path):
     """bench.py's kernel-only figures come from a rocprofv3 --kernel-trace --stats sub-run: the reading of its
-    p_kernel_stats.csv (per-forward normalisation by the gather launches, GEMM class = gemm_nt_kernel + chain_kernel) and
+    p_kernel_stats.csv (per-forward normalisation by the gather launches, GEMM class = gemm_nt_kernel + the chain launch in any of its forms) and
     the roofline split are host logic -- checked here against a hand-written trace, with the profiler call replaced."""
     import argparse
     import importlib
     import sys
     sys.path.insert(0, ROOT)
     bench = importlib.import_module('bench')
-    rows = [('void lamp::chain_kernel<2, 8, 64, 2, 1>(lamp::ChainParams)', 40, 60000.0),
+    rows = [('void lamp::chain_rows4_kernel<2, 3>(lamp::ChainParams)', 40, 60000.0),
             ('void lamp::gemm_nt_kernel<64, 64, 16, 2, 2, false, 16, true, true, 0>(lamp::GemmParams, int)', 40, 45000.0),
             ('void lamp::gemm_nt_kernel<128, 64, 16, 2, 2, false, 16, false, true, 0>(lamp::GemmParams, int)', 10, 158000.0),
             ('void lamp::attn16_kernel<128, 1, 4, 0, 3>(lamp::AttnParams)', 20, 25000.0),
@@ -250,7 +251,8 @@ def test_bench_kernel_trace_parsing_and_roofline_split(monkeypatch, tmp_path):
     assert live['forwards_traced'] == 10
     assert abs(live['gemm_class_us_per_forward'] - (4 * 60.0 + 4 * 45.0 + 158.0)) < 1e-9
     assert abs(live['all_kernels_us_per_forward'] - (578.0 + 2 * 25.0 + 12.0)) < 1e-9   # the runtime's copy kernel is not ours
-    assert list(live['by_kernel'])[0].startswith('chain_kernel') and live['by_kernel']['embed_plan_kernel']['launches_per_forward'] == 1.0
+    assert list(live['by_kernel'])[0].startswith('chain_rows4_kernel') and bench.is_chain_kernel('lamp::chain_packed_kernel<2, 16, 32, 4>') and\
+        not bench.is_chain_kernel('lamp::pack_weight_kernel<1>') and live['by_kernel']['embed_plan_kernel']['launches_per_forward'] == 1.0
     # 10 steps of 69.2 GFLOP in the GEMM class, 18.1 of them in the chain launches
     prof = {'gemm': {'flops': 69.2e9 * 10, 'ms': 7.0, 'launches': 120, 'bytes': 1e9}}
     roof = bench.roofline_of(prof, 10, None, live, 18.1)

@@ -1,0 +1,89 @@
+"""Build-time guards of the hand-scheduled kernels (CPU only: hipcc cross-compiles gfx950 without a GPU).
+
+chain.hip issues loads from inline assembly with hand-counted waits; the compiler does not know those registers are in
+flight.  Two failure modes have produced silently wrong results in this repository's history (profiles/r04_rejected_experiments.txt
+#4): spilled / AGPR-parked W-stream registers overwritten by loads still in flight, and register copies placed
+right behind an untracked load.  Neither is visible to a parity test that happens to pass; both are visible in the compiler's
+own resource report and in the ISA:
+  * every kernel lamp_forward can reach has ScratchSize 0 (two known, harmless exceptions are pinned by name and size), and the
+    chain kernels use no AGPRs (lamp_amd.build keeps hipcc's -Rpass-analysis=kernel-resource-usage report beside each object);
+  * tools/check_untracked_loads.py finds no instruction that touches the destination of an inline-assembly load before a wait.
+"""
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+from lamp_amd import build as B
+
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import check_untracked_loads as CUL  # noqa: E402
+
+# kernels allowed to spill: (translation unit, name) -> max bytes per lane.  Neither uses inline-assembly loads.
+KNOWN_SCRATCH = {
+    ('attention.hip', 'lamp::attn_kernel<128, 1, 0, 1>'): 16,        # u8-mask variant of the large attention (cold path: the forward
+                                                                     # hands the label graph over bit-packed)
+    ('backward.hip', 'lamp::layernorm_bwd_kernel<16, true, 3>'): 160,  # training only
+}
+FORWARD_UNITS = ['gemm.hip', 'chain.hip', 'attention.hip', 'attention_small.hip', 'attention_general.hip', 'pointwise.hip']
+
+
+@pytest.mark.parametrize('tuning', [False, True])
+def test_no_kernel_spills_and_the_chain_uses_no_agprs(tuning):
+    seen = 0
+    for unit in B.SOURCES:
+        if unit == 'api.hip' or (tuning and unit not in B.TUNING_SOURCES):
+            continue
+        res = B.kernel_resources(unit, tuning)
+        assert res, unit
+        for name, r in res.items():
+            seen += 1
+            allowed = KNOWN_SCRATCH.get((unit, name), 0)
+            if tuning and 'gemm_pair_kernel' in name:
+                allowed = 80   # the rejected counter-chained FFN pair (profiles/r04_rejected_experiments.txt #11): tuning build only
+            assert r.get('scratch', 0) <= allowed, (unit, name, r)
+            if 'chain' in name and 'kernel' in name:
+                # the W stream's registers must stay where the in-flight loads will write them
+                assert r.get('agpr', 0) == 0 and r.get('scratch', 0) == 0, (name, r)
+    assert seen > 100
+    # the production chain kernels exist in the product build (what lamp_forward launches at batch 32)
+    prod = B.kernel_resources('chain.hip', False)
+    for want in ('lamp::chain_kernel<2, 16, 32, 2, 1>', 'lamp::chain_packed_kernel<2, 16, 32, 4>', 'lamp::chain_rows4_kernel<2, 3>'):
+        assert want in prod, sorted(prod)
+        assert prod[want]['occupancy'] >= (2 if 'rows4' in want else 4), prod[want]
+
+
+def test_checker_sees_a_copy_behind_an_untracked_load():
+    """The exact shape of round 5's bug (LayerNorm operands read under `if`): the merge's copies right behind the read."""
+    bad = '''
+_ZN4lamp12chain_kernelILi2ELi16ELi32ELi2ELi1EEEvNS_11ChainParamsE:
+	s_cbranch_vccnz .LBB0_2
+	;;#ASMSTART
+	ds_read_b128 v[28:31], v0
+	;;#ASMEND
+	s_nop 0
+	v_mov_b32_e32 v38, v29
+.LBB0_2:
+	;;#ASMSTART
+	s_waitcnt lgkmcnt(0)
+	;;#ASMEND
+	v_add_f32_e32 v1, v28, v2
+	s_endpgm
+'''
+    kernels, loads, findings = CUL.check(bad)
+    assert kernels == 1 and loads == 1 and len(findings) == 1 and 'v_mov_b32' in findings[0][4]
+    good = bad.replace('\tv_mov_b32_e32 v38, v29\n', '')
+    assert CUL.check(good)[2] == []
+    # a register in flight overwritten before its wait
+    clobber = bad.replace('v_mov_b32_e32 v38, v29', 'v_mov_b32_e32 v30, v2')
+    assert len(CUL.check(clobber)[2]) == 1
+
+
+@pytest.mark.parametrize('flags', [(), ('-DLAMP_TUNING',)])
+def test_no_instruction_touches_an_inline_assembly_load_before_a_wait(flags):
+    asm = CUL.device_asm(os.path.join(ROOT, 'lamp_amd', 'csrc', 'chain.hip'), flags)
+    kernels, loads, findings = CUL.check(asm)
+    assert kernels >= 12 and loads > 1000
+    assert findings == [], findings[:5]

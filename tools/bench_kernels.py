@@ -342,14 +342,16 @@ def chain():
     fnc = lib.lamp_debug_launch_chain
     fnc.restype = ctypes.c_int
     fnc.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
-                    ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+                    ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_void_p] * 6
+    pk = [N.weight_pack(w, f) for f in (0, 1) for w in (wfc, w1, w2)]
     hook = lib.lamp_debug_set_chain_trace
     hook.argtypes = [ctypes.c_void_p]
     hook.restype = None
 
     def fused():
         N.check(fnc(A.data_ptr(), d, d, Y.data_ptr(), 0, M, d, wfc.data_ptr(), g1.data_ptr(), be1.data_ptr(), w1.data_ptr(),
-                    b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), g2.data_ptr(), be2.data_ptr(), dff, out.data_ptr(), N.stream()), 'chain')
+                    b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), g2.data_ptr(), be2.data_ptr(), dff, out.data_ptr(), N.stream(),
+                    *[t.data_ptr() for t in pk]), 'chain')
 
     def separate():
         st = N.stream()
@@ -363,7 +365,13 @@ def chain():
     geom.restype = None
     GEOMS = {0: '16 waves x 32 cols, 2 reg sets, 1 slot', 1: '8 x 32, 4 sets, 2 slots', 2: '8 x 32, 2 sets, 2 slots',
              3: '8 x 32, 4 sets, 1 slot', 4: '8 waves x 64 cols, 2 sets, 1 slot',
-             5: 'W direct: 16 x 32, 2 sets', 6: 'W direct: 8 x 64, 4 sets'}
+             5: 'W direct: 16 x 32, 2 sets', 6: 'W direct: 8 x 64, 4 sets', 7: 'W packed: 16 x 32, 2 sets',
+             8: 'W packed: 16 x 32, 4 sets', 9: 'W packed: 8 x 64, 2 sets', 10: 'W packed: 8 x 64, 4 sets',
+             11: 'packed kernel: 16 x 32, 2 sets', 12: 'packed kernel: 16 x 32, 4 sets', 13: 'packed kernel: 8 x 64, 2 sets',
+             14: 'packed kernel: 8 x 64, 4 sets', 15: '4x4x1 kernel: 4-row panels', 16: '4x4x1 kernel: 8-row panels',
+             17: '4x4x1 kernel: 12-row panels'}
+    if len(sys.argv) > 4:
+        GEOMS = {int(k): GEOMS[int(k)] for k in sys.argv[4].split(',')}
     separate()
     for gi in sorted(GEOMS):
         geom(gi)
@@ -377,16 +385,18 @@ def chain():
         for gi in sorted(GEOMS):
             geom(gi)
             print('chain launch, geometry %d (%s): %.1f us' % (gi, GEOMS[gi], statistics.median(time_fn(fused, iters=20, warm=3) for _ in range(7))))
-    geom(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+    tgeom = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    geom(tgeom)
+    print('# timeline of geometry %d' % tgeom)
     n_wg = (M + 15) // 16
-    buf = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(n_wg * 24, dtype=torch.int64, device=dev)
     for _ in range(5):
         fused()
     hook(buf.data_ptr())
     fused()
     torch.cuda.synchronize()
     hook(None)
-    t = buf.cpu().view(n_wg, 8).double()
+    t = buf.cpu().view(n_wg, 24).double()
     t0 = t[:, 0].min()
     ghz = (t[:, 6] / ((t[:, 5] - t[:, 0]) * 10.0)).median().item()
     print('# shader clock during the chain (s_memtime cycles / wall_clock64 time, median over workgroups): %.3f GHz' % ghz)
@@ -402,6 +412,13 @@ def chain():
             line += '   phase p50 %6.2f max %6.2f' % (q(ph, 0.5), ph.max().item())
         print(line)
         prev = t[:, i]
+    # wave 0's shader-clock stamps inside each GEMM step: prologue (first stages requested and landed), k loop, epilogue + barrier
+    cyc = lambda a: '%7.0f' % q(a, 0.5)  # noqa: E731
+    print('# wave 0, shader cycles (median over workgroups): prologue / k loop / epilogue + barrier / whole step')
+    for gi, nm in enumerate(('fc', 'W1', 'W2')):
+        g = t[:, 8 + 4 * gi: 12 + 4 * gi]
+        print('%-4s %s %s %s %s   (%.2f us at %.3f GHz)' % (nm, cyc(g[:, 1] - g[:, 0]), cyc(g[:, 2] - g[:, 1]), cyc(g[:, 3] - g[:, 2]),
+                                                           cyc(g[:, 3] - g[:, 0]), q(g[:, 3] - g[:, 0], 0.5) / ghz / 1e3, ghz))
 
 
 def attn_lib_ab(rounds=9):

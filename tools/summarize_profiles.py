@@ -42,7 +42,7 @@ def kernel_only_gemm_us(src, wl):
     fwd = sum(int(r['Calls']) for r in rows if 'seq_plan_kernel' in r['Name'] or 'embed_plan_kernel' in r['Name'])
     # (the decoder chain launch is the GEMM class of the bench line too: its FLOPs are the three GEMMs it holds, its
     # time includes their two LayerNorms)
-    ns = sum(float(r['TotalDurationNs']) for r in rows if 'gemm_nt_kernel' in r['Name'] or 'chain_kernel' in r['Name'])
+    ns = sum(float(r['TotalDurationNs']) for r in rows if 'gemm_nt_kernel' in r['Name'] or ('chain_' in r['Name'] and 'kernel' in r['Name'] and 'pack_weight' not in r['Name']))
     return ns / fwd / 1e3 if fwd else None
 
 
@@ -127,7 +127,7 @@ def main():
         for (n, g, f), (_, _, w) in zip(res['FETCH_SIZE'], res['WRITE_SIZE']):
             fm, wm = f * 1024 * 2 / 1e6, w * 1024 / 1e6
             tf, tw = tf + fm, tw + wm
-            if 'gemm_nt_kernel' in n or 'chain_kernel' in n:
+            if 'gemm_nt_kernel' in n or ('chain_' in n and 'kernel' in n and 'pack_weight' not in n):
                 gf, gw, ng = gf + fm, gw + wm, ng + 1
             L.append('%-46s %10d %12.2f %12.2f' % (short(n), g, fm, wm))
         L.append('%-46s %10s %12.2f %12.2f' % ('TOTAL per forward', '', tf, tw))
