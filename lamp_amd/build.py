@@ -22,8 +22,9 @@ LIB = os.path.join(HERE, 'liblamp_hip.so')
 LIB_TUNING = os.path.join(HERE, 'liblamp_hip_tuning.so')
 SOURCES = ['gemm.hip', 'gemm_gen.hip', 'attention.hip', 'attention_small.hip', 'attention_general.hip', 'pointwise.hip',
            'backward.hip', 'chain.hip', 'api.hip']
-TUNING_SOURCES = {'gemm.hip', 'attention.hip', 'attention_small.hip', 'chain.hip'}   # the units that contain LAMP_TUNING code
-HEADERS = [os.path.join(CSRC, 'lamp_kernels.h'), os.path.join(HERE, '..', 'include', 'lamp_hip.h')]
+TUNING_SOURCES = {'gemm.hip', 'attention.hip', 'attention_small.hip', 'chain.hip'}
+TUNING_ONLY = ['slab.hip']   # experiments kept bit-identical and benchmarkable, not part of the product library   # the units that contain LAMP_TUNING code
+HEADERS = [os.path.join(CSRC, 'lamp_kernels.h'), os.path.join(CSRC, 'lamp_asm.h'), os.path.join(HERE, '..', 'include', 'lamp_hip.h')]
 REMARKS = ['-Rpass-analysis=kernel-resource-usage']   # per-kernel VGPR / AGPR / scratch report, saved beside each object
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-fvisibility-inlines-hidden', '-Wno-unused-result']
 
@@ -43,7 +44,7 @@ def _newer(target, deps):
 
 
 def needs_build():
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    deps = [os.path.join(CSRC, s) for s in SOURCES + TUNING_ONLY] + HEADERS
     return _newer(LIB, deps) or _newer(LIB_TUNING, deps) or not all(os.path.exists(resources_path(s)) for s in SOURCES)
 
 
@@ -105,10 +106,16 @@ def build(force=False, verbose=False):
             tobj = os.path.join(OBJ, s.replace('.hip', '.tuning.o'))
             if force or _newer(tobj, deps) or not os.path.exists(resources_path(s, True)):
                 jobs.append(([cc] + FLAGS + REMARKS + ['-DLAMP_TUNING', '-c', src, '-o', tobj], resources_path(s, True)))
+    for s in TUNING_ONLY:
+        src = os.path.join(CSRC, s)
+        tobj = os.path.join(OBJ, s.replace('.hip', '.tuning.o'))
+        if force or _newer(tobj, [src] + HEADERS) or not os.path.exists(resources_path(s, True)):
+            jobs.append(([cc] + FLAGS + REMARKS + ['-DLAMP_TUNING', '-c', src, '-o', tobj], resources_path(s, True)))
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4) or 1) as ex:
         list(ex.map(lambda j: _run(j[0], verbose, j[1]), jobs))
     objs = [os.path.join(OBJ, s.replace('.hip', '.o')) for s in SOURCES]
     tobjs = [os.path.join(OBJ, s.replace('.hip', '.tuning.o' if s in TUNING_SOURCES else '.o')) for s in SOURCES]
+    tobjs += [os.path.join(OBJ, s.replace('.hip', '.tuning.o')) for s in TUNING_ONLY]
     _run([cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs, verbose)
     _run([cc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_TUNING] + tobjs, verbose)
     return LIB

@@ -37,9 +37,7 @@
 //
 // All LDS traffic of this kernel is inline assembly (explicit lgkmcnt waits): the row loads at the start are LDS-DMA, and
 // hipcc orders every ds_read / ds_write it can see behind ALL earlier LDS-DMA with a full vmcnt(0) drain (gemm.hip, DMA = 1).
-#include <type_traits>
-
-#include "lamp_kernels.h"
+#include "lamp_asm.h"
 
 namespace lamp {
 
@@ -47,68 +45,6 @@ namespace {
 constexpr int ROWS = 16;          // rows of a panel = the MFMA block edge
 constexpr int BK = 32;            // k per stage of the W stream: whole 128-byte lines per W row
 
-typedef __attribute__((address_space(3))) void* lds_ptr;
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, float* dst, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, voff, soff, 0, 0);
-}
-__device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-// A 16-byte global load the compiler does not track: issued at the start of a pass, consumed after its k loop -- loads retire
-// in order and every k step waits until at most one W stage is outstanding, so the value has landed long before.  (An
-// ordinary load makes hipcc wait vmcnt(0) at the use, which drains the W stages requested ahead for the NEXT pass.)
-__device__ __forceinline__ f32x4 global_read16_untracked(const float* ptr) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-    return v;
-}
-// The W stream's loads, equally invisible to the compiler: its own wait-count bookkeeping is exact inside straight-line code
-// but gives up at a loop's back edge -- an unrolled group of k steps then starts by draining EVERY stage in flight
-// (s_waitcnt vmcnt(3) .. vmcnt(0) before the first ds_write), i.e. the prefetch depth collapses once per group.  With the
-// loads in inline assembly the only vector-memory waits in the k loop are the counted ones written below.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4 raw_rsrc(const float* base, unsigned bytes) {
-    const uint64_t b = reinterpret_cast<uint64_t>(base);
-    return u32x4{unsigned(__builtin_amdgcn_readfirstlane(unsigned(b))), unsigned(__builtin_amdgcn_readfirstlane(unsigned(b >> 32) & 0xffffu)),
-                 unsigned(__builtin_amdgcn_readfirstlane(bytes)), 0x00020000u};
-}
-__device__ __forceinline__ f32x4 buffer_read16_untracked(u32x4 rs, unsigned voff, unsigned soff) {
-    f32x4 v;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_write16(unsigned addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int N>
-__device__ __forceinline__ void wait_lgkmcnt() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);   // hipcc moves register-only instructions (MFMAs) across an asm wait otherwise
-}
-__device__ __forceinline__ void wg_barrier() {   // LDS writes of this wave done, then the workgroup barrier
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ const float* uniform_ptr(const float* q) {
-    const uint64_t b = reinterpret_cast<uint64_t>(q);
-    const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(b)), hi = __builtin_amdgcn_readfirstlane(unsigned(b >> 32));
-    return reinterpret_cast<const float*>((uint64_t(hi) << 32) | lo);
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_u(const float* base, uint64_t bytes) {
-    const unsigned n = bytes >= 0x7fffffffull ? 0x7fffffffu : unsigned(bytes);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(base)), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
-}
 }  // namespace
 
 // One GEMM step of the chain: dst = act(src . W_s^T + bias_s) (+ what dst held), s < nseg; dst in LDS and / or global memory.
@@ -316,6 +252,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(ChainParam
             // prologue: stages 0 .. DEPTH - 2 requested; A fragments of stage 0
             static_for<0, DEPTH - 1>([&](auto J) {
                 constexpr int j = decltype(J)::value;
+                sgpr_guard(rsW, p_so);
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -328,6 +265,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(ChainParam
         // prologue: DEPTH stages requested, stage 0 through LDS into fragment set 0
         static_for<0, DEPTH>([&](auto J) {
             constexpr int j = decltype(J)::value;
+            sgpr_guard(rsW, p_so);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) part_load(R[j], i);
             part_book();
@@ -335,6 +273,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(ChainParam
         wait_vmcnt<(DEPTH - 1) * NLD>();
 #pragma unroll
         for (int i = 0; i < NLD; ++i) part_write(R[0], 0, i);
+        sgpr_guard(rsW, p_so);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) part_load(R[0], i);
         part_book();
@@ -450,6 +389,28 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(ChainParam
                         });
                     });
                 }
+                // requests past the end of the stream / reads behind the last stage: their registers stay live until they
+                // have landed (keep_alive, lamp_asm.h)
+                if (seg + 1 == g.nseg && pass + 1 == npass) wait_vmcnt<0>();
+                if constexpr (WDIR) {
+                    static_for<0, DEPTH - 1>([&](auto J) {   // the stages in flight behind the last step: sets 0 .. DEPTH - 2
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int jb = 0; jb < NB; ++jb) keep_alive(F[decltype(J)::value][c][jb]);
+                    });
+                } else {
+                    static_for<0, DEPTH>([&](auto J) {
+#pragma unroll
+                        for (int i = 0; i < NLD; ++i) keep_alive(R[decltype(J)::value][i]);
+                    });
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int jb = 0; jb < NB; ++jb) keep_alive(fw[0][c][jb]);
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) keep_alive(fa[0][c]);
                 CHAIN_STAMP(2);
                 // ---- epilogue of the pass: lane (row l15, hi) holds columns col0 + 16 j + 4 hi .. + 3 of its row ----
 #pragma unroll
@@ -615,21 +576,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(ChainParam
 //     start, together with the panel: the epilogues and the LayerNorms read LDS (~100 cycles) instead of waiting for global
 //     loads (~1000 cycles) behind a workgroup barrier.
 // Same fragments, same k order, same epilogue order, same LayerNorm functions: bit-identical to the kernel above.
-// The values of inline-assembly loads become usable at the counted wait that covers them.  The compiler sees them "defined" at
-// the load itself, so two rules keep it from touching the registers early: (1) no control-flow merge between an untracked load
-// and its wait -- a load under `if` makes the merge a register COPY placed right behind the load, before the data has landed
-// (found in round 5: LayerNorm operands read under `if (n.res)` came out stale, never twice the same); loads are unconditional,
-// from a harmless address when the operand is absent, and the CHOICE happens after the wait; (2) settle() right behind the
-// wait: an empty asm that "rewrites" the registers, so that every use is ordered behind it.
-__device__ __forceinline__ void settle(f32x4& a) { asm volatile("" : "+v"(a)); }
-__device__ __forceinline__ void settle(float& a) { asm volatile("" : "+v"(a)); }
-template <int OFF>
-__device__ __forceinline__ f32x4 lds_read16_off(unsigned addr) {
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-
 template <int NV, int WAVES, int WCOLS, int DEPTH>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_packed_kernel(ChainParams p) {
     constexpr int NB = WCOLS / 16, NL = 2 * NB, NMF = 8 * NB, PASS_COLS = WAVES * WCOLS, RPW = ROWS / WAVES;
@@ -745,6 +691,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_packed_kernel(Cha
         // prologue: stages 0 .. DEPTH - 2 requested, A fragments of stage 0
         static_for<0, DEPTH - 1>([&](auto J) {
             constexpr int j = decltype(J)::value;
+            sgpr_guard(rsW, s_off);
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -811,6 +758,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_packed_kernel(Cha
                     });
                 });
             }
+            // requests past the end of the stream / reads behind the last stage: live until landed (keep_alive, lamp_asm.h)
+            if (pass + 1 == npass) wait_vmcnt<0>();
+            static_for<0, DEPTH - 1>([&](auto J) {   // the stages in flight behind the last step: sets 0 .. DEPTH - 2
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int jb = 0; jb < NB; ++jb) keep_alive(F[decltype(J)::value][c][jb]);
+            });
+#pragma unroll
+            for (int c = 0; c < 2; ++c) keep_alive(fa[0][c]);
             CHAIN_STAMP(2);
             // ---- epilogue of the pass: lane (row l15, hi) holds columns col0 + 16 j + 4 hi .. + 3 of its row ----
             f32x4 bv[NB], rv[NB];
@@ -961,25 +918,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_packed_kernel(Cha
 // Weights: format 1 of lamp_pack_weight -- per 64 columns and chunk of 16 k, quad q of every column lane by lane (one KiB
 // per load instruction).  Eight waves x 64 columns = one pass of 512; everything else (LDS-resident operands, one operation
 // per MFMA gap, stream bookkeeping, LayerNorm) as in chain_packed_kernel.
-template <int OFF>
-__device__ __forceinline__ f32x4 buffer_read16_untracked_off(u32x4 rs, unsigned voff, unsigned soff) {
-    f32x4 v;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
-    return v;
-}
-__device__ __forceinline__ float lds_read4(unsigned addr) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-template <int OFF>
-__device__ __forceinline__ float lds_read4_off(unsigned addr) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-__device__ __forceinline__ void lds_write4(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-
 template <int NV, int G>
 __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
     constexpr int WAVES = 8, R = 4 * G, DEPTH = 4, NMF = 16 * G, RPW = (R + WAVES - 1) / WAVES;
@@ -1088,6 +1026,7 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
         // prologue
         static_for<0, DEPTH - 1>([&](auto J) {
             constexpr int j = decltype(J)::value;
+            sgpr_guard(rsW, s_off);
             static_for<0, 4>([&](auto Q) { wload(F[j][decltype(Q)::value], Q); });
             adv_a(); adv_b(); adv_c();
         });
@@ -1137,6 +1076,10 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
                     });
                 });
             }
+            // requests past the end of the stream / reads behind the last chunk: live until landed (keep_alive, lamp_asm.h)
+            if (pass + 1 == npass) wait_vmcnt<0>();
+            static_for<0, DEPTH - 1>([&](auto J) { static_for<0, 4>([&](auto Q) { keep_alive(F[decltype(J)::value][decltype(Q)::value]); }); });
+            static_for<0, G>([&](auto GG) { keep_alive(fa[0][decltype(GG)::value]); });
             CHAIN_STAMP(2);
             // ---- epilogue of the pass: register i of acc[gg] = row 4 gg + i, this lane's column ----
             const unsigned drow = unsigned(buf_w(g.dst)) * 4u;

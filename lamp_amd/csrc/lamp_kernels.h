@@ -70,6 +70,10 @@ struct AttnParams {
 };
 
 int launch_gemm(const GemmParams& p, hipStream_t s);
+// slab.hip (tuning build only: measured slower than the tile kernel, profiles/r05_rejected_experiments.txt): the same product
+// from format-1 weight packs, one slab of rows per CU, bit-identical to launch_gemm
+bool slab_applies(int64_t M, int N, int K, int nseg, const float* const* Wq);
+int launch_slab_gemm(const GemmParams& p, const float* const* Wq, hipStream_t s);
 int launch_attn(const AttnParams& p, hipStream_t s);
 int launch_attn_general(const AttnParams& p, hipStream_t s);  // any d_k / d_v: scores through memory
 bool attn_small_applies(const AttnParams& p, bool any_lq = false);  // attention_small.hip: lq <= 256 or lk <= 64 (shape-only rule)

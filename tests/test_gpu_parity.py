@@ -732,6 +732,41 @@ def test_chain_launches_survive_a_busy_neighbour_stream(dev):
         assert not bad, (b, bad[:10])
 
 
+@pytest.mark.parametrize('M', [3, 1019, 3067, 5115, 9665, 10235])
+def test_slab_gemm_experiment_is_bit_identical(dev, tuning, M):
+    """slab.hip (tuning build only; profiles/r05_rejected_experiments.txt): a GEMM over row slabs on the 4x4x1 MFMA from format-1
+    weight packs -- one to ten row groups per workgroup, bias / ReLU / residual epilogues, two segments sharing A, and a live
+    row count in device memory (ragged batches) -- gives the bits of the tile kernel."""
+    import ctypes
+    from lamp_amd import _native as N
+    fn = tuning.lamp_debug_slab_gemm
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
+                   ctypes.c_void_p, ctypes.c_void_p]
+    K = Nn = 512
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g).to(dev)
+    ws = [(torch.randn(Nn, K, generator=g) / K ** 0.5).to(dev) for _ in range(2)]
+    wq = [N.weight_pack(w, 1) for w in ws]
+    b = torch.randn(Nn, generator=g).to(dev)
+    r = torch.randn(M, Nn, generator=g).to(dev)
+    for nseg, bias, res, relu in ((1, b, None, 1), (1, b, r, 0), (2, None, None, 0)):
+        want = [N.linear(x, w, bias, residual=res, relu=bool(relu)) for w in ws[:nseg]]
+        outs = [torch.full((M, Nn), float('nan'), device=dev) for _ in range(nseg)]
+        for _ in range(2):
+            N.check(fn(x.data_ptr(), M, K, K, wq[0].data_ptr(), wq[1].data_ptr() if nseg > 1 else None, Nn, N.ptr(bias), N.ptr(res), Nn, relu,
+                       outs[0].data_ptr(), outs[1].data_ptr() if nseg > 1 else None, Nn, None, N.stream()), 'slab')
+            assert all(torch.equal(a, w_) for a, w_ in zip(outs, want)), (M, nseg)
+    if M > 100:   # live rows from device memory: the rows past them stay untouched
+        live = M * 3 // 5
+        m_dev = torch.tensor([live, live], dtype=torch.int32, device=dev)
+        out = torch.full((M, Nn), 7.0, device=dev)
+        N.check(fn(x.data_ptr(), M, K, K, wq[0].data_ptr(), None, Nn, N.ptr(b), None, Nn, 1, out.data_ptr(), None, Nn, m_dev.data_ptr(),
+                   N.stream()), 'slab')
+        assert torch.equal(out[:live], N.linear(x[:live], ws[0], b, relu=True)) and bool((out[live:] == 7.0).all())
+
+
 def test_requested_maps_do_not_change_logits(dev):
     """Requested maps come from the same single-pass kernels (scores + row log-sum-exp written on the side): the
     logits do not change by a bit when maps or intermediate predictions are asked for, nor under micro-batching."""

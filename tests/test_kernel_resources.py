@@ -33,8 +33,8 @@ FORWARD_UNITS = ['gemm.hip', 'chain.hip', 'attention.hip', 'attention_small.hip'
 @pytest.mark.parametrize('tuning', [False, True])
 def test_no_kernel_spills_and_the_chain_uses_no_agprs(tuning):
     seen = 0
-    for unit in B.SOURCES:
-        if unit == 'api.hip' or (tuning and unit not in B.TUNING_SOURCES):
+    for unit in B.SOURCES + (B.TUNING_ONLY if tuning else []):
+        if unit == 'api.hip' or (tuning and unit not in B.TUNING_SOURCES and unit not in B.TUNING_ONLY):
             continue
         res = B.kernel_resources(unit, tuning)
         assert res, unit
@@ -44,7 +44,7 @@ def test_no_kernel_spills_and_the_chain_uses_no_agprs(tuning):
             if tuning and 'gemm_pair_kernel' in name:
                 allowed = 80   # the rejected counter-chained FFN pair (profiles/r04_rejected_experiments.txt #11): tuning build only
             assert r.get('scratch', 0) <= allowed, (unit, name, r)
-            if 'chain' in name and 'kernel' in name:
+            if ('chain' in name or 'slab' in name) and 'kernel' in name:
                 # the W stream's registers must stay where the in-flight loads will write them
                 assert r.get('agpr', 0) == 0 and r.get('scratch', 0) == 0, (name, r)
     assert seen > 100
@@ -81,9 +81,30 @@ _ZN4lamp12chain_kernelILi2ELi16ELi32ELi2ELi1EEEvNS_11ChainParamsE:
     assert len(CUL.check(clobber)[2]) == 1
 
 
-@pytest.mark.parametrize('flags', [(), ('-DLAMP_TUNING',)])
-def test_no_instruction_touches_an_inline_assembly_load_before_a_wait(flags):
-    asm = CUL.device_asm(os.path.join(ROOT, 'lamp_amd', 'csrc', 'chain.hip'), flags)
+def test_checker_sees_a_scalar_written_by_the_vector_unit_in_front_of_a_load():
+    """Round 5, slab.hip: the compiler reloaded the stream's scalar offset with v_readlane right in front of an inline-assembly
+    load (no hazard padding for instructions it cannot see): the load went out with the old offset."""
+    bad = '''
+_ZN4lamp16slab_gemm_kernelILi10EEEvNS_10SlabParamsE:
+	v_readlane_b32 s8, v209, 5
+	;;#ASMSTART
+	buffer_load_dwordx4 v[46:49], v85, s[16:19], s8 offen offset:0
+	;;#ASMEND
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+	s_endpgm
+'''
+    assert len(CUL.check(bad)[2]) == 1
+    assert CUL.check(bad.replace('\t;;#ASMSTART\n\tbuffer_load', '\ts_nop 4\n\t;;#ASMSTART\n\tbuffer_load'))[2] == []
+    assert len(CUL.check(bad.replace('v_readlane_b32 s8, v209, 5', 'v_readfirstlane_b32 s18, v86'))[2]) == 1   # a descriptor word
+
+
+@pytest.mark.parametrize('unit,flags,n_kernels', [('chain.hip', (), 12), ('chain.hip', ('-DLAMP_TUNING',), 12), ('slab.hip', ('-DLAMP_TUNING',), 1)])
+def test_no_instruction_touches_an_inline_assembly_load_before_a_wait(unit, flags, n_kernels):
+    """... nor does one overwrite a register in flight, nor does an inline-assembly memory instruction read a scalar the vector
+    unit wrote fewer than five wait states earlier (tools/check_untracked_loads.py: the three rules)."""
+    asm = CUL.device_asm(os.path.join(ROOT, 'lamp_amd', 'csrc', unit), flags)
     kernels, loads, findings = CUL.check(asm)
-    assert kernels >= 12 and loads > 1000
+    assert kernels >= n_kernels and loads > 500
     assert findings == [], findings[:5]

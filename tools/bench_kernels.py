@@ -421,6 +421,49 @@ def chain():
                                                            cyc(g[:, 3] - g[:, 0]), q(g[:, 3] - g[:, 0], 0.5) / ghz / 1e3, ghz))
 
 
+def slab():
+    """The slab kernel (slab.hip: one slab of rows per CU, packed weights, 4x4x1 MFMA) against the tile kernel on the token-row GEMMs:
+    bit identity and round-robin median times.  argv[2:]: row counts."""
+    import statistics
+    lib = N.lib()
+    dev = torch.device('cuda:0')
+    fn = lib.lamp_debug_slab_gemm
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
+                   ctypes.c_void_p, ctypes.c_void_p]
+    rows = [int(a) for a in sys.argv[2:]] or [9665, 9664, 5000, 3200, 1283]
+    for M in rows:
+        for name, Nn, K, nseg, relu, res in (('W1 +b relu', 512, 512, 1, 1, 0), ('W2 +b +R', 512, 512, 1, 0, 1), ('K,V (2 x 1024)', 1024, 512, 2, 0, 0),
+                                             ('ffn 1024', 1024, 512, 1, 1, 0)):
+            g = torch.Generator().manual_seed(M + Nn)
+            x = torch.randn(M, K, generator=g).to(dev)
+            ws = [(torch.randn(Nn, K, generator=g) / K ** 0.5).to(dev) for _ in range(nseg)]
+            wq = [N.weight_pack(w, 1) for w in ws]
+            b = torch.randn(Nn, generator=g).to(dev) if nseg == 1 else None
+            r = torch.randn(M, Nn, generator=g).to(dev) if res else None
+            want = [N.linear(x, w, b, residual=r, relu=bool(relu)) for w in ws]
+            outs = [torch.zeros(M, Nn, device=dev) for _ in range(nseg)]
+
+            def run_slab():
+                N.check(fn(x.data_ptr(), M, K, K, wq[0].data_ptr(), wq[1].data_ptr() if nseg > 1 else None, Nn, N.ptr(b), N.ptr(r), Nn, relu,
+                           outs[0].data_ptr(), outs[1].data_ptr() if nseg > 1 else None, Nn, None, N.stream()), 'slab')
+
+            def run_tile():
+                for w in ws:
+                    N.linear(x, w, b, residual=r, relu=bool(relu))
+            run_slab()
+            torch.cuda.synchronize()
+            same = all(torch.equal(a, w_) for a, w_ in zip(outs, want))
+            ts, tt = [], []
+            for _ in range(7):
+                tt.append(time_fn(run_tile, iters=20, warm=3))
+                ts.append(time_fn(run_slab, iters=20, warm=3))
+            fl = 2.0 * M * Nn * K * nseg
+            ms, mt = statistics.median(ts), statistics.median(tt)
+            print('M=%5d %-16s bitwise %s   tile %7.1f us (%5.1f TF)   slab %7.1f us (%5.1f TF)' % (M, name, same, mt, fl / mt / 1e6, ms, fl / ms / 1e6))
+
+
 def attn_lib_ab(rounds=9):
     """A/B of BUILDS of the library (argv[2:]: paths) on the attention shapes of the forwards, heuristic variant, the
     masks the forward uses (bit-packed label graph for self-attention, none for enc-dec: the padding mask of a full-length
@@ -776,4 +819,4 @@ def ffn_pair():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
     {'gemm': gemm, 'gemm_ab': gemm_ab, 'lib_ab': lib_ab, 'walk': walk, 'walk_pmc': walk_pmc, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
-     'gemm_trace': gemm_trace, 'gemm_clock': gemm_clock, 'attn_lib_ab': attn_lib_ab, 'chain': chain, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency, 'ffn_pair': ffn_pair}[which]()
+     'gemm_trace': gemm_trace, 'gemm_clock': gemm_clock, 'attn_lib_ab': attn_lib_ab, 'chain': chain, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency, 'ffn_pair': ffn_pair, 'slab': slab}[which]()

@@ -41,12 +41,37 @@ def device_asm(path, extra=()):
         return open(f.name).read()
 
 
-def check(asm, wanted=('chain',)):
-    """-> (kernels checked, loads checked, findings: [(kernel, load line no, load, reader line no, reader)])"""
+WAIT = re.compile(r'(vmcnt|lgkmcnt)\((\d+)\)')
+SREG = re.compile(r's\[(\d+):(\d+)\]|\bs(\d+)\b')
+VALU_SGPR_WAIT_STATES = 5   # VALU writes an SGPR (v_readlane, v_readfirstlane, carry / compare results) -> VMEM reads it
+
+
+def sregs_of(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def check(asm, wanted=('chain', 'slab')):
+    """-> (kernels checked, loads checked, findings: [(kernel, load line no, load, reader line no, reader)]).
+
+    Two in-order queues of inline-assembly loads, followed along the FALL-THROUGH path (reset at unconditional branches): vector memory (buffer / global loads) and LDS reads.  A wait
+    `vmcnt(N)` / `lgkmcnt(N)` retires all but the N youngest of its queue (loads of a kind return in order; other operations the
+    compiler issued only make the hardware count higher, i.e. retire less than assumed here -- the model errs towards missing a
+    finding, never towards inventing one).  Until retired, a load's destination registers may be neither read nor written."""
     findings, n_loads, kernels = [], 0, 0
     lines = asm.split('\n')
     kernel, in_asm = None, False
-    pending = []   # (dest regs, line no, text) of loads no wait has followed yet
+    pend = {'vm': [], 'lgkm': []}   # [(dest regs, line no, text)]
+    fresh = {}                      # SGPR -> (wait states since a VALU instruction wrote it, line no, text)
+
+    def all_pending():
+        return pend['vm'] + pend['lgkm']
+
     for no, line in enumerate(lines, 1):
         t = line.strip()
         m = re.match(r'^(_Z\w+):', line)
@@ -54,7 +79,7 @@ def check(asm, wanted=('chain',)):
             name = subprocess.run(['c++filt', m.group(1)], capture_output=True, text=True).stdout.strip()
             kernel = name if any(w in name for w in wanted) and 'kernel' in name else None
             kernels += kernel is not None
-            pending = []
+            pend = {'vm': [], 'lgkm': []}
             continue
         if kernel is None or not t or t.startswith(';') and 'ASM' not in t:
             continue
@@ -64,55 +89,78 @@ def check(asm, wanted=('chain',)):
         if t.startswith(';;#ASMEND'):
             in_asm = False
             continue
-        if t.startswith('.') or t.endswith(':'):          # label: a new basic block (the scan is per block)
-            pending = []
+        if t.startswith('.') or t.endswith(':'):          # label: reached by fall-through with the loads of this path still in flight
             continue
+        # ---- rule 4: scalar registers written by the vector unit, and the inline-assembly memory instructions that read them
+        op0 = t.split(None, 1)
+        if in_asm and op0[0].startswith(('buffer_', 'global_', 'ds_', 'scratch_')) and len(op0) > 1:
+            for r in sregs_of(op0[1].split(';')[0]):
+                if r in fresh and fresh[r][0] < VALU_SGPR_WAIT_STATES:
+                    findings.append((kernel, fresh[r][1], fresh[r][2], no, t + '   ; reads s%d %d wait state(s) after the vector unit wrote it' % (r, fresh[r][0])))
+        step = 1
+        mnop = re.match(r's_nop\s+(\d+)', t)
+        if mnop:
+            step = int(mnop.group(1)) + 1
+        fresh = {r: (a + step, l, x) for r, (a, l, x) in fresh.items() if a + step < 16}
+        if op0[0].startswith('v_') and len(op0) > 1:
+            first = op0[1].split(',')[0].strip()
+            if first.startswith('s') and not first.startswith('src'):
+                for r in sregs_of(first):
+                    fresh[r] = (0, no, t)
         if t.startswith('s_endpgm'):
             kernel = None
             continue
         if t.startswith('s_waitcnt'):
-            pending = []
+            for which, n in WAIT.findall(t):
+                q = 'vm' if which == 'vmcnt' else 'lgkm'
+                n = int(n)
+                pend[q] = pend[q][len(pend[q]) - n:] if n else []
             continue
-        if t.startswith(('s_cbranch', 's_branch', 's_barrier')):
-            if t.startswith('s_barrier'):
-                continue
-            pending = []
+        if t.startswith('s_cbranch'):                     # the fall-through path goes on with the same loads in flight
+            continue
+        if t.startswith(('s_branch', 's_setpc', 's_swappc')):   # what follows is reached from elsewhere: unknown state
+            pend = {'vm': [], 'lgkm': []}
             continue
         m = LOAD.match(t)
-        if m:
+        if m and not t.split()[-1] == 'lds':
             dest, rest = regs_of(m.group(2)), m.group(3)
-            for regs, lno, ltxt in pending:          # the address operands of this load are sources too
+            for regs, lno, ltxt in all_pending():          # the address operands of this load are sources too
                 if regs & regs_of(rest.split(';')[0]):
                     findings.append((kernel, lno, ltxt, no, t))
-            # a later load that re-targets the same registers simply replaces the entry (write after write)
-            pending = [(r, l, x) for r, l, x in pending if not (r & dest)]
+            q = 'lgkm' if t.startswith('ds_') else 'vm'
+            # a later load of the same kind that re-targets the registers replaces the entry (in-order return: the later one wins);
+            # one of the OTHER kind racing an in-flight load is a finding
+            other = 'vm' if q == 'lgkm' else 'lgkm'
+            for regs, lno, ltxt in pend[other]:
+                if regs & dest:
+                    findings.append((kernel, lno, ltxt, no, t + '   ; WRITES a register in flight'))
+            pend[q] = [(r, l, x) for r, l, x in pend[q] if not (r & dest)]
             if in_asm:
-                pending.append((dest, no, t))
+                pend[q].append((dest, no, t))
                 n_loads += 1
             continue
-        if not pending:
+        if not all_pending():
             continue
         ops = t.split(None, 1)
-        if len(ops) < 2:
+        if len(ops) < 2 or ops[0].startswith('s_'):
             continue
         operands = ops[1].split(';')[0]
         parts = [p.strip() for p in operands.split(',')]
-        # first operand is the destination for VALU / MFMA / DS-read style instructions; stores have sources only
-        is_store = ops[0].startswith(('ds_write', 'buffer_store', 'global_store', 'scratch_store'))
+        is_store = ops[0].startswith(('ds_write', 'buffer_store', 'global_store', 'scratch_store', 'buffer_load'))
         srcs = regs_of(','.join(parts if is_store else parts[1:]))
         dsts = set() if is_store else regs_of(parts[0])
-        for regs, lno, ltxt in pending:
+        for regs, lno, ltxt in all_pending():
             if regs & srcs:
                 findings.append((kernel, lno, ltxt, no, t))
-            elif regs & dsts and not ops[0].startswith('v_mfma'):
-                # overwriting a register whose load is still in flight (the landing data would clobber the new value)
+            elif regs & dsts:
+                # overwriting a register whose load is still in flight: the landing data would clobber the new value
                 findings.append((kernel, lno, ltxt, no, t + '   ; WRITES a register in flight'))
     return kernels, n_loads, findings
 
 
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else 'lamp_amd/csrc/chain.hip'
-    wanted = tuple(sys.argv[2:]) or ('chain',)
+    wanted = tuple(sys.argv[2:]) or ('chain', 'slab')
     kernels, n_loads, findings = check(device_asm(path), wanted)
     print('%d kernels, %d inline-assembly loads checked, %d findings' % (kernels, n_loads, len(findings)))
     for k, lno, ltxt, no, t in findings[:40]:
