@@ -109,7 +109,7 @@ def live_kernel_trace(args):
     cmd = [exe, '--kernel-trace', '--stats', '-d', out, '-o', 'p', '-f', 'csv', '--', sys.executable,
            os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--batch', str(args.batch),
            '--steps', str(KERNEL_TRACE_STEPS), '--warmup', '10', '--no-cpu-baseline', '--no-extra-workloads', '--no-pipelined',
-           '--no-kernel-trace']
+           '--no-kernel-trace', '--no-pmc']
     env = dict(os.environ, TMPDIR='/tmp', LAMP_BENCH_INNER='1')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'LAMP_BENCH_SPAWNED'):
         env.pop(k, None)
@@ -149,6 +149,86 @@ def live_kernel_trace(args):
         'all_kernels_us_per_forward': sum(float(r['TotalDurationNs']) for r in lamp) / fwd / 1e3,
         'by_kernel': by_kernel,
     }
+
+PMC_PASSES = (('FETCH_SIZE',), ('WRITE_SIZE',), ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES'))
+PMC_TIMEOUT_S = 120
+
+
+def live_pmc(args):
+    """Hardware counters measured IN THIS INVOCATION (N = 1): three short `rocprofv3 --kernel-trace --pmc ...` passes around this
+    same script -- FETCH_SIZE, WRITE_SIZE (the L2s' memory-side traffic; separate passes, FETCH_SIZE doubled per the gfx950
+    calibration of MI355X_MICROARCH.md) and the matrix-pipe busy cycles -- read back per dispatch and averaged per launch of each
+    kernel.  Counters are never combined with any trace domain but the kernel trace.  -> dict {'by_kernel': {name: {launches,
+    avg_us, fetch_bytes, write_bytes, hbm_gbs, mfma_busy}}, ...} or {'skipped': reason}."""
+    import collections
+    import csv
+    import shutil
+    import tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return {'skipped': 'rocprofv3 not found'}
+    if under_profiler():
+        return {'skipped': 'this process already runs under the profiler'}
+    env = dict(os.environ, TMPDIR='/tmp', LAMP_BENCH_INNER='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'LAMP_BENCH_SPAWNED'):
+        env.pop(k, None)
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))   # kernel -> counter / 'us' -> per-dispatch values
+    t0 = time.perf_counter()
+    for counters in PMC_PASSES:
+        try:
+            out = tempfile.mkdtemp(prefix='lamp_bench_pmc_', dir='/tmp' if os.path.isdir('/tmp') else None)
+        except OSError as e:
+            return {'skipped': 'no scratch directory for the profiler output: %s' % e}
+        cmd = [exe, '--kernel-trace', '--pmc'] + list(counters) + ['-d', out, '-o', 'p', '-f', 'csv', '--', sys.executable,
+               os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--batch', str(args.batch), '--steps', '4', '--warmup', '2',
+               '--no-cpu-baseline', '--no-extra-workloads', '--no-pipelined', '--no-kernel-trace', '--no-pmc']
+        try:
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=PMC_TIMEOUT_S)
+            cc, kt = os.path.join(out, 'p_counter_collection.csv'), os.path.join(out, 'p_kernel_trace.csv')
+            if r.returncode != 0 or not os.path.exists(cc) or not os.path.exists(kt):
+                return {'skipped': 'rocprofv3 --pmc %s sub-run failed (exit %d)' % (' '.join(counters), r.returncode)}
+            with open(kt) as f:
+                dur = {row['Dispatch_Id']: (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1000.0 for row in csv.DictReader(f)}
+            seen = set()
+            with open(cc) as f:
+                for row in csv.DictReader(f):
+                    name = row['Kernel_Name']
+                    if 'lamp::' not in name:
+                        continue
+                    short = name.split('(')[0].replace('void lamp::', '').replace('lamp::', '')
+                    acc[short][row['Counter_Name']].append(float(row['Counter_Value']))
+                    if counters[0] == 'FETCH_SIZE' and row['Dispatch_Id'] not in seen:
+                        seen.add(row['Dispatch_Id'])
+                        acc[short]['us'].append(dur.get(row['Dispatch_Id'], 0.0))
+                    if counters[0].startswith('SQ_') and row['Counter_Name'] == 'SQ_BUSY_CYCLES':
+                        acc[short]['us_sq'].append(dur.get(row['Dispatch_Id'], 0.0))
+        except subprocess.TimeoutExpired:
+            return {'skipped': 'rocprofv3 --pmc sub-run exceeded %d s' % PMC_TIMEOUT_S}
+        except (OSError, ValueError, KeyError) as e:
+            return {'skipped': 'rocprofv3 --pmc sub-run: %s' % e}
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    mean = lambda v: sum(v) / len(v) if v else None   # noqa: E731
+    by_kernel = {}
+    for k, c in acc.items():
+        if 'pack_weight' in k or not c.get('us'):
+            continue
+        us = mean(c['us'])
+        fetch = mean(c.get('FETCH_SIZE', [])) or 0.0
+        write = mean(c.get('WRITE_SIZE', [])) or 0.0
+        e = {'launches': len(c['us']), 'avg_us': us, 'fetch_bytes': fetch * 1024 * 2, 'write_bytes': write * 1024}
+        e['hbm_gbs'] = (e['fetch_bytes'] + e['write_bytes']) / (us * 1e-6) / 1e9 if us else None
+        busy, mf, us_sq = mean(c.get('SQ_BUSY_CYCLES', [])), mean(c.get('SQ_VALU_MFMA_BUSY_CYCLES', [])), mean(c.get('us_sq', []))
+        if busy and us_sq:
+            clk_ghz = busy / 32 / us_sq / 1000          # SQ_BUSY_CYCLES sums the 32 shader engines
+            e['clock_ghz_under_profiler'] = clk_ghz
+            e['mfma_busy'] = (mf or 0.0) / (1024 * us_sq * 1000 * clk_ghz)   # of the 1024 SIMDs' cycles
+        by_kernel[k] = e
+    return {'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES> -- python bench.py '
+                       '--workload %s --batch %d --steps 4 ... (three passes of this invocation, %.0f s)' %
+                       (args.workload, args.batch, time.perf_counter() - t0),
+            'units': 'bytes per launch (FETCH_SIZE x 1 KiB x 2: gfx950 calibration; WRITE_SIZE x 1 KiB), HBM-side incl. Infinity-Cache hits',
+            'by_kernel': by_kernel}
 
 
 def f_live(w, n_enc=2, n_dec=2):
@@ -291,7 +371,7 @@ def profile_steps(N, step, n_steps):
     return prof, kernels
 
 
-def roofline_of(prof, n_steps, workload, live=None, chain_gflop=None):
+def roofline_of(prof, n_steps, workload, live=None, chain_gflop=None, pmc=None, attn_prof=None):
     gemm = prof['gemm']
     tf = gemm['flops'] / (gemm['ms'] * 1e-3) / 1e12 if gemm['ms'] > 0 else 0.0
     tr = load_traffic(workload)
@@ -342,7 +422,41 @@ def roofline_of(prof, n_steps, workload, live=None, chain_gflop=None):
             out['kernel_only_stale'] = True
     if live and live.get('skipped'):
         out['kernel_trace_skipped'] = live['skipped']
-    if tr and tr.get('gemm_launches'):
+    if pmc and pmc.get('by_kernel'):
+        # measured in this invocation: GEMM-class launches weighted by their launch counts
+        g = [e for k, e in pmc['by_kernel'].items() if 'gemm_nt_kernel' in k or is_chain_kernel(k)]
+        n = sum(e['launches'] for e in g)
+        if n:
+            fetch = sum(e['fetch_bytes'] * e['launches'] for e in g) / n
+            write = sum(e['write_bytes'] * e['launches'] for e in g) / n
+            out['traffic'] = fetch + write
+            out['traffic_source'] = 'live'
+            out['traffic_stale'] = False
+            out['traffic_detail'] = {'unit': 'bytes per GEMM-class launch (HBM-side: L2 fabric requests incl. Infinity-Cache hits)',
+                                     'fetch': fetch, 'write': write, 'launches_measured': n, 'measured': pmc['command']}
+        # the masked-softmax attention kernels: HBM-side GB/s against the 8 TB/s peak and the matrix pipes' busy fraction, as
+        # BASELINE.json's north_star words it ("evidenced by rocprof HBM-GB/s and MFMA-busy")
+        a = {k: e for k, e in pmc['by_kernel'].items() if 'attn' in k}
+        n = sum(e['launches'] for e in a.values())
+        if n:
+            us = sum(e['avg_us'] * e['launches'] for e in a.values()) / n
+            by = sum((e['fetch_bytes'] + e['write_bytes']) * e['launches'] for e in a.values()) / n
+            busy = [e['mfma_busy'] * e['launches'] for e in a.values() if e.get('mfma_busy') is not None]
+            out['attention'] = {
+                'kernel': 'attn16_kernel / attn_kernel (masked softmax attention: scores never leave the CU)',
+                'bound': 'mfma', 'hbm_gbs': by / (us * 1e-6) / 1e9, 'hbm_peak_gbs': PEAK_HBM_GBS, 'hbm_frac': by / (us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                'traffic_bytes_per_launch': by, 'avg_launch_us_under_profiler': us, 'mfma_busy': sum(busy) / n if busy else None,
+                'algorithmic_gbs': attn_prof.get('algorithmic_gbs') if attn_prof else None,
+                'achieved_tflops': attn_prof.get('tflops') if attn_prof else None,
+                'frac_of_fp32_mfma_peak': attn_prof['tflops'] / PEAK_FP32_MFMA_TFLOPS if attn_prof and attn_prof.get('tflops') else None,
+                'by_kernel': {k: {'avg_us': e['avg_us'], 'hbm_gbs': e['hbm_gbs'], 'mfma_busy': e.get('mfma_busy')} for k, e in a.items()},
+                'source': 'live: ' + pmc['command']}
+    if pmc and pmc.get('skipped'):
+        out['pmc_skipped'] = pmc['skipped']
+    if out.get('traffic_source') == 'live':
+        pass
+    elif tr and tr.get('gemm_launches'):
+        out['traffic_source'] = 'committed'
         out['traffic'] = (tr['gemm_fetch_bytes'] + tr['gemm_write_bytes']) / tr['gemm_launches']
         out['traffic_stale'] = not fresh
         out['traffic_detail'] = {
@@ -477,6 +591,8 @@ def main():
                     help='sequence lengths U{lo..hi} padded to the batch maximum (SURVEY.md 8d variant ii) instead of fixed T')
     ap.add_argument('--no-kernel-trace', action='store_true',
                     help='skip the rocprofv3 --kernel-trace --stats sub-run behind roofline.frac_kernel_only (N = 1)')
+    ap.add_argument('--no-pmc', action='store_true',
+                    help='skip the three rocprofv3 --pmc sub-runs behind roofline.traffic / roofline.attention (N = 1)')
     ap.add_argument('--no-chain-packs', action='store_true',
                     help='A/B switch: run the decoder chain launch from the native weight layouts (no weights-only repack)')
     ap.add_argument('--mask', default=None, choices=['prior', 'none', 'inveye'], help='override the workload label mask')
@@ -497,6 +613,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X: no HIP device is visible (there is no CPU path)')
     dev_index = local_rank % torch.cuda.device_count()  # > 1 rank per GPU only happens in the 1-GPU smoke test
     torch.cuda.set_device(dev_index)
+    affinity = None
+    if world > 1:
+        from lamp_amd.sharding import pin_rank_to_device_cpus
+        affinity = pin_rank_to_device_cpus(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     device = torch.device('cuda', dev_index)
     # "nccl" is RCCL on ROCm.  LAMP_BENCH_BACKEND=gloo lets two ranks share one GPU to smoke-test this path.
     from lamp_amd.sharding import ControlPlane
@@ -519,11 +639,23 @@ def main():
                 graph=args.graph, n_max=n_max)
     model, step, run, my_elapsed = m['model'], m['step'], m['run'], m['elapsed']
 
+    # host issue time per forward: how long the Python / ctypes side takes to ENQUEUE one forward (all its launches) while the
+    # device still has work queued -- what eight issue loops on one host compete with (outside the timed region)
+    torch.cuda.synchronize()
+    n_issue = min(args.steps, 50)
+    t_i = time.perf_counter()
+    for _ in range(n_issue):
+        run()
+    host_issue_us = (time.perf_counter() - t_i) / n_issue * 1e6
+    torch.cuda.synchronize()
+    cp.barrier()
+
     # every rank reports (rank, device, elapsed, samples, tokens); rank 0 aggregates: total samples / max elapsed
     n_tok = float(sum(lengths)) if lengths else float(args.batch * w['T'])
     rows = [r.tolist() for r in cp.gather(torch.tensor(
-        [float(rank), float(dev_index), my_elapsed, float(args.batch * args.steps), n_tok, float(w['T'])],
+        [float(rank), float(dev_index), my_elapsed, float(args.batch * args.steps), n_tok, float(w['T']), host_issue_us],
         dtype=torch.float64))]
+    affinities = cp.gather_objects(affinity)
     ident_rows = cp.gather_objects(device_identity(dev_index))
     identities = [i for i, _ in ident_rows]
     identity_strong = all(st for _, st in ident_rows)
@@ -617,7 +749,10 @@ def main():
     n_chains = sum(2 if hasattr(l, 'slf_attn') else 1 for l in dec)
     hdv = dec[0].enc_attn.n_head * dec[0].enc_attn.d_v
     chain_gflop = n_chains * (2.0 * rows_dec * hdv * w['d'] + 4.0 * rows_dec * w['d'] * w['dff']) / 1e9
-    roof = roofline_of(prof, prof_steps, args.workload if plain else None, live, chain_gflop)
+    pmc = None
+    if n_gpus == 1 and world == 1 and plain and not args.graph and not args.no_pmc and args.batch <= 64:
+        pmc = live_pmc(args)
+    roof = roofline_of(prof, prof_steps, args.workload if plain else None, live, chain_gflop, pmc, kernels.get('attention'))
     if args.ragged and prof['gemm']['ms'] > 0:
         # the launchers count the padded upper bound of the packed encoder's rows: use the real token count
         gf = gemm_flops_per_step(w, args.batch, n_tok)
@@ -635,7 +770,10 @@ def main():
         'ranks_seen': ranks_seen,
         'per_rank': [{'rank': int(r[0]), 'device': int(r[1]), 'device_identity': identities[int(r[0])],
                       'value': r[3] / r[2], 'ms_per_step': r[2] / args.steps * 1e3, 'tokens_per_batch': int(r[4]),
-                      'padded_length': int(r[5])} for r in sorted(rows)],
+                      'padded_length': int(r[5]), 'host_issue_us_per_forward': r[6],
+                      'host_issue_frac_of_step': r[6] / (r[2] / args.steps * 1e6),
+                      'cpu_affinity': affinities[int(r[0])]} for r in sorted(rows)],
+        'host_issue_us_per_forward': max(r[6] for r in rows),
         'physical_devices': physical, 'physical_devices_from': 'pci/uuid' if identity_strong else 'host/visibility/index (weak)',
         'backend': cp.backend, 'control_plane_ranks': cp.ranks_in_group(),
         'cross_rank_check': cross,
@@ -664,6 +802,7 @@ def main():
         },
         'kernels': kernels,
         'kernel_trace': live,
+        'pmc': pmc,
         'pipelined_batches_in_flight': pipelined,
     }
 

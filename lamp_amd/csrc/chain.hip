@@ -946,7 +946,7 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
         const int rl = buf_w(which);
         for (int k = first(); k < n; k += WAVES) {
             const int r = k / ppr, part = k - r * ppr;
-            const unsigned voff = unsigned(r) * unsigned(ld) * 4u + unsigned(part * 64 + (lane ^ r)) * 16u;
+            const unsigned voff = unsigned(r) * unsigned(ld) * 4u + unsigned(part * 64 + (lane ^ (r & 15))) * 16u;
             lds_dma16(rs, dst + r * rl + part * 256, r < rows_m ? voff : OOB, 0);
         }
         pc += n;
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
         float fa[2][G];
         // A operand of chunk ch, row group g: ONE register -- lane (block b = l >> 2, i = l & 3) holds X[4 g + i][16 ch + b], and the
         // MFMA for k = 16 ch + b broadcasts block b to all sixteen blocks (cbsz = 4, abid = b).  Element (row r = 4 g + i, k) sits
-        // in quad 4 ch + (b >> 2) of its row, slot quad ^ r = 16 (ch >> 2) + 4 ((ch & 3) ^ g) + ((b >> 2) ^ i): one address
+        // in quad 4 ch + (b >> 2) of its row, slot quad ^ (r & 15) = 16 (ch >> 2) + 4 ((ch & 3) ^ (g & 3)) + ((b >> 2) ^ i): one address
         // register per row group + the immediate 64 ((ch & 3) ^ g); the registers move on by 256 bytes per group of four chunks.
         // A b32 read: the four rows of a block group land in four different 16-byte slots of one 64-byte window: conflict-free.
         unsigned a_cur[G];
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
         for (int gg = 0; gg < G; ++gg) a_cur[gg] = a_lane(gg);
         auto aread = [&](auto SET, auto GG, auto J) {
             constexpr int set = decltype(SET)::value, gg = decltype(GG)::value, j = decltype(J)::value;
-            fa[set][gg] = lds_read4_off<64 * (j ^ gg)>(a_cur[gg]);
+            fa[set][gg] = lds_read4_off<64 * (j ^ (gg & 3))>(a_cur[gg]);
         };
         // prologue
         static_for<0, DEPTH - 1>([&](auto J) {
@@ -1057,18 +1057,18 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
 #if !(defined(CHAIN_ABL) && (CHAIN_ABL & 16))
                             wload(F[jl][i / 2], std::integral_constant<int, i / 2>{});
 #endif
-                        } else if constexpr (i < 2 * G && i % 2 == 1) {
+                        } else if constexpr (i < 2 * G && i % 2 == 1 && i != NMF - 1) {
 #if !(defined(CHAIN_ABL) && (CHAIN_ABL & 8))
                             aread(std::integral_constant<int, setn>{}, std::integral_constant<int, i / 2>{}, std::integral_constant<int, jn>{});
 #endif
-                        } else if constexpr (i == 9) {
+                        } else if constexpr (i == 8) {
                             adv_a();
-                        } else if constexpr (i == 11) {
+                        } else if constexpr (i == 10) {
                             adv_b();
-                        } else if constexpr (i == 13) {
+                        } else if constexpr (i == 12) {
                             adv_c();
-                        } else if constexpr (i >= 10 && i % 2 == 0 && (i - 10) / 2 < G && j == DEPTH - 2) {
-                            a_cur[(i - 10) / 2] = a_lane((i - 10) / 2) + q_next;
+                        } else if constexpr (i >= 14 && i % 2 == 0 && (i - 14) / 2 < G && j == DEPTH - 2) {
+                            a_cur[(i - 14) / 2] = a_lane((i - 14) / 2) + q_next;
                         } else if constexpr (i == NMF - 1) {
                             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((DEPTH - 2) * 4) : "memory");
                         }
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * gg + i;
-                    at[gg][i] = buf_b(g.dst) + unsigned(r) * drow + unsigned(((col >> 2) ^ r) << 4) + unsigned(col & 3) * 4u;
+                    at[gg][i] = buf_b(g.dst) + unsigned(r) * drow + unsigned(((col >> 2) ^ (r & 15)) << 4) + unsigned(col & 3) * 4u;
                     rv[gg][i] = lds_read4(at[gg][i]);   // unconditional (see settle()); used only with add_dst
                 }
             float bias_v = lds_read4(bias_at >= 0 ? lds0 + unsigned(bias_at + col) * 4u : at[0][0]);
@@ -1134,7 +1134,7 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
                 f32x4 raw[NV], gg[NV], bb[NV], rr[NV], ww[NV];
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
-                    const unsigned self = row_b + unsigned((cq[i] ^ r) << 4);
+                    const unsigned self = row_b + unsigned((cq[i] ^ (r & 15)) << 4);
                     raw[i] = lds_read16(self);
                     gg[i] = lds_read16(lds0 + unsigned(g_at) * 4u + unsigned(cq[i]) * 16u);
                     bb[i] = lds_read16(lds0 + unsigned(be_at) * 4u + unsigned(cq[i]) * 16u);
@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
                     if (lane + i * 64 < nv) {
                         const float4 o = ln_row_apply(v[i], mean, rstd, make_float4(gg[i].x, gg[i].y, gg[i].z, gg[i].w),
                                                       make_float4(bb[i].x, bb[i].y, bb[i].z, bb[i].w));
-                        lds_write16(row_b + unsigned((cq[i] ^ r) << 4), f32x4{o.x, o.y, o.z, o.w});
+                        lds_write16(row_b + unsigned((cq[i] ^ (r & 15)) << 4), f32x4{o.x, o.y, o.z, o.w});
                         if (yr) yr[cq[i]] = o;
                         if (n.w_out) dot += dot4_nocontract(o, make_float4(ww[i].x, ww[i].y, ww[i].z, ww[i].w));
                     }
@@ -1236,7 +1236,7 @@ extern "C" __attribute__((visibility("default"))) void lamp_debug_chain_geometry
 #ifndef LAMP_CHAIN_PACKED_GEOM
 #define LAMP_CHAIN_PACKED_GEOM 12   // the geometry a caller-provided weight pack selects in the product build
 #endif
-static bool chain_geom_packed(int idx) { return idx >= 7 && idx <= 17; }   // 15-17: chain_rows4_kernel with 1-3 row groups (format-1 packs)
+static bool chain_geom_packed(int idx) { return idx >= 7 && idx <= 20; }   // 15-20: chain_rows4_kernel with 1-6 row groups (format-1 packs)
 static bool chain_geom_lds_operands(int idx) { return idx >= 11 && idx <= 14; }   // chain_packed_kernel: LayerNorm / bias operands in LDS
 #if LAMP_CHAIN_PACKED_GEOM == 11
 #define LAMP_CHAIN_PACKED_CASE(X) X(11, 16, 32, 2, 4)
@@ -1275,11 +1275,18 @@ static int chain_geom_index(bool have_pack = false) {
 static int rows4_groups(int64_t M, int d, int k_h, int dff, bool has_ffn, const lamp_chain_pack* pk, bool res_mod, bool w_out) {
     if (!pk || !pk->fc4 || (has_ffn && (!pk->w14 || !pk->w24))) return 0;
     int G = int((M + 4 * 256 - 1) / (4 * 256));
+    bool forced = false;
 #ifdef LAMP_TUNING
-    if (g_chain_geom >= 15 && g_chain_geom <= 17) G = g_chain_geom - 14;
-    else if (g_chain_geom >= 0) return 0;
+    if (g_chain_geom >= 15 && g_chain_geom <= 20) {
+        G = g_chain_geom - 14;
+        forced = true;
+    } else if (g_chain_geom >= 0) {
+        return 0;
+    }
 #endif
-    if (G < 1 || G > 3 || M > int64_t(4 * G) * 65535 || d % 512 || k_h % 64 || (has_ffn && dff % 512)) return 0;
+    // one to three row groups up to 3072 rows; 3073-4096 rows belong to the sixteen-row panels of chain_packed_kernel (same
+    // MFMA count, the 16x16x4 instruction at a higher clock); five and six row groups carry the chain to 6144 rows
+    if (G < 1 || G > 6 || (G == 4 && !forced) || M > int64_t(4 * G) * 65535 || d % 512 || k_h % 64 || (has_ffn && dff % 512)) return 0;
     const int hw = has_ffn ? (k_h > dff ? k_h : dff) : k_h;
     const size_t lds4 = (size_t(4 * G) * size_t(d + hw) + size_t(5) * d + size_t(has_ffn ? dff : 0) + (res_mod ? size_t(4 * G) * d : 0) +
                          (w_out ? size_t(4 * G) * d : 0)) * 4;
@@ -1307,8 +1314,8 @@ bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn, const lamp_
     // at 720 rows (five launches: 36), 34 at 1440 (49), 38 at 2048 (50), 46 at 2400 (63), 50 at 2880-3072 (64-65) -- and sixteen-row
     // panels up to 4096 rows (54-56 us against 77-82).  Below ~500 rows the five launches sit at their latency floor (~30 us).
     if (pk && pk->fc && (!has_ffn || (pk->w1 && pk->w2))) {
-        const int G = M <= 3072 ? rows4_groups(M, d, k_h, dff, has_ffn, pk, true, true) : 0;
-        return G > 0 ? M >= 512 : panels > 128 && panels <= 256;
+        if (rows4_groups(M, d, k_h, dff, has_ffn, pk, true, false) > 0) return M >= 512;   // (residual rows and read-out rows never meet in one chain of a 2+ layer decoder)
+        return panels > 128 && panels <= 256;
     }
     // From the native layouts (round 4; profiles/r04_chain.txt): the chain takes 57-58 us whatever the row count (62 at one
     // panel per CU); the five launches take 37 us at 720 rows, 52 at 1920-2048, then -- the 32 x 64 tiles of a 512-column GEMM
@@ -1388,18 +1395,24 @@ int launch_chain(const float* A, int64_t lda, int k_h, const float* res, int64_t
                 case 11: kern = chain_rows4_kernel<1, 1>; break;
                 case 12: kern = chain_rows4_kernel<1, 2>; break;
                 case 13: kern = chain_rows4_kernel<1, 3>; break;
+                case 14: kern = chain_rows4_kernel<1, 4>; break;
+                case 15: kern = chain_rows4_kernel<1, 5>; break;
+                case 16: kern = chain_rows4_kernel<1, 6>; break;
                 case 21: kern = chain_rows4_kernel<2, 1>; break;
                 case 22: kern = chain_rows4_kernel<2, 2>; break;
                 case 23: kern = chain_rows4_kernel<2, 3>; break;
+                case 24: kern = chain_rows4_kernel<2, 4>; break;
+                case 25: kern = chain_rows4_kernel<2, 5>; break;
+                case 26: kern = chain_rows4_kernel<2, 6>; break;
                 default: return LAMP_E_UNSUPPORTED;
             }
-            static AttrOnce once[6];
-            if (int e = once[(nv - 1) * 3 + G - 1].set(reinterpret_cast<const void*>(kern), 160 * 1024)) return e;
+            static AttrOnce once[12];
+            if (int e = once[(nv - 1) * 6 + G - 1].set(reinterpret_cast<const void*>(kern), 160 * 1024)) return e;
             hipLaunchKernelGGL(kern, dim3(grid4), dim3(512), lds4, s, p);
             return int(hipGetLastError());
         }
 #ifdef LAMP_TUNING
-        if (g_chain_geom >= 15) return LAMP_E_UNSUPPORTED;
+        if (g_chain_geom >= 15) return LAMP_E_UNSUPPORTED;   // a forced 4x4x1 geometry that does not fit this call
 #endif
     }
     int gidx = chain_geom_index(have_pack);

@@ -109,7 +109,7 @@ def spawn_ranks(n, argv):
         port = s.getsockname()[1]
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, '-m', 'lamp_amd.run_eval'] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -143,6 +143,8 @@ def main(argv=None):
     dev_index = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count() if world > 1 else torch.cuda.current_device()
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
+    if world > 1:   # this rank's issue loop and host threads on the cores next to its device (sharding.pin_rank_to_device_cpus)
+        sharding.pin_rank_to_device_cpus(int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     # gloo rendezvous + an RCCL group for the final gather when RCCL comes up (probed; falls back to gloo and says so);
     # LAMP_EVAL_BACKEND=gloo lets several ranks share one GPU (tests)
     plane = sharding.ControlPlane(rank, world, device, os.environ.get('LAMP_EVAL_BACKEND', 'nccl'))

@@ -54,6 +54,70 @@ def sharded_forward(forward_fn, src_seq, src_pos, world_size, rank):
     return forward_fn(seq, pos)
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of /sys/.../local_cpulist)."""
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def device_local_cpus(index):
+    """The CPUs of the NUMA node the GPU `index` hangs off (its PCI function's local_cpulist), or None when sysfs does not
+    say (virtualised PCI, no such attribute)."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = '%04x:%02x:%02x.0' % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        with open('/sys/bus/pci/devices/%s/local_cpulist' % bdf) as f:
+            cpus = parse_cpulist(f.read())
+        return cpus or None
+    except (OSError, AttributeError, ValueError, RuntimeError):
+        return None
+
+
+def rank_cpu_set(allowed, local_lists, local_rank):
+    """Host logic of the pinning (no GPU needed): `allowed` = the CPUs this process may use, `local_lists[r]` = the CPUs local to
+    the device of local rank r (or None).  Rank r gets its device's local CPUs -- split evenly among the ranks whose devices
+    share that list, in rank order -- or, when the locality is unknown, an even contiguous share of `allowed`.
+    -> (sorted CPU list, 'pci-locality' | 'even-split')."""
+    allowed = sorted(allowed)
+    n = len(local_lists)
+    mine = local_lists[local_rank]
+    if mine:
+        mine = [c for c in mine if c in set(allowed)]
+    if mine:
+        sharers = [r for r in range(n) if local_lists[r] == local_lists[local_rank]]
+        k, i = len(sharers), sharers.index(local_rank)
+        lo, hi = shard_bounds(len(mine), k, i)
+        if hi > lo:
+            return mine[lo:hi], 'pci-locality'
+    lo, hi = shard_bounds(len(allowed), n, local_rank)
+    return (allowed[lo:hi] or allowed), 'even-split'
+
+
+def pin_rank_to_device_cpus(local_rank, local_world, device_of_rank=None):
+    """One process per GPU on a many-core host (the MI355X nodes have 256 CPUs on two sockets): keep this rank's Python issue
+    loop -- ~20 launches per 0.75 ms forward -- and torch's host threads on the cores next to ITS device instead of letting eight
+    ranks migrate over both sockets.  Replaces nothing in the reference (nn.DataParallel runs its replicas as threads of one
+    process, main.py:106-108).  LAMP_NO_PIN=1 leaves the affinity alone.  -> dict for the report."""
+    if os.environ.get('LAMP_NO_PIN') == '1' or not hasattr(os, 'sched_setaffinity'):
+        return {'pinned': False, 'reason': 'disabled' if os.environ.get('LAMP_NO_PIN') == '1' else 'no sched_setaffinity'}
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    device_of_rank = device_of_rank or (lambda r: r % max(n_dev, 1))
+    lists = [device_local_cpus(device_of_rank(r)) if n_dev else None for r in range(local_world)]
+    allowed = os.sched_getaffinity(0)
+    cpus, how = rank_cpu_set(allowed, lists, local_rank)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError as e:
+        return {'pinned': False, 'reason': str(e)}
+    torch.set_num_threads(max(1, min(len(cpus), 16)))
+    return {'pinned': True, 'cpus': len(cpus), 'first_cpu': cpus[0], 'last_cpu': cpus[-1], 'source': how}
+
+
 class ControlPlane:
     """torch.distributed as a CONTROL plane only (the forward has no collective): bench.py's barrier around the timed
     region, its gathers of per-rank reports and of a few logits for the cross-rank bitwise check, and run_eval's final

@@ -96,6 +96,12 @@ def test_bench_kernel_only_fraction_is_measured_in_the_run(dev):
         < 1e-6 * roof['achieved_kernel_only']
     split = roof['kernel_only_split']
     assert split['chain_kernel']['frac'] < roof['frac_kernel_only'] < split['gemm_nt_kernel']['frac'] < 1.0
+    # roofline.traffic and the attention block come from counter passes of the same invocation (three short rocprofv3 --pmc runs)
+    assert out['pmc'] and 'skipped' not in out['pmc'], out['pmc']
+    assert roof['traffic_source'] == 'live' and roof['traffic_stale'] is False and 1e6 < roof['traffic'] < 1e9
+    att = roof['attention']
+    assert att['source'].startswith('live:') and 0.0 < att['hbm_frac'] < 1.0 and 0.05 < att['mfma_busy'] < 1.0
+    assert any('attn16_kernel' in k for k in att['by_kernel'])
 
 
 def test_bench_and_eval_with_eight_ranks_on_one_device(dev, tmp_path):
@@ -114,6 +120,13 @@ def test_bench_and_eval_with_eight_ranks_on_one_device(dev, tmp_path):
         assert abs(out['value'] - 8 * 32 / (slowest * 1e-3)) < 1e-6 * out['value']
         if extra:
             assert len({p['padded_length'] for p in out['per_rank']}) > 1
+        # every rank says which physical device it ran on, which CPUs it was pinned to and how long its Python side takes to
+        # enqueue one forward (the host side of the 8-GPU run: eight issue loops on one host)
+        assert len({p['device_identity'] for p in out['per_rank']}) == 1
+        for p in out['per_rank']:
+            assert p['cpu_affinity']['pinned'] and p['cpu_affinity']['cpus'] >= 1, p['cpu_affinity']
+            assert 0.0 < p['host_issue_us_per_forward'] < 5000.0 and p['host_issue_frac_of_step'] > 0.0
+        assert out['host_issue_us_per_forward'] == max(p['host_issue_us_per_forward'] for p in out['per_rank'])
 
 
 def test_rccl_control_plane_calls_work(dev):

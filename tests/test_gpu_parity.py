@@ -516,11 +516,11 @@ def test_decoder_chain_launch_is_bit_identical(dev, tuning, monkeypatch, name, B
     assert max_abs_diff(got, ref) < TOL_LOGIT
 
 
-@pytest.mark.parametrize('geometry', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize('geometry', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
 def test_decoder_chain_every_geometry_is_bit_identical(dev, tuning, monkeypatch, geometry):
     """Every geometry of the chain launch (tuning build) -- waves x columns per wave, register sets of the W stream, LDS slots
     (0-4), W fragments straight from the native layout (5, 6), from the packed weights (7-10), and the round-5 kernel on packed
-    weights with the LayerNorm / bias operands in LDS (11-14), panels of 4 / 8 / 12 rows on the 4x4x1 MFMA (15-17): same k-order -- the bits of the separate
+    weights with the LayerNorm / bias operands in LDS (11-14), panels of 4 to 24 rows on the 4x4x1 MFMA (15-20): same k-order -- the bits of the separate
     launches, ragged batch with a partial last panel."""
     import ctypes
     from lamp_amd import _native as N
@@ -606,7 +606,7 @@ def test_decoder_chain_without_self_attention_and_odd_batches(dev, tuning, monke
     m = m.to(dev).eval()
     seq, spos = R.make_batch(50, V, T, lengths=[40, 7, 33, 12, 1] * 10, seed=3)
     seq, spos = seq.to(dev), spos.to(dev)
-    big, _, _ = m((seq, spos), None, None, None)            # 4500 rows = 282 panels: separate launches
+    big, _, _ = m((seq, spos), None, None, None)            # 4500 rows: 20-row panels with packed weights (282 sixteen-row panels: separate launches without)
     small, _, _ = m((seq[:45], spos[:45]), None, None, None)  # 4050 rows = 254 panels: the chain
     assert torch.equal(small, big[:45])
     monkeypatch.setattr(N, '_lib', tuning)
@@ -650,8 +650,9 @@ def test_weight_pack_formats_are_exact_rearrangements(dev):
 
 
 def test_chain_routes_of_the_product_library_give_every_sample_the_same_bits(dev):
-    """PRODUCT library, no debug hook: the decoder's row-local tail runs, by row count, as five launches (< 512 rows, > 4096),
-    as panels of 4, 8 or 12 rows on the 4x4x1 MFMA (<= 1024 / 2048 / 3072 rows), or as sixteen-row panels (<= 4096) -- from packed
+    """PRODUCT library, no debug hook: the decoder's row-local tail runs, by row count, as five launches (< 512 rows, > 6144),
+    as panels of 4, 8, 12, 20 or 24 rows on the 4x4x1 MFMA (<= 1024 / 2048 / 3072 / 5120 / 6144 rows), or as sixteen-row panels
+    (3073-4096 rows) -- from packed
     weights -- and from the native weight layouts (use_chain_packs = False: sixteen-row panels for 2049-4096 rows).  One pool
     of samples through every route: each sample's logits, encoder rows and intermediate read-outs come out bit-identical
     whatever batch it rides in, with and without the packs; a weight update through .data invalidates the packs."""
@@ -664,14 +665,16 @@ def test_chain_routes_of_the_product_library_give_every_sample_the_same_bits(dev
              dec_dropout2=False)
     m.load_state_dict(sd)
     m = m.to(dev).eval()
-    B = 50
-    seq, spos = R.make_batch(B, V, T, lengths=[T, 3, 17, 9, 24] * 10, seed=11)
+    B = 70   # 6300 rows: the five separate launches
+    seq, spos = R.make_batch(B, V, T, lengths=[T, 3, 17, 9, 24] * 14, seed=11)
     seq, spos = seq.to(dev), spos.to(dev)
     assert m.use_chain_packs
-    ref, enc_ref, ip_ref = m((seq, spos), None, None, None, int_preds=True)       # 4500 rows: separate launches
+    ref, enc_ref, ip_ref = m((seq, spos), None, None, None, int_preds=True)       # 6300 rows: separate launches
+    r64, _, ip64 = m((seq[:64], spos[:64]), None, None, None, int_preds=True)     # 5760 rows: 24-row panels
+    assert torch.equal(r64, ref[:64]) and all(torch.equal(a, w[:64]) for a, w in zip(ip64, ip_ref))
     packs = m._native_model()[4]
     assert packs is not None and packs[0].fc and packs[0].fc4 and packs[3].w24
-    for b in (4, 8, 12, 20, 24, 32, 40, 45):   # 360 (separate), 720, 1080, 1800, 2160, 2880, 3600, 4050 rows
+    for b in (4, 8, 12, 20, 24, 32, 40, 45, 48):   # 360 (separate), 720, 1080, 1800, 2160, 2880, 3600, 4050, 4320 (20-row panels) rows
         for lo in (0, B - b):
             got, enc, ip = m((seq[lo:lo + b], spos[lo:lo + b]), None, None, None, int_preds=True)
             assert torch.equal(got, ref[lo:lo + b]) and torch.equal(enc, enc_ref[lo:lo + b]), (b, lo)

@@ -260,6 +260,45 @@ def test_bench_kernel_trace_parsing_and_roofline_split(monkeypatch, tmp_path):
     sp = roof['kernel_only_split']
     assert abs(sp['chain_kernel']['tflops'] - 18.1 / 240.0 * 1e3) < 1e-9
     assert abs(sp['gemm_nt_kernel']['tflops'] - 51.1 / 338.0 * 1e3) < 1e-6
+    # ---- the counter passes (roofline.traffic, roofline.attention): three sub-runs, counters never beside another trace domain
+    calls = []
+
+    def fake_pmc(cmd, **kw):
+        assert cmd[1] == '--kernel-trace' and cmd[2] == '--pmc' and '--stats' not in cmd and '--sys-trace' not in cmd and '--no-pmc' in cmd
+        counters = cmd[3:cmd.index('-d')]
+        calls.append(counters)
+        out = cmd[cmd.index('-d') + 1]
+        kernels = [('void lamp::gemm_nt_kernel<64, 64, 16, 2, 2, false, 16, true, true, 0>(lamp::GemmParams, int)', 45.0, 30000.0, 20000.0),
+                   ('void lamp::chain_rows4_kernel<2, 3>(lamp::ChainParams)', 50.0, 4000.0, 6000.0),
+                   ('void lamp::attn16_kernel<128, 1, 4, 0, 3>(lamp::AttnParams)', 25.0, 9000.0, 1500.0)]
+        with open(os.path.join(out, 'p_kernel_trace.csv'), 'w') as f:
+            f.write('"Dispatch_Id","Start_Timestamp","End_Timestamp"\n')
+            for i, (_, us, _, _) in enumerate(kernels * 2):
+                f.write('%d,%d,%d\n' % (i, 1000000 * i, 1000000 * i + int(us * 1000)))
+        with open(os.path.join(out, 'p_counter_collection.csv'), 'w') as f:
+            f.write('"Dispatch_Id","Kernel_Name","Grid_Size","Workgroup_Size","Counter_Name","Counter_Value"\n')
+            for i, (name, us, fetch_kib, write_kib) in enumerate(kernels * 2):
+                for c in counters:
+                    v = {'FETCH_SIZE': fetch_kib, 'WRITE_SIZE': write_kib, 'SQ_BUSY_CYCLES': 32 * us * 1000 * 2.0,
+                         'SQ_VALU_MFMA_BUSY_CYCLES': 1024 * us * 1000 * 2.0 * 0.5}[c]
+                    f.write('%d,"%s",1024,256,"%s",%f\n' % (i, name, c, v))
+        return subprocess.CompletedProcess(cmd, 0, b'', b'')
+
+    monkeypatch.setattr(bench.subprocess, 'run', fake_pmc)
+    pmc = bench.live_pmc(args)
+    assert calls == [['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES']]
+    g = pmc['by_kernel']['gemm_nt_kernel<64, 64, 16, 2, 2, false, 16, true, true, 0>']
+    assert g['launches'] == 2 and abs(g['fetch_bytes'] - 30000.0 * 1024 * 2) < 1e-3 and abs(g['write_bytes'] - 20000.0 * 1024) < 1e-3
+    assert abs(g['mfma_busy'] - 0.5) < 1e-9 and abs(g['clock_ghz_under_profiler'] - 2.0) < 1e-9
+    roof = bench.roofline_of(prof, 10, 'reuters', live, 18.1, pmc, {'tflops': 60.0, 'algorithmic_gbs': 500.0})
+    want = ((30000.0 * 2 + 20000.0) + (4000.0 * 2 + 6000.0)) * 1024 / 2          # GEMM class: tile kernel + chain, per launch
+    assert roof['traffic_source'] == 'live' and abs(roof['traffic'] - want) < 1e-3 and roof['traffic_stale'] is False
+    att = roof['attention']
+    assert abs(att['hbm_gbs'] - (9000.0 * 2 + 1500.0) * 1024 / 25e-6 / 1e9) < 1e-6 and abs(att['mfma_busy'] - 0.5) < 1e-9
+    assert att['hbm_peak_gbs'] == 8000.0 and att['frac_of_fp32_mfma_peak'] == 60.0 / 157.3 and att['source'].startswith('live:')
+    # without the passes the committed figure is used and says so
+    assert bench.roofline_of(prof, 10, 'reuters', live, 18.1, {'skipped': 'x'}).get('traffic_source') in ('committed', None)
+    monkeypatch.setattr(bench.subprocess, 'run', fake_run)
     # a profiled parent never starts a nested profiler
     monkeypatch.setenv('ROCPROFILER_TOOL', '1')
     assert 'skipped' in bench.live_kernel_trace(args)

@@ -113,3 +113,27 @@ def test_bench_batches_are_rebuildable_by_every_rank():
     # analytic GEMM FLOPs of a fixed-length reuters step = what the library's launchers count (69.2 GFLOP)
     gf = bench.gemm_flops_per_step(bench.WORKLOADS['reuters'], 32, 32 * 302)
     assert abs(gf / 1e9 - 69.22) < 0.05
+
+
+def test_rank_cpu_sets_follow_device_locality():
+    """sharding.rank_cpu_set (host logic of the per-rank CPU pinning of bench.py --gpus N / run_eval -gpus N): ranks whose devices
+    share a NUMA node split its CPUs in rank order; unknown locality falls back to an even share of the allowed CPUs; the sets
+    of one node never overlap."""
+    from lamp_amd import sharding as S
+    assert S.parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11] and S.parse_cpulist('') == []
+    node0, node1 = list(range(0, 64)) + list(range(128, 192)), list(range(64, 128)) + list(range(192, 256))
+    lists = [node0] * 4 + [node1] * 4
+    allowed = set(range(256))
+    sets = [S.rank_cpu_set(allowed, lists, r) for r in range(8)]
+    assert all(how == 'pci-locality' and len(c) == 32 for c, how in sets)
+    assert set(sets[0][0]) <= set(node0) and set(sets[5][0]) <= set(node1)
+    flat = [c for cs, _ in sets for c in cs]
+    assert len(flat) == len(set(flat)) == 256
+    # no sysfs locality (virtualised PCI): an even contiguous share
+    sets = [S.rank_cpu_set(set(range(16)), [None] * 8, r) for r in range(8)]
+    assert [c for c, _ in sets] == [[2 * r, 2 * r + 1] for r in range(8)] and all(h == 'even-split' for _, h in sets)
+    # eight ranks sharing one device (the one-GPU rehearsal): its CPUs split eight ways; a restricted cpuset is honoured
+    cs, how = S.rank_cpu_set({0, 1, 2, 3}, [[0, 1, 2, 3, 4, 5, 6, 7]] * 2, 1)
+    assert cs == [2, 3] and how == 'pci-locality'
+    # more ranks than local CPUs: nobody is left with an empty set
+    assert S.rank_cpu_set({0, 1}, [[0, 1]] * 4, 3)[0]

@@ -6,7 +6,7 @@ TAG=$1; FLAGS=$2; shift 2
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 for name in "$@"; do
   lib=$PWD/lamp_amd/build/liblamp_$name.so; [ "$name" = cur ] && lib=$PWD/lamp_amd/liblamp_hip.so
-  ( cd /tmp && LAMP_HIP_LIBRARY=$lib rocprofv3 --kernel-trace --stats -d "$OUT/stats_$name" -o p -f csv -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-extra-workloads --no-pipelined $FLAGS > /dev/null 2>&1 )
+  ( cd /tmp && LAMP_HIP_LIBRARY=$lib rocprofv3 --kernel-trace --stats -d "$OUT/stats_$name" -o p -f csv -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-extra-workloads --no-pipelined --no-pmc $FLAGS > /dev/null 2>&1 )
   python - "$OUT/stats_$name/p_kernel_stats.csv" "$name" <<'PY' | tee -a $OUT/ab_kernel_stats.txt
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'lamp::' in r['Name']]

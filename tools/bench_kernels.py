@@ -369,7 +369,8 @@ def chain():
              8: 'W packed: 16 x 32, 4 sets', 9: 'W packed: 8 x 64, 2 sets', 10: 'W packed: 8 x 64, 4 sets',
              11: 'packed kernel: 16 x 32, 2 sets', 12: 'packed kernel: 16 x 32, 4 sets', 13: 'packed kernel: 8 x 64, 2 sets',
              14: 'packed kernel: 8 x 64, 4 sets', 15: '4x4x1 kernel: 4-row panels', 16: '4x4x1 kernel: 8-row panels',
-             17: '4x4x1 kernel: 12-row panels'}
+             17: '4x4x1 kernel: 12-row panels', 18: '4x4x1 kernel: 16-row panels', 19: '4x4x1 kernel: 20-row panels',
+             20: '4x4x1 kernel: 24-row panels'}
     if len(sys.argv) > 4:
         GEOMS = {int(k): GEOMS[int(k)] for k in sys.argv[4].split(',')}
     separate()

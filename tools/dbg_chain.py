@@ -28,7 +28,7 @@ def run(gi, res, r_mod, ffn=True):
 for label, res, r_mod, ffn in (('row residual', Y, 0, True), ('modulo residual', T, L, True), ('no residual', None, 0, True),
                                ('modulo residual, no ffn', T, L, False), ('row residual, no ffn', Y, 0, False)):
     ref = run(8, res, r_mod, ffn)
-    for gi in (0, 12, 13, 11, 14, 15, 16, 17):
+    for gi in (0, 12, 13, 11, 14, 15, 16, 17, 18, 19, 20):
         try:
             got = run(gi, res, r_mod, ffn)
         except Exception as e:

@@ -7,7 +7,7 @@ timeout 300 python tools/bench_kernels.py chain 4096 8 0,7,8,9,10 2>&1 | grep -v
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "chain or model_golden or baseline_sizes" -p no:cacheprovider 2>&1 | tail -5 | tee $OUT/pytest_chain.txt
 for r in 1 2 3; do
   for f in "" "--no-chain-packs"; do
-    python bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-extra-workloads --no-pipelined --no-kernel-trace $f 2>/dev/null | \
+    python bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-extra-workloads --no-pipelined --no-kernel-trace --no-pmc $f 2>/dev/null | \
       python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-18s' % sys.argv[1], round(d['value']), {k: round(v['us_per_step'],1) for k,v in d['kernels'].items()})" "packs${f}" | tee -a $OUT/ab_bench.txt
   done
 done
