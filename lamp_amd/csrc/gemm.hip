@@ -260,8 +260,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
     // held in vector registers compiles to a waterfall loop -- hand the compiler scalars)
     const __amdgpu_buffer_rsrc_t rsA =
         make_rsrc(uniform_ptr(Abase + m0 * p.lda), __builtin_amdgcn_readfirstlane(unsigned((uint64_t(rows_m - 1) * lda + p.K) * 4u)));
-    const __amdgpu_buffer_rsrc_t rsW =
-        make_rsrc(uniform_ptr(p.W[seg] + int64_t(n0) * p.ldw), __builtin_amdgcn_readfirstlane(unsigned((uint64_t(rows_n - 1) * ldw + p.K) * 4u)));
+    // WDIR with a packed copy (lamp_pack_weight format 0: per 16 columns and 32 k the two fragment chunks lane by lane): a fragment
+    // load is one contiguous KiB instead of 16 rows x 64 bytes
+    const bool wpk = WDIR && MF == 16 && p.Wp[seg] != nullptr;
+    const __amdgpu_buffer_rsrc_t rsW = wpk
+        ? make_rsrc(uniform_ptr(p.Wp[seg]), __builtin_amdgcn_readfirstlane(unsigned(uint64_t(p.N) * uint64_t(p.K) * 4u)))
+        : make_rsrc(uniform_ptr(p.W[seg] + int64_t(n0) * p.ldw), __builtin_amdgcn_readfirstlane(unsigned((uint64_t(rows_n - 1) * ldw + p.K) * 4u)));
 
     acc_t acc[T::MI][T::NI];
 #pragma unroll
@@ -283,10 +287,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
 #pragma unroll
         for (int c = 0; c < BK / KCH; ++c)
 #pragma unroll
-            for (int j = 0; j < T::NI; ++j) vow[c * T::NI + j] = unsigned((wn * T::WTN + j * MF + l31) * ldw + c * KCH + hi * 4) * 4u;
+            for (int j = 0; j < T::NI; ++j)
+                vow[c * T::NI + j] = wpk ? unsigned((n0 + wn * T::WTN + j * MF) / 16) * unsigned(p.K / 32) * 2048u + unsigned(c) * 1024u + unsigned(lane) * 16u
+                                         : unsigned((wn * T::WTN + j * MF + l31) * ldw + c * KCH + hi * 4) * 4u;
     }
     auto wload = [&](int k0, float4 (&wf)[NWF]) {
-        const unsigned so = unsigned(k0) * 4u;
+        const unsigned so = wpk ? unsigned(k0) * 64u : unsigned(k0) * 4u;
 #pragma unroll
         for (int x = 0; x < NWF; ++x) wf[x] = bload4(rsW, vow[x], so);
     };
@@ -833,6 +839,8 @@ static int launch_cfg(const GemmParams& p, hipStream_t s) {
 // Tuning build only (liblamp_hip_tuning.so: tools/bench_kernels.py and the every-variant tests): force a tile
 // configuration (0 = heuristic) and collect a per-workgroup timeline.  The production library has neither.
 static int g_force_tile = 0;
+static const float* g_gemm_wp = nullptr;   // packed copy of the NEXT launches' weight matrix (single segment), for the W-direct tiles
+extern "C" __attribute__((visibility("default"))) void lamp_debug_gemm_packed_w(const float* wp) { g_gemm_wp = wp; }
 static unsigned long long* g_gemm_trace = nullptr;  // n_slabs slabs of slab_words u64: launch i records into slab i % n_slabs,
 static long long g_trace_slab = 0;                  // 8 words per workgroup (entry, loop start, loop end, exit: wall_clock64
 static int g_trace_slabs = 0, g_trace_count = 0;    // ticks; HW_ID; XCC_ID; work item; main loop in shader cycles)
@@ -865,6 +873,7 @@ int launch_gemm(const GemmParams& p_in, hipStream_t s) {
     for (int i = 0; i < p.nseg; ++i) vec = vec && aligned16(p.C[i]) && (!p.bias[i] || aligned16(p.bias[i]));
     p.vec_epilogue = vec ? 1 : 0;
 #ifdef LAMP_TUNING
+    if (g_gemm_wp && p.nseg == 1 && p.N % 16 == 0 && p.K % 32 == 0) p.Wp[0] = g_gemm_wp;
     if (g_gemm_trace && g_trace_slabs > 0) {
         // upper bound of the grid over the tile menu: 32x64 tiles
         const long long wg_max = ((p.M + 31) / 32) * ((p.N + 63) / 64) * p.nseg;

@@ -24,6 +24,8 @@ struct GemmParams {
     int N;  // per segment
     int nseg;
     const float* W[GEMM_MAX_SEG];
+    const float* Wp[GEMM_MAX_SEG];   // nullable: the same matrices in format 0 of lamp_pack_weight (gemm.hip: W fragments straight from
+                                     // the packed copy, no LDS pass for W; experiment, tuning build)
     int64_t ldw;
     const float* bias[GEMM_MAX_SEG];
     float* C[GEMM_MAX_SEG];
@@ -122,7 +124,11 @@ int launch_seq_plan(const int64_t* seq, const int64_t* pos, int nb, int T, int64
                     const SeqPlan& sp, hipStream_t s);
 int launch_embed_packed(const int64_t* seq, const int64_t* pos, int nb, int T, const float* emb, int n_vocab,
                         const float* pos_table, int n_position, int d, const SeqPlan& sp, float* out, hipStream_t s);
-// the two above (packed layout) as ONE launch; granules: 2 * nb + 2 unsigned 64-bit words of workspace, any content
+// the two above (packed layout) as ONE launch; granules: 2 * nb + 2 unsigned 64-bit words of workspace.  Their content on entry
+// must not carry THIS launch's epoch tag: the tag is a host counter (unique per launch), and the last encoder LayerNorm of the
+// forward zeroes the granules again -- which is what makes a REPLAYED HIP graph (same tag every replay) safe.  Precondition of a
+// replay therefore: the previous replay ran to that LayerNorm (an aborted replay, or a workspace restored from a copy taken
+// between the gather and that LayerNorm, would leave granules of the same epoch behind; zero the 2 nb + 2 words first).
 int launch_embed_plan(const int64_t* seq, const int64_t* pos, bool plan_uses_pos, int nb, int T, const float* emb, int n_vocab,
                       const float* pos_table, int n_position, int d, const SeqPlan& sp, unsigned long long* granules, float* out,
                       hipStream_t s);

@@ -422,6 +422,43 @@ def chain():
                                                            cyc(g[:, 3] - g[:, 0]), q(g[:, 3] - g[:, 0], 0.5) / ghz / 1e3, ghz))
 
 
+def gemm_packed():
+    """W fragments straight from a PACKED weight copy in the tile GEMM (gemm.hip DMA = 3 with GemmParams::Wp): the W-direct tiles
+    30-33 with and without the pack against the production tiles, bit identity and round-robin medians on the token-row shapes."""
+    import statistics
+    lib = N.lib()
+    force = lib.lamp_debug_force_gemm_tile
+    force.argtypes = [ctypes.c_int]; force.restype = None
+    setwp = lib.lamp_debug_gemm_packed_w
+    setwp.argtypes = [ctypes.c_void_p]; setwp.restype = None
+    dev = torch.device('cuda:0')
+    shapes = [('encFFN 9664x512x512', 9664, 512, 512), ('encKV 9664x2048x512', 9664, 2048, 512), ('dec 2880x512x512', 2880, 512, 512),
+              ('decQKV 2880x1536x512', 2880, 1536, 512), ('delic ffn1 31456x2048x1024', 31456, 2048, 1024)]
+    cfgs = [(0, False), (11, False), (12, False), (18, False), (9, False), (30, False), (30, True), (31, True), (33, True), (32, True)]
+    print('%-28s' % 'shape (median us)' + ''.join('%14s' % (TILES[c] + ('+pk' if pk else '')) for c, pk in cfgs))
+    for name, M, Nn, K in shapes:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(Nn, K, device=dev) / K ** 0.5
+        wp = N.weight_pack(w, 0)
+        b = torch.randn(Nn, device=dev)
+        r = torch.randn(M, Nn, device=dev)
+        out = torch.empty(M, Nn, device=dev)
+
+        def fn():
+            N.check(lib.lamp_linear_fwd(x.data_ptr(), M, K, K, w.data_ptr(), Nn, K, b.data_ptr(), r.data_ptr(), Nn, 1, out.data_ptr(), Nn, N.stream()), 'linear')
+        force(0); setwp(None); fn(); want = out.clone()
+        samples = {c: [] for c in cfgs}
+        same = {}
+        for rnd in range(5):
+            for c in cfgs:
+                force(c[0]); setwp(wp.data_ptr() if c[1] else None)
+                if rnd == 0:
+                    out.zero_(); fn(); torch.cuda.synchronize(); same[c] = torch.equal(out, want)
+                samples[c].append(time_fn(fn, iters=5 if M * Nn * K > 1e11 else 20, warm=2))
+        force(0); setwp(None)
+        print('%-28s' % name + ''.join('%8.1f%s/%4.0f' % (statistics.median(samples[c]), ' ' if same[c] else '!', 2.0 * M * Nn * K / statistics.median(samples[c]) / 1e6) for c in cfgs))
+
+
 def slab():
     """The slab kernel (slab.hip: one slab of rows per CU, packed weights, 4x4x1 MFMA) against the tile kernel on the token-row GEMMs:
     bit identity and round-robin median times.  argv[2:]: row counts."""
@@ -820,4 +857,4 @@ def ffn_pair():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
     {'gemm': gemm, 'gemm_ab': gemm_ab, 'lib_ab': lib_ab, 'walk': walk, 'walk_pmc': walk_pmc, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
-     'gemm_trace': gemm_trace, 'gemm_clock': gemm_clock, 'attn_lib_ab': attn_lib_ab, 'chain': chain, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency, 'ffn_pair': ffn_pair, 'slab': slab}[which]()
+     'gemm_trace': gemm_trace, 'gemm_clock': gemm_clock, 'attn_lib_ab': attn_lib_ab, 'chain': chain, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency, 'ffn_pair': ffn_pair, 'slab': slab, 'gemm_packed': gemm_packed}[which]()
