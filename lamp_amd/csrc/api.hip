@@ -222,7 +222,7 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     const int64_t M = int64_t(B) * lq;
     const int64_t r_mod = xq_shared ? lq : 0;
     if (tail) tail->done = false;
-    if (h > 1 && tail && tail->ffn && chain_applies(M, d, hdv, tail->dff, true, tail->pk)) {
+    if (h > 1 && tail && tail->ffn && chain_applies(M, d, hdv, tail->dff, true, tail->pk, xq_shared, tail->w_out != nullptr)) {
         // fc (+ residual) -> LayerNorm -> W1 -> W2 (+ residual) -> LayerNorm in one launch over 16-row panels (same bits)
         tail->done = true;
         return launch_chain(sc.A, hdv, hdv, xq, r_mod, M, d, w.fc, w.ln_g, w.ln_b, tail->ffn, tail->dff,

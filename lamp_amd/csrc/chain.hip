@@ -1293,9 +1293,9 @@ static int rows4_groups(int64_t M, int d, int k_h, int dff, bool has_ffn, const 
     return lds4 <= size_t(160) * 1024 ? G : 0;
 }
 
-bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn, const lamp_chain_pack* pk) {
+bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn, const lamp_chain_pack* pk, bool res_mod, bool w_out) {
 #ifdef LAMP_NO_CHAIN   // A/B builds (tools/build_variant.sh with EXTRA=-DLAMP_NO_CHAIN=1): always the separate launches
-    (void)M; (void)d; (void)k_h; (void)dff; (void)has_ffn; (void)pk;
+    (void)M; (void)d; (void)k_h; (void)dff; (void)has_ffn; (void)pk; (void)res_mod; (void)w_out;
     return false;
 #else
     const ChainGeomInfo gi = chain_geom(chain_geom_index());
@@ -1314,7 +1314,9 @@ bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn, const lamp_
     // at 720 rows (five launches: 36), 34 at 1440 (49), 38 at 2048 (50), 46 at 2400 (63), 50 at 2880-3072 (64-65) -- and sixteen-row
     // panels up to 4096 rows (54-56 us against 77-82).  Below ~500 rows the five launches sit at their latency floor (~30 us).
     if (pk && pk->fc && (!has_ffn || (pk->w1 && pk->w2))) {
-        if (rows4_groups(M, d, k_h, dff, has_ffn, pk, true, false) > 0) return M >= 512;   // (residual rows and read-out rows never meet in one chain of a 2+ layer decoder)
+        // (res_mod / w_out: this sub-chain's LayerNorm operands that have to sit in LDS beside the panel -- the modulo residual rows
+        // of layer 0's first block, the read-out rows of the last block)
+        if (rows4_groups(M, d, k_h, dff, has_ffn, pk, res_mod, w_out) > 0) return M >= 512;
         return panels > 128 && panels <= 256;
     }
     // From the native layouts (round 4; profiles/r04_chain.txt): the chain takes 57-58 us whatever the row count (62 at one
@@ -1343,7 +1345,7 @@ int launch_chain(const float* A, int64_t lda, int k_h, const float* res, int64_t
                  int n_labels, float* logits, hipStream_t s, const lamp_chain_pack* pk) {
     if (!A || !w_fc || !ln1_g || !ln1_b || (!y && !w_out)) return LAMP_E_NULL;
     if (ffn && (!ffn->w1 || !ffn->b1 || !ffn->w2 || !ffn->b2 || !ffn->ln_g || !ffn->ln_b)) return LAMP_E_NULL;
-    if (!chain_applies(M, d, k_h, dff, ffn != nullptr, pk)) return LAMP_E_UNSUPPORTED;
+    if (!chain_applies(M, d, k_h, dff, ffn != nullptr, pk, res != nullptr && r_mod > 0, w_out != nullptr)) return LAMP_E_UNSUPPORTED;
     // every pointer below is read or written with 16-byte accesses (LDS-DMA rows, dwordx4 W stream, float4 LayerNorm operands)
     if (!aligned16(A) || !aligned16(res) || !aligned16(w_fc) || !aligned16(ln1_g) || !aligned16(ln1_b) || !aligned16(y) ||
         !aligned16(w_out) || (lda & 3))

@@ -144,7 +144,8 @@ int launch_layernorm(const float* x, int64_t M, int d, const float* g, const flo
 // chain.hip: the row-local tail of a decoder block -- attention output projection (+ residual) -> LayerNorm [-> FFN ->
 // LayerNorm] -- as ONE launch over 16-row panels, bit-identical to the separate launches.  chain_applies: shape limits
 // (LDS residency, tiling) and the row-count heuristic (at most one panel per CU).
-bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn, const lamp_chain_pack* pk = nullptr);
+bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn, const lamp_chain_pack* pk = nullptr, bool res_mod = false,
+                   bool w_out = false);
 int launch_chain(const float* A, int64_t lda, int k_h, const float* res, int64_t r_mod, int64_t M, int d, const float* w_fc,
                  const float* ln1_g, const float* ln1_b, const lamp_ffn_weights* ffn, int dff, float* y, const float* w_out,
                  int n_labels, float* logits, hipStream_t s, const lamp_chain_pack* pk = nullptr);
