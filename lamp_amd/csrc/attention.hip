@@ -299,8 +299,10 @@ __global__ __launch_bounds__(256, (PM == 0 && MK != LAMP_MASK_KEY_TOKENS_I64) ? 
                 f32x16 s;
                 scores(kt, s);
                 __builtin_amdgcn_sched_barrier(0);
+#if !(defined(ATTN_ABL) && (ATTN_ABL & 2))   // timing experiments (tools/build_variant.sh EXTRA=-DATTN_ABL=..): 2 = no loads in the loop
                 load_k(kn);     // unconditional prefetch, flies under softmax + PV
                 load_mask(kn);
+#endif
                 if constexpr (PM == 2) {
                     float* Srow = p.P + (int64_t(h) * p.P_batch + p.P_b0 + b) * int64_t(p.lq) * p.lk + int64_t(qi) * p.lk;
 #pragma unroll
@@ -309,6 +311,16 @@ __global__ __launch_bounds__(256, (PM == 0 && MK != LAMP_MASK_KEY_TOKENS_I64) ? 
                         if (qi < p.lq && key < p.lk) Srow[key] = s[r];
                     }
                 }
+#if defined(ATTN_ABL) && (ATTN_ABL & 1)   // 1 = no softmax arithmetic between the two products
+                l_run += 1.0f;
+                pv(s, o);
+                __builtin_amdgcn_sched_barrier(0);
+#if !(ATTN_ABL & 2)
+                load_v(kn);
+#endif
+                kt = kn;
+                continue;
+#endif
                 float tmax = s[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
@@ -334,7 +346,9 @@ __global__ __launch_bounds__(256, (PM == 0 && MK != LAMP_MASK_KEY_TOKENS_I64) ? 
                 l_run += psum;
                 pv(s, o);
                 __builtin_amdgcn_sched_barrier(0);
+#if !(defined(ATTN_ABL) && (ATTN_ABL & 2))
                 load_v(kn);  // flies under the next QK^T
+#endif
                 kt = kn;
             }
         }
