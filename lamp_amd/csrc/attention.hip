@@ -209,15 +209,24 @@ __global__ __launch_bounds__(256, (PM == 0 && MK != LAMP_MASK_KEY_TOKENS_I64) ? 
             if (key >= lk_b || blk) s[r] = -INFINITY;
         }
     };
-    auto pv = [&](const f32x16& pr, f32x16 (&o)[DVB]) {
+    auto pv = [&](const f32x16& pr, f32x16 (&o)[DVB], int k_next = -1) {
 #ifdef LAMP_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-        for (int e = 0; e < DVB; ++e)
+        for (int e = 0; e < DVB; ++e) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 o[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r][e], pr[r], o[e], 0, 0, 0);
+#ifdef ATTN_K_AFTER_PV0   // experiment: the next tile's K / mask requested behind the first PV block instead of behind QK^T
+            if (e == 0 && k_next >= 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_k(k_next);
+                load_mask(k_next);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+        }
 #ifdef LAMP_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(256, (PM == 0 && MK != LAMP_MASK_KEY_TOKENS_I64) ? 
                 f32x16 s;
                 scores(kt, s);
                 __builtin_amdgcn_sched_barrier(0);
-#if !(defined(ATTN_ABL) && (ATTN_ABL & 2))   // timing experiments (tools/build_variant.sh EXTRA=-DATTN_ABL=..): 2 = no loads in the loop
+#if !(defined(ATTN_ABL) && (ATTN_ABL & 2)) && !defined(ATTN_K_AFTER_PV0)   // timing experiments (tools/build_variant.sh EXTRA=-DATTN_ABL=..): 2 = no loads in the loop
                 load_k(kn);     // unconditional prefetch, flies under softmax + PV
                 load_mask(kn);
 #endif
@@ -344,7 +353,11 @@ __global__ __launch_bounds__(256, (PM == 0 && MK != LAMP_MASK_KEY_TOKENS_I64) ? 
                 }
                 psum += xor32(psum);
                 l_run += psum;
+#ifdef ATTN_K_AFTER_PV0
+                pv(s, o, kn);
+#else
                 pv(s, o);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #if !(defined(ATTN_ABL) && (ATTN_ABL & 2))
                 load_v(kn);  // flies under the next QK^T
@@ -475,7 +488,8 @@ __global__ __launch_bounds__(256) void softmax_from_scores_kernel(float* __restr
 
 #ifdef LAMP_TUNING
 // Tuning build only (liblamp_hip_tuning.so): 0 = heuristic; bits 0-2: force that key split (1/2/4); bits 4-6: query
-// blocks per workgroup of the small-shape kernel (attention_small.hip).
+// blocks per workgroup of the small-shape kernel (attention_small.hip); bit 7: that kernel for any query count; bit 8: no
+// LDS-tile kernel (attention_tile.hip).
 static int g_force_attn = 0;
 extern "C" __attribute__((visibility("default"))) void lamp_debug_force_attn(int v) { g_force_attn = v; }
 #else
@@ -516,6 +530,8 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     // at most 256 queries: 16-query blocks on 16x16x4 (attention_small.hip); bit 7 of the tuning hook lifts the limit
     if (attn_small_applies(p, (g_force_attn & 0x80) != 0))
         rc = launch_attn_small(p, g_force_attn, s);
+    else if (ksplit == 1 && !(g_force_attn & 0x100) && attn_tile_applies(p))   // bit 8 of the tuning hook: attn_kernel instead
+        rc = launch_attn_tile(p, s);
     else if (dmax <= 32)
         rc = launch_attn_dp<32>(p, ksplit, s);
     else if (dmax <= 64)

@@ -80,6 +80,9 @@ int launch_attn(const AttnParams& p, hipStream_t s);
 int launch_attn_general(const AttnParams& p, hipStream_t s);  // any d_k / d_v: scores through memory
 bool attn_small_applies(const AttnParams& p, bool any_lq = false);  // attention_small.hip: lq <= 256 or lk <= 64 (shape-only rule)
 int launch_attn_small(const AttnParams& p, int force_ksplit, hipStream_t s);
+// attention_tile.hip: long key sequences, K / V tiles shared by a workgroup through LDS-DMA; the bits of attn_kernel<128, 1, 0, MK>
+bool attn_tile_applies(const AttnParams& p);
+int launch_attn_tile(const AttnParams& p, hipStream_t s);
 size_t gemm_gen_workspace_bytes(int M, int N, int K, int batch);
 int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStream_t s);
 // Counter-based dropout (lamp_dropout): element e of a site is kept iff mix32(e, seed) >= threshold, kept values are

@@ -869,6 +869,89 @@ def test_sdpa_tile_skipping_is_exact(dev, lq, extra):
         assert torch.equal(out['sparse'], out['dense'])
 
 
+@pytest.mark.parametrize('B,H,lq,lk,dk,dv,mask_kind', [
+    (2, 2, 300, 256, 128, 128, 'bits'), (1, 2, 983, 983, 128, 128, 'none'), (1, 1, 983, 983, 128, 128, 'bits'),
+    (2, 1, 257, 300, 128, 128, 'bits'), (1, 2, 400, 1000, 96, 72, 'bits'), (1, 1, 385, 257, 68, 128, 'none'),
+    (1, 1, 1100, 2100, 128, 128, 'tiles'), (2, 1, 600, 600, 128, 100, 'tiles'), (1, 1, 520, 4096, 128, 128, 'bits')])
+def test_lds_tile_attention_has_the_bits_of_the_wave_private_kernel(dev, tuning, B, H, lq, lk, dk, dv, mask_kind):
+    """attention_tile.hip (K / V tiles shared by a workgroup through LDS-DMA, Q fragments in registers) against attn_kernel
+    (bit 8 of the tuning hook keeps it off): the same MFMA sequence on the same operands, so every output bit must agree --
+    ragged last tiles, head dimensions below 128 (range-checked chunks must land as ZEROS in LDS), dead rows, a late key
+    that forces the online rescale, and the union of the four query blocks' tile lists for a hinted shared mask."""
+    import ctypes
+    from lamp_amd import _native as N
+    force = tuning.lamp_debug_force_attn
+    g = torch.Generator().manual_seed(lq * 31 + lk + dk)
+    q = torch.randn(B, lq, H * dk, generator=g)
+    k = torch.randn(B, lk, H * dk, generator=g)
+    v = torch.randn(B, lk, H * dv, generator=g)
+    k[:, lk - 7, :dk] = q[:, 5, :dk] * 5.0       # a spike in the last tile: the running max jumps there
+    q, k, v = q.to(dev), k.to(dev), v.to(dev)
+    if mask_kind == 'tiles':
+        blocked = (clustered_adjacency(max(lq, lk), 7, extra=0.00002)[:lq, :lk] == 0).to(torch.uint8)
+    else:
+        blocked = (torch.rand(lq, lk, generator=g) < 0.5).to(torch.uint8)
+    blocked[:, 0] = 0
+    blocked[lq // 3, :] = 1                       # a dead row
+    bits = N.pack_mask_bits(blocked).to(dev)
+    tiles = N.active_tile_list(blocked.to(dev)).to(dev) if mask_kind == 'tiles' else None
+    if tiles is not None:
+        assert tiles[:, 0].float().mean().item() < 0.75 * (tiles.size(1) - 1)
+    ms = None if mask_kind == 'none' else N.Mask(N.LAMP_MASK_BITS_U32, 0, bits.data_ptr(), 0, bits.size(1),
+                                                 tiles.data_ptr() if tiles is not None else None,
+                                                 tiles.size(1) if tiles is not None else 0)
+    lay = N.AttnLayout(lq * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lk * H * dv, dv, H * dv, lq * H * dv, dv, H * dv)
+    out = {}
+    for name, mode in (('tile', 0), ('wave', 0x100)):
+        # poison what an earlier launch may have left in LDS is not possible from here; the zero fill itself is pinned by
+        # tools/probes/lds_dma_oob.hip -- here stale finite values would already show as wrong bits in the d_k = 96 case
+        o = torch.full((B, lq, H * dv), float('nan'), device=dev)
+        try:
+            force(mode)
+            N.check(tuning.lamp_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), None, B, H, lq, lk, dk, dv,
+                                         dk ** -0.5, ctypes.byref(ms) if ms is not None else None, ctypes.byref(lay),
+                                         N.stream()), 'sdpa')
+        finally:
+            force(0)
+        out[name] = o
+    dead = torch.isnan(out['wave'])
+    if mask_kind != 'none':
+        assert dead[:, lq // 3].all() and not dead[:, lq // 3 + 1].any()
+    assert torch.equal(dead, torch.isnan(out['tile']))
+    assert torch.equal(out['tile'][~dead], out['wave'][~dead])
+    # and the oracle, on one head
+    hq, hk, hv = q[:, :, :dk].cpu().double(), k[:, :, :dk].cpu().double(), v[:, :, :dv].cpu().double()
+    ref_o, _ = R.sdpa(hq, hk, hv, blocked.bool().unsqueeze(0).expand(B, lq, lk) if mask_kind != 'none' else None)
+    got = out['tile'][:, :, :dv].cpu()
+    ok = ~torch.isnan(got)
+    assert (got[ok].double() - ref_o[ok]).abs().max().item() < 5e-5
+
+
+def test_lds_tile_attention_inside_the_forward_ragged_keys_and_tile_lists(dev, tuning, monkeypatch):
+    """The same comparison through lamp_forward: 600 labels over ragged sources of up to 320 tokens -- the enc-dec attention
+    takes each sample's own key count and first row (AttnParams::kv_len / kv_off: descriptors that end at the sample's last
+    key), the label self-attention the model's tile lists."""
+    import ctypes
+    from lamp_amd import _native as N
+    cfg = (500, 600, 320, 256, 512, 2, 'prior', True, 4, 0.05, [320, 257, 31, 1])
+    m, sd, blocked, seq, spos, h = make_case(cfg, dev)
+    monkeypatch.setattr(N, '_lib', tuning)
+    force = tuning.lamp_debug_force_attn
+    src = (seq.to(dev), spos.to(dev))
+    try:
+        force(0x100)
+        want, enc_want, _ = m(src, None, None, None)
+        force(0)
+        for _ in range(3):
+            got, enc_got, _ = m(src, None, None, None)
+            assert torch.equal(got, want) and torch.equal(enc_got, enc_want)
+    finally:
+        force(0)
+    with torch.no_grad():
+        ref, _, _ = R.forward(sd, seq, spos, h, blocked)
+    assert max_abs_diff(got, ref) < TOL_LOGIT
+
+
 @pytest.mark.parametrize('lq,lk', [(90, 90), (159, 159), (70, 130), (33, 31)])
 def test_bit_packed_mask_equals_byte_mask(dev, lq, lk):
     """LAMP_MASK_BITS_U32 (one dword per row and 32-key tile) must give exactly the bits of the uint8 mask,

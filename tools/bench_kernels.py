@@ -502,6 +502,81 @@ def slab():
             print('M=%5d %-16s bitwise %s   tile %7.1f us (%5.1f TF)   slab %7.1f us (%5.1f TF)' % (M, name, same, mt, fl / mt / 1e6, ms, fl / ms / 1e6))
 
 
+def attn_tile(rounds=7):
+    """attention_tile.hip against attn_kernel (bit 8 of the tuning hook) on the long-sequence shapes, round-robin medians."""
+    import statistics
+    dev = torch.device('cuda:0')
+    cases = [('delicious self', 32, 8, 983, 983, 128, False), ('delicious self bits', 32, 8, 983, 983, 128, True),
+             ('synthetic self', 4, 8, 4096, 4096, 128, True), ('synthetic enc', 4, 8, 4096, 512, 128, False),
+             ('synthetic self B=8', 8, 8, 4096, 4096, 128, True)]
+    force = N.lib().lamp_debug_force_attn
+    force.argtypes = [ctypes.c_int]
+    for name, B, H, lq, lk, dk, masked in cases:
+        q = torch.randn(B, lq, H * dk, device=dev)
+        k = torch.randn(B, lk, H * dk, device=dev)
+        v = torch.randn(B, lk, H * dk, device=dev)
+        o = torch.empty(B, lq, H * dk, device=dev)
+        mask = (torch.rand(lq, lk, device=dev) < 0.9).to(torch.uint8)
+        mask[:, 0] = 0
+        bits = N.pack_mask_bits(mask).to(dev)
+        ms = N.Mask(N.LAMP_MASK_BITS_U32, 0, bits.data_ptr(), 0, bits.size(1)) if masked else None
+        lay = N.AttnLayout(lq * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lk * H * dk, dk, H * dk,
+                           lq * H * dk, dk, H * dk)
+        modes = (0, 0x100)
+        samples = [[] for _ in modes]
+        outs = []
+        for _ in range(rounds):
+            for i, mode in enumerate(modes):
+                force(mode)
+
+                def fn():
+                    N.check(N.lib().lamp_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), None, B, H, lq, lk,
+                                                  dk, dk, dk ** -0.5, ctypes.byref(ms) if ms is not None else None,
+                                                  ctypes.byref(lay), N.stream()), 'sdpa')
+                samples[i].append(time_fn(fn, iters=10, warm=2))
+                if len(outs) < 2:
+                    outs.append(o.clone())
+                force(0)
+        fl = 4.0 * B * H * lq * lk * dk
+        med = [statistics.median(x) for x in samples]
+        # the clock the key loop runs at: shader cycles / wall clock of wave 0 of every workgroup of the last of 4 launches
+        nwg = B * H * ((lq + 127) // 128)
+        buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
+        hook = N.lib().lamp_debug_set_attn_tile_trace
+        hook.argtypes = [ctypes.c_void_p]
+        hook.restype = None
+        hook(buf.data_ptr())
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
+        hook(None)
+        t = buf.cpu().view(-1, 8).double()
+        ghz = statistics.median(((t[:, 1] - t[:, 0]) / ((t[:, 3] - t[:, 2]) * 10.0)).tolist())
+        loop_us = statistics.median(((t[:, 3] - t[:, 2]) / 100.0).tolist())
+        span_us = (t[:, 3].max() - t[:, 2].min()).item() / 100.0
+        pipe = fl / 65536.0 / (med[0] * ghz * 1e3)     # MFMA cycles every SIMD needs / cycles of the launch at that clock
+        if len(sys.argv) > 2 and sys.argv[2] == 'timeline':
+            t0 = t[:, 2].min()
+            st, en = (t[:, 2] - t0) / 100.0, (t[:, 3] - t0) / 100.0
+            dur = en - st
+            q = lambda x, f: x.sort().values[int(f * (x.numel() - 1))].item()
+            print('   loop duration us  p5 %.0f p25 %.0f p50 %.0f p75 %.0f p95 %.0f max %.0f | start us p25 %.0f p50 %.0f p75 %.0f max %.0f | '
+                  'end us p50 %.0f p95 %.0f max %.0f' % (q(dur, .05), q(dur, .25), q(dur, .5), q(dur, .75), q(dur, .95), dur.max().item(),
+                                                         q(st, .25), q(st, .5), q(st, .75), st.max().item(), q(en, .5), q(en, .95), en.max().item()))
+            cu = ((t[:, 6].long() & 15) << 8) | ((t[:, 5].long() >> 8) & 0xff)      # XCC, SE / SH / CU
+            ids = cu.unique()
+            busy = torch.tensor([dur[cu == i].sum().item() for i in ids])
+            cnt = torch.tensor([(cu == i).sum().item() for i in ids])
+            for i in ids[:3].tolist() + ids[-2:].tolist():
+                sel = (cu == i).nonzero().flatten().tolist()
+                print('   CU %03x: ' % i + '  '.join('[%4.0f, %4.0f]' % (st[j].item(), en[j].item()) for j in sorted(sel, key=lambda j: st[j].item())))
+            print('   %d CUs seen; workgroups per CU min %d max %d; sum of loop time per CU (2 slots): min %.0f median %.0f max %.0f us of a %.0f us span' %
+                  (ids.numel(), cnt.min().item(), cnt.max().item(), busy.min().item(), busy.median().item(), busy.max().item(), en.max().item()))
+        print('%-22s tile kernel %9.1f us %6.1f TFLOP/s | attn_kernel %9.1f us %6.1f TFLOP/s | same bits: %s | loop clock %.3f GHz, '
+              'MFMA pipe busy %.3f of the launch; a workgroup\'s key loop %.1f us, first entry to last exit %.1f us' %
+              (name, med[0], fl / med[0] / 1e6, med[1], fl / med[1] / 1e6, torch.equal(outs[0], outs[1]), ghz, pipe, loop_us, span_us))
+
+
 def attn_lib_ab(rounds=9):
     """A/B of BUILDS of the library (argv[2:]: paths) on the attention shapes of the forwards, heuristic variant, the
     masks the forward uses (bit-packed label graph for self-attention, none for enc-dec: the padding mask of a full-length
@@ -857,4 +932,4 @@ def ffn_pair():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
     {'gemm': gemm, 'gemm_ab': gemm_ab, 'lib_ab': lib_ab, 'walk': walk, 'walk_pmc': walk_pmc, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
-     'gemm_trace': gemm_trace, 'gemm_clock': gemm_clock, 'attn_lib_ab': attn_lib_ab, 'chain': chain, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency, 'ffn_pair': ffn_pair, 'slab': slab, 'gemm_packed': gemm_packed}[which]()
+     'gemm_trace': gemm_trace, 'gemm_clock': gemm_clock, 'attn_lib_ab': attn_lib_ab, 'attn_tile': attn_tile, 'chain': chain, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency, 'ffn_pair': ffn_pair, 'slab': slab, 'gemm_packed': gemm_packed}[which]()
