@@ -111,25 +111,23 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
     auto tile_at = [&](int idx) { return idx < n_act ? (lst ? __builtin_amdgcn_readfirstlane(lst[idx]) : idx) : nt; };
 
     // ---- DMA: wave w requests rows 8w .. 8w+7 of the K and of the V tile, two rows (1 KiB) per instruction ----
+    // Per-lane offsets inside tile 0, with the head-dimension check folded in once (OOB + a tile's base stays out of range:
+    // bases are < 2^31); per tile one vector add per request.
     const int rr = lane >> 5, pp = lane & 31;   // row within the pair, linear 16-byte position
     unsigned kvo[4], vvo[4];
-    bool kok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 8 * wave + 2 * i + rr;
         const int q = pp ^ (r & 15);            // the chunk that belongs at position pp of row r
-        kok[i] = 4 * q < p.dk;
-        kvo[i] = unsigned(r * k_r + 4 * q) * 4u;
-        vvo[i] = unsigned(r * v_r + 4 * pp) * 4u;
+        kvo[i] = 4 * q < p.dk ? unsigned(r * k_r + 4 * q) * 4u : OOB;
+        vvo[i] = 4 * pp < p.dv ? unsigned(r * v_r + 4 * pp) * 4u : OOB;
     }
-    const bool vok = 4 * pp < p.dv;
-    // piece i of a tile's eight requests: 0-3 the K rows, 4-7 the V rows
-    auto dma_piece = [&](int i, unsigned kb, unsigned vb, unsigned dst) {
-#if defined(TILE_ABL) && (TILE_ABL & 2)   // 2 = no DMA and no barrier in the key loop (the first tile over and over)
-        if (kb != 0xffffffffu) return;
-#endif
-        if (i < 4) dma16(rsK, dst + 1024u * i, kok[i] ? kb + kvo[i] : OOB);
-        else dma16(rsV, dst + TILE_FLOATS * 4u + 1024u * (i - 4), vok ? vb + vvo[i - 4] : OOB);
+    const unsigned k_tile = 32u * unsigned(k_r) * 4u, v_tile = 32u * unsigned(v_r) * 4u;   // bytes from one tile to the next
+    auto dma_k = [&](int i, int kt, int buf) {
+        dma16(rsK, unsigned(buf) * (BUF_FLOATS * 4u) + unsigned(wave) * 4096u + 1024u * i, unsigned(kt) * k_tile + kvo[i]);
+    };
+    auto dma_v = [&](int i, int kt, int buf) {
+        dma16(rsV, unsigned(buf) * (BUF_FLOATS * 4u) + TILE_FLOATS * 4u + unsigned(wave) * 4096u + 1024u * i, unsigned(kt) * v_tile + vvo[i]);
     };
     // this row's 32 mask bits of a tile: an UNTRACKED load (lamp_asm.h) -- a load hipcc counts would make it wait, in the middle
     // of QK^T, until all but one of the loads behind it have landed: the next tile's DMA
@@ -138,11 +136,31 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
         if constexpr (MK == LAMP_MASK_BITS_U32) return buffer_read4_untracked(rsM, mrow + unsigned(kt) * 4u);
         return 0.f;
     };
+    // the value of the lane 32 away without LDS: v_permlane32_swap on (x, x) leaves (low half, low half) and (high half, high half)
+    auto other_half_max = [](float x) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    };
+    auto other_half_sum = [](float x) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    };
 
-    // fragment addresses (bytes): K  row l31, chunk (2c + hi) ^ (l31 & 15)  =  ky ^ 32c;   V  row 4hi + key(r), 16 bytes at 4 l31
+    // Fragment addresses.  K: row l31, chunk (2c + hi) ^ (l31 & 15) = (ky ^ 32 (c & 7)) + 256 (c >> 3): EIGHT per-lane addresses,
+    // everything else (c >> 3, the buffer) an immediate offset -- no vector instruction per read.  V: row 4hi + key(r), 16 bytes
+    // at 4 l31: one address, the row an immediate.
+    typedef __attribute__((address_space(3))) const f32x4* lds_f4;
     const unsigned ky = unsigned(l31) * 512u + unsigned((l31 & 15) ^ hi) * 16u;
-    const unsigned vy = TILE_FLOATS * 4u + unsigned(hi) * 2048u + unsigned(l31) * 16u;
-    const char* lds = reinterpret_cast<const char*>(smem);
+    unsigned ka[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ka[j] = ky ^ (32u * j);
+        asm volatile("" : "+v"(ka[j]));   // keep the eight addresses: recomputing one costs as much as an MFMA pass
+    }
+    unsigned va = TILE_FLOATS * 4u + unsigned(hi) * 2048u + unsigned(l31) * 16u;
+    asm volatile("" : "+v"(va));
+    auto read_k = [&](int buf, int c) { return *(lds_f4)(uintptr_t)(ka[c & 7] + unsigned(buf) * (BUF_FLOATS * 4u) + unsigned(c >> 3) * 256u); };
+    auto read_v = [&](int buf, int r) { return *(lds_f4)(uintptr_t)(va + unsigned(buf) * (BUF_FLOATS * 4u) + unsigned((r & 3) + 8 * (r >> 2)) * 512u); };
 
     f32x16 o[DVB];
 #pragma unroll
@@ -154,77 +172,77 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
     constexpr int AHEAD = 3;               // fragment reads in flight in front of the MFMAs that use them
 
     // tuning build: shader-clock cycles and 100 MHz wall clock around wave 0's key loop -> the clock the loop really runs at
-    unsigned long long t_c0 = 0, t_w0 = 0;
-    if (p.trace) {
-        t_c0 = __builtin_readcyclecounter();
-        t_w0 = wall_clock64();
-    }
-    int kt = tile_at(0);
-    sgpr_guard(rsK);
-    sgpr_guard(rsV);
-    sgpr_guard(rsM);
-    {
-        const unsigned kb = unsigned(kt) * 32u * unsigned(k_r) * 4u, vb = unsigned(kt) * 32u * unsigned(v_r) * 4u;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i < 4) dma16(rsK, unsigned(wave) * 4096u + 1024u * i, kok[i] ? kb + kvo[i] : OOB);
-            else dma16(rsV, unsigned(wave) * 4096u + TILE_FLOATS * 4u + 1024u * (i - 4), vok ? vb + vvo[i - 4] : OOB);
-        }
-    }
-    float mword = load_mask(kt);
-    wait_vmcnt<0>();
-    settle(mword);
-    __syncthreads();
-    for (int idx = 0; idx < n_act; ++idx) {
-        const int kn = tile_at(idx + 1);
-        const unsigned cur = unsigned(idx & 1) * (BUF_FLOATS * 4u);
-        const unsigned kb = unsigned(kn) * 32u * unsigned(k_r) * 4u, vb = unsigned(kn) * 32u * unsigned(v_r) * 4u;
-        const unsigned dst = (BUF_FLOATS * 4u - cur) + unsigned(wave) * 4096u;
-        float mnext = load_mask(kn);
-        if (wave_active) {
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-            const unsigned kbase = ky + cur, vbase = vy + cur;
-#if defined(TILE_ABL) && (TILE_ABL & 4)   // 4 = no fragment reads from LDS (the Q registers stand in)
-            auto read_k = [&](int c) { return qf[(c + 1) & 15]; };
-            auto read_v = [&](int r) { return qf[(r + 3) & 15]; };
-#else
-            auto read_k = [&](int c) { return *reinterpret_cast<const f32x4*>(lds + (kbase ^ (32u * c))); };
-            auto read_v = [&](int r) { return *reinterpret_cast<const f32x4*>(lds + vbase + unsigned((r & 3) + 8 * (r >> 2)) * 512u); };
+#ifdef TILE_TRACE
+    const unsigned long long t_c0 = __builtin_readcyclecounter(), t_w0 = wall_clock64();
+    unsigned long long ph[4] = {0, 0, 0, 0};
 #endif
-            f32x4 kk[AHEAD + 1];
+
+    // ONE TILE STEP (PAR = the tile's buffer, a compile-time constant: the loop below is unrolled by two).  Every vector
+    // instruction here costs matrix-pipe time (profiles/r05_mfma_chain.txt): on gfx950 the fp32 MFMA and the vector ALU are one
+    // resource, ~4.6 cycles per instruction on top of the 128 x 64 of the MFMAs -- so the step is written for instruction COUNT:
+    //   * blocked keys enter as the ACCUMULATOR'S initial value (-inf where blocked, 0 elsewhere: -inf + anything finite = -inf,
+    //     0 + x = what the constant-zero accumulator gives): two instructions per score (bit-field extract, shift into
+    //     0xff800000), none after the product; keys past the sample's last one are merged into the mask word (one scalar OR);
+    //     without a mask only the sample's last, partial tile takes this path at all;
+    //   * fragment addresses are loop invariants plus immediates; the DMA offsets one add per request;
+    //   * score - max as eight packed subtractions; lane exchanges through v_permlane32_swap.
+    auto step = [&](auto par, int idx, int kt, int kn, float mword, float& mnext) {
+        constexpr int PAR = decltype(par)::value;
+#ifdef TILE_TRACE
+        const unsigned long long ts0 = __builtin_readcyclecounter();
+        if (p.trace && tid == 0 && idx < 256)   // when this workgroup started each of its first 256 tiles
+            p.trace[size_t(gridDim.x) * 8 + size_t(blockIdx.x) * 256 + idx] = wall_clock64();
+#endif
+        mnext = load_mask(kn);
+        {
+            const int valid = lk_b - kt * 32;                                     // keys of this tile (>= 1)
+            const unsigned tail = valid >= 32 ? 0u : ~0u << valid;                // scalar
+            f32x16 s;
+            auto qk = [&](auto biased) {
+                if constexpr (decltype(biased)::value) {
+                    const int mw = int((__float_as_uint(mword) | tail) >> (4 * hi));
 #pragma unroll
-            for (int c = 0; c < AHEAD; ++c) kk[c] = read_k(c);
+                    for (int r = 0; r < 16; ++r) {   // 0 or 0xff800000 = -inf: bit-field extract (0 / -1), AND -- in assembly, or hipcc makes it three
+                        int t;
+                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t) : "v"(mw), "n"((r & 3) + 8 * (r >> 2)));
+                        s[r] = __int_as_float(t & int(0xff800000u));
+                    }
+                } else {
 #pragma unroll
-            for (int c = 0; c < DKC; ++c) {
-                if (c + AHEAD < DKC) kk[(c + AHEAD) % (AHEAD + 1)] = read_k(c + AHEAD);
-                if ((c & 1) == 0) dma_piece(c >> 1, kb, vb, dst);   // the next tile's requests, one per two fragments
-                const f32x4 k4 = kk[c % (AHEAD + 1)];
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[0], qf[c][0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[1], qf[c][1], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[2], qf[c][2], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[3], qf[c][3], s, 0, 0, 0);
-            }
+                    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                }
+                f32x4 kk[AHEAD + 1];
+#pragma unroll
+                for (int c = 0; c < AHEAD; ++c) kk[c] = read_k(PAR, c);
+#pragma unroll
+                for (int c = 0; c < DKC; ++c) {
+                    if (c + AHEAD < DKC) kk[(c + AHEAD) % (AHEAD + 1)] = read_k(PAR, c + AHEAD);
+                    if ((c & 1) == 0) {   // the next tile's requests, one per two fragments
+                        if (c < 8) dma_k(c >> 1, kn, PAR ^ 1);
+                        else dma_v((c - 8) >> 1, kn, PAR ^ 1);
+                    }
+                    const f32x4 k4 = kk[c % (AHEAD + 1)];
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[0], qf[c][0], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[1], qf[c][1], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[2], qf[c][2], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[3], qf[c][3], s, 0, 0, 0);
+                }
+            };
+            if (MK == LAMP_MASK_BITS_U32 || tail != 0u) qk(std::true_type{});
+            else qk(std::false_type{});
+#ifdef TILE_TRACE
+            ph[0] += __builtin_readcyclecounter() - ts0;
+#endif
             f32x4 vv[AHEAD + 1];   // the first V fragments fly under the softmax
 #pragma unroll
-            for (int r = 0; r < AHEAD; ++r) vv[r] = read_v(r);
-            const int keyb = kt * 32 + 4 * hi;
-            const unsigned mw = MK == LAMP_MASK_BITS_U32 ? __float_as_uint(mword) >> (4 * hi) : 0u;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = keyb + (r & 3) + 8 * (r >> 2);
-                bool blk = false;
-                if constexpr (MK == LAMP_MASK_BITS_U32) blk = (mw & (1u << ((r & 3) + 8 * (r >> 2)))) != 0;
-                if (key >= lk_b || blk) s[r] = -INFINITY;
-            }
+            for (int r = 0; r < AHEAD; ++r) vv[r] = read_v(PAR, r);
 #if defined(TILE_ABL) && (TILE_ABL & 1)   // timing experiments (EXTRA=-DTILE_ABL=.. tools/build_variant.sh): 1 = no softmax arithmetic
             l_run += 1.0f;
 #else
             float tmax = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = other_half_max(tmax);
             if (__any(tmax > m_run + RESCALE_THR)) {
                 const float m_new = fmaxf(m_run, tmax);
                 const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
@@ -236,41 +254,93 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
                     for (int r = 0; r < 16; ++r) o[e][r] *= alpha;
             }
             const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
             float psum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 d = f32x2{s[r], s[r + 1]} - f32x2{m_use, m_use};   // v_pk_add_f32
+                s[r] = __builtin_amdgcn_exp2f(d[0]);
+                s[r + 1] = __builtin_amdgcn_exp2f(d[1]);
                 psum += s[r];
+                psum += s[r + 1];
             }
-            psum += __shfl_xor(psum, 32, 64);
-            l_run += psum;
+            l_run += other_half_sum(psum);
 #endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (r + AHEAD < 16) vv[(r + AHEAD) % (AHEAD + 1)] = read_v(r + AHEAD);
+                if (r + AHEAD < 16) vv[(r + AHEAD) % (AHEAD + 1)] = read_v(PAR, r + AHEAD);
                 const f32x4 v4 = vv[r % (AHEAD + 1)];
 #pragma unroll
                 for (int e = 0; e < DVB; ++e) o[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[e], s[r], o[e], 0, 0, 0);
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dma_piece(i, kb, vb, dst);
         }
+#ifdef TILE_TRACE
+        const unsigned long long ts2 = __builtin_readcyclecounter();
+#endif
         wait_vmcnt<0>();       // this wave's quarter of tile kn has landed ...
         settle(mnext);
+#ifdef TILE_TRACE
+        const unsigned long long ts3 = __builtin_readcyclecounter();
+#endif
 #if !(defined(TILE_ABL) && (TILE_ABL & 2))
         __syncthreads();       // ... and everybody's; everybody is done reading tile kt
 #endif
-        kt = kn;
-        mword = mnext;
+#ifdef TILE_TRACE   // where a step's cycles go (QK^T | softmax + PV | wait for the DMA | barrier)
+        const unsigned long long ts4 = __builtin_readcyclecounter();
+        ph[1] += ts2 - ts0;
+        ph[2] += ts3 - ts2;
+        ph[3] += ts4 - ts3;
+#endif
+    };
+    // a wave whose 32 queries lie past the last one: its share of the requests and the barriers, nothing else
+    auto idle_step = [&](int kn, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_k(i, kn, buf);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_v(i, kn, buf);
+        wait_vmcnt<0>();
+#if !(defined(TILE_ABL) && (TILE_ABL & 2))
+        __syncthreads();
+#endif
+    };
+
+    if (n_act > 0) {
+        int kt = tile_at(0);
+        sgpr_guard(rsK);
+        sgpr_guard(rsV);
+        sgpr_guard(rsM);
+        float mw0 = load_mask(kt), mw1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_k(i, kt, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_v(i, kt, 0);
+        wait_vmcnt<0>();
+        settle(mw0);
+        __syncthreads();
+        if (wave_active) {
+            int idx = 0;
+            for (; idx + 1 < n_act; idx += 2) {   // two tiles per trip: the buffer of a step is a compile-time constant
+                const int k1 = tile_at(idx + 1);
+                step(std::integral_constant<int, 0>{}, idx, kt, k1, mw0, mw1);
+                kt = tile_at(idx + 2);
+                step(std::integral_constant<int, 1>{}, idx + 1, k1, kt, mw1, mw0);
+            }
+            if (idx < n_act) step(std::integral_constant<int, 0>{}, idx, kt, nt, mw0, mw1);   // an odd last tile
+        } else {
+            for (int idx = 0; idx < n_act; ++idx) idle_step(tile_at(idx + 1), (idx + 1) & 1);
+        }
     }
 
+#ifdef TILE_TRACE
     if (p.trace && tid == 0) {
         unsigned long long* t = p.trace + size_t(blockIdx.x) * 8;
         t[0] = t_c0; t[1] = __builtin_readcyclecounter(); t[2] = t_w0; t[3] = wall_clock64(); t[4] = unsigned(n_act);
         t[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: bits 8-11 CU, 12 SH, 13-15 SE (placement)
         t[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // XCC_ID
+        unsigned long long* u = p.trace + size_t(gridDim.x) * (8 + 256) + size_t(blockIdx.x) * 4;
+        u[0] = ph[0]; u[1] = ph[1] - ph[0]; u[2] = ph[2]; u[3] = ph[3];
     }
+#endif
     const float inv_l = 1.0f / l_run;
 #pragma unroll
     for (int e = 0; e < DVB; ++e)

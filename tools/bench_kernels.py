@@ -541,7 +541,7 @@ def attn_tile(rounds=7):
         med = [statistics.median(x) for x in samples]
         # the clock the key loop runs at: shader cycles / wall clock of wave 0 of every workgroup of the last of 4 launches
         nwg = B * H * ((lq + 127) // 128)
-        buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
+        buf = torch.zeros(nwg * (8 + 256 + 4), dtype=torch.int64, device=dev)
         hook = N.lib().lamp_debug_set_attn_tile_trace
         hook.argtypes = [ctypes.c_void_p]
         hook.restype = None
@@ -550,7 +550,13 @@ def attn_tile(rounds=7):
             fn()
         torch.cuda.synchronize()
         hook(None)
-        t = buf.cpu().view(-1, 8).double()
+        tiles_t = buf[nwg * 8:nwg * (8 + 256)].cpu().view(nwg, 256).double()
+        phases = buf[nwg * (8 + 256):].cpu().view(nwg, 4).double()
+        t = buf[:nwg * 8].cpu().view(-1, 8).double()
+        if t[:, 3].max().item() == 0:   # a library without -DTILE_TRACE: no stamps
+            print('%-22s tile kernel %9.1f us %6.1f TFLOP/s | attn_kernel %9.1f us %6.1f TFLOP/s | same bits: %s' %
+                  (name, med[0], fl / med[0] / 1e6, med[1], fl / med[1] / 1e6, torch.equal(outs[0], outs[1])))
+            continue
         ghz = statistics.median(((t[:, 1] - t[:, 0]) / ((t[:, 3] - t[:, 2]) * 10.0)).tolist())
         loop_us = statistics.median(((t[:, 3] - t[:, 2]) / 100.0).tolist())
         span_us = (t[:, 3].max() - t[:, 2].min()).item() / 100.0
@@ -570,6 +576,15 @@ def attn_tile(rounds=7):
             for i in ids[:3].tolist() + ids[-2:].tolist():
                 sel = (cu == i).nonzero().flatten().tolist()
                 print('   CU %03x: ' % i + '  '.join('[%4.0f, %4.0f]' % (st[j].item(), en[j].item()) for j in sorted(sel, key=lambda j: st[j].item())))
+            # tile steps of the workgroups of one CU: us per 16 tiles along each workgroup's life (2 x 8192 MFMA cycles per SIMD and
+            # pair of tiles = 6.86 us at 2.39 GHz when two workgroups share the CU, 3.43 us per tile for one alone)
+            nt_ = min((lk + 31) // 32, 256)
+            for j in sorted((cu == ids[0]).nonzero().flatten().tolist(), key=lambda j: st[j].item()):
+                tt = (tiles_t[j, :nt_] - t0) / 100.0
+                steps = [(tt[min(a + 16, nt_ - 1)] - tt[a]).item() / (min(a + 16, nt_ - 1) - a) for a in range(0, nt_ - 1, 16)]
+                print('   CU %03x workgroup from %4.0f us: us per tile, 16-tile windows: ' % (ids[0], st[j].item()) + ' '.join('%.2f' % x for x in steps))
+                print('        wave 0, shader cycles per tile step: QK^T + softmax %.0f | PV + mask %.0f | wait for the DMA %.0f | barrier %.0f' %
+                      tuple((phases[j] / max(t[j, 4].item(), 1)).tolist()))
             print('   %d CUs seen; workgroups per CU min %d max %d; sum of loop time per CU (2 slots): min %.0f median %.0f max %.0f us of a %.0f us span' %
                   (ids.numel(), cnt.min().item(), cnt.max().item(), busy.min().item(), busy.median().item(), busy.max().item(), en.max().item()))
         print('%-22s tile kernel %9.1f us %6.1f TFLOP/s | attn_kernel %9.1f us %6.1f TFLOP/s | same bits: %s | loop clock %.3f GHz, '

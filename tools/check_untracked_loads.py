@@ -56,6 +56,33 @@ def sregs_of(text):
     return out
 
 
+def pk_sources(parts):
+    """Registers a packed instruction (v_pk_mul_f32 v[d:d+1], v[a:a+1], v[b:b+1] op_sel:[..] op_sel_hi:[..]) really reads: of a
+    two-register source the low one feeds a result half whose select bit is 0, the high one a half whose bit is 1 (defaults
+    op_sel = 0, op_sel_hi = 1) -- `v[92:93] ... op_sel_hi:[0,1]` broadcasts v92 and never touches v93."""
+    text = ','.join(parts[1:])
+    sel = {'op_sel': None, 'op_sel_hi': None}
+    for key in sel:
+        m = re.search(key + r':\[([01,]+)\]', text)
+        if m:
+            sel[key] = [int(x) for x in m.group(1).split(',')]
+    text = re.sub(r'op_sel(_hi)?:\[[01,]+\]', '', text)
+    out = set()
+    for k, src in enumerate([x.strip() for x in text.split(',') if x.strip()]):
+        m = re.match(r'v\[(\d+):(\d+)\]', src)
+        if not m or int(m.group(2)) - int(m.group(1)) != 1:
+            out |= regs_of(src)
+            continue
+        lo, hi = int(m.group(1)), int(m.group(2))
+        a = sel['op_sel'][k] if sel['op_sel'] and k < len(sel['op_sel']) else 0
+        b = sel['op_sel_hi'][k] if sel['op_sel_hi'] and k < len(sel['op_sel_hi']) else 1
+        if a == 0 or b == 0:
+            out.add(lo)
+        if a == 1 or b == 1:
+            out.add(hi)
+    return out
+
+
 def check(asm, wanted=('chain', 'slab')):
     """-> (kernels checked, loads checked, findings: [(kernel, load line no, load, reader line no, reader)]).
 
@@ -147,7 +174,7 @@ def check(asm, wanted=('chain', 'slab')):
         operands = ops[1].split(';')[0]
         parts = [p.strip() for p in operands.split(',')]
         is_store = ops[0].startswith(('ds_write', 'buffer_store', 'global_store', 'scratch_store', 'buffer_load'))
-        srcs = regs_of(','.join(parts if is_store else parts[1:]))
+        srcs = pk_sources(parts) if ops[0].startswith('v_pk_') else regs_of(','.join(parts if is_store else parts[1:]))
         dsts = set() if is_store else regs_of(parts[0])
         for regs, lno, ltxt in all_pending():
             if regs & srcs:
