@@ -31,8 +31,10 @@ constexpr size_t LDS_BYTES_LIST = LDS_BYTES + (MAX_LIST_TILES / 32) * 4 + MAX_LI
 
 // One KiB of a tile: lane l's 16 bytes land at lds_addr + 16 l.  m0 carries the LDS address; the instruction behind s_mov m0
 // needs one wait state.
-__device__ __forceinline__ void dma16(u32x4 rs, unsigned lds_addr, unsigned voff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs)
+// The tile's base goes in the SCALAR offset: the descriptor's range check covers voffset + soffset (tools/probes/lds_dma_oob.hip),
+// so the per-lane offsets are loop invariants and a request costs no vector instruction.
+__device__ __forceinline__ void dma16(u32x4 rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
                  : "memory");   // m0: nothing else in this kernel uses it (tests/test_kernel_resources.py checks the ISA)
 }
 
@@ -66,14 +68,7 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
                                      unsigned((uint64_t(p.lq - 1) * uint64_t(p.m_sq) + (p.lk + 31) / 32) * 4u))
                           : raw_rsrc(p.K, 0u);
 
-    // ---- this lane's Q fragments: Q[query][8c + 4hi .. +3], pre-scaled exactly as attn_kernel's LDS copy ----
-    f32x4 qf[DKC];
-#pragma unroll
-    for (int c = 0; c < DKC; ++c) {
-        const int col = 8 * c + 4 * hi;
-        const float4 v = bload4(rsQ, (qi < p.lq && col < p.dk) ? unsigned(qi * q_r + col) * 4u : OOB, 0);
-        qf[c] = f32x4{v.x * p.scale_log2e, v.y * p.scale_log2e, v.z * p.scale_log2e, v.w * p.scale_log2e};
-    }
+    f32x4 qf[DKC];   // this lane's Q fragments, loaded behind the first tile's requests (below)
 
     // ---- the key tiles this workgroup visits ----
     const int nt = (lk_b + 31) / 32;
@@ -112,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
 
     // ---- DMA: wave w requests rows 8w .. 8w+7 of the K and of the V tile, two rows (1 KiB) per instruction ----
     // Per-lane offsets inside tile 0, with the head-dimension check folded in once (OOB + a tile's base stays out of range:
-    // bases are < 2^31); per tile one vector add per request.
+    // bases are < 2^31); the tile's base is the instruction's scalar offset.
     const int rr = lane >> 5, pp = lane & 31;   // row within the pair, linear 16-byte position
     unsigned kvo[4], vvo[4];
 #pragma unroll
@@ -124,10 +119,10 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
     }
     const unsigned k_tile = 32u * unsigned(k_r) * 4u, v_tile = 32u * unsigned(v_r) * 4u;   // bytes from one tile to the next
     auto dma_k = [&](int i, int kt, int buf) {
-        dma16(rsK, unsigned(buf) * (BUF_FLOATS * 4u) + unsigned(wave) * 4096u + 1024u * i, unsigned(kt) * k_tile + kvo[i]);
+        dma16(rsK, unsigned(buf) * (BUF_FLOATS * 4u) + unsigned(wave) * 4096u + 1024u * i, kvo[i], unsigned(kt) * k_tile);
     };
     auto dma_v = [&](int i, int kt, int buf) {
-        dma16(rsV, unsigned(buf) * (BUF_FLOATS * 4u) + TILE_FLOATS * 4u + unsigned(wave) * 4096u + 1024u * i, unsigned(kt) * v_tile + vvo[i]);
+        dma16(rsV, unsigned(buf) * (BUF_FLOATS * 4u) + TILE_FLOATS * 4u + unsigned(wave) * 4096u + 1024u * i, vvo[i], unsigned(kt) * v_tile);
     };
     // this row's 32 mask bits of a tile: an UNTRACKED load (lamp_asm.h) -- a load hipcc counts would make it wait, in the middle
     // of QK^T, until all but one of the loads behind it have landed: the next tile's DMA
@@ -139,7 +134,9 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
     // the value of the lane 32 away without LDS: v_permlane32_swap on (x, x) leaves (low half, low half) and (high half, high half)
     auto other_half_max = [](float x) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-        return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+        float m;
+        asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+        return m;
     };
     auto other_half_sum = [](float x) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -239,9 +236,12 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
 #if defined(TILE_ABL) && (TILE_ABL & 1)   // timing experiments (EXTRA=-DTILE_ABL=.. tools/build_variant.sh): 1 = no softmax arithmetic
             l_run += 1.0f;
 #else
-            float tmax = s[0];
+            // row maximum: seven v_max3 and one v_max, in assembly (fmaxf() brings a canonicalising v_max x, x per operand chain)
+            float tmax;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(s[0]), "v"(s[1]), "v"(s[2]));
 #pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+            for (int r = 3; r < 15; r += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tmax) : "v"(s[r]), "v"(s[r + 1]));
+            asm("v_max_f32 %0, %0, %1" : "+v"(tmax) : "v"(s[15]));
             tmax = other_half_max(tmax);
             if (__any(tmax > m_run + RESCALE_THR)) {
                 const float m_new = fmaxf(m_run, tmax);
@@ -254,17 +254,19 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
                     for (int r = 0; r < 16; ++r) o[e][r] *= alpha;
             }
             const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            float psum = 0.f;
+            const f32x2 mm = {m_use, m_use};
+            f32x2 ps = {0.f, 0.f};   // even and odd registers summed apart (v_pk_add_f32), as attn_kernel does
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const f32x2 d = f32x2{s[r], s[r + 1]} - f32x2{m_use, m_use};   // v_pk_add_f32
-                s[r] = __builtin_amdgcn_exp2f(d[0]);
-                s[r + 1] = __builtin_amdgcn_exp2f(d[1]);
-                psum += s[r];
-                psum += s[r + 1];
+                f32x2 d;   // (s[r], s[r+1]) - (m, m) as ONE packed add (hipcc splits it into two)
+                asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(f32x2{s[r], s[r + 1]}), "v"(mm));
+                d[0] = __builtin_amdgcn_exp2f(d[0]);
+                d[1] = __builtin_amdgcn_exp2f(d[1]);
+                asm("v_pk_add_f32 %0, %0, %1" : "+v"(ps) : "v"(d));
+                s[r] = d[0];
+                s[r + 1] = d[1];
             }
-            l_run += other_half_sum(psum);
+            l_run += other_half_sum(ps[0] + ps[1]);
 #endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -314,6 +316,14 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
         for (int i = 0; i < 4; ++i) dma_k(i, kt, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_v(i, kt, 0);
+        // ---- this lane's Q fragments: Q[query][8c + 4hi .. +3], pre-scaled exactly as attn_kernel's LDS copy; requested BEHIND
+        // the first tile so that the two memory round trips of a workgroup's start overlap ----
+#pragma unroll
+        for (int c = 0; c < DKC; ++c) {
+            const int col = 8 * c + 4 * hi;
+            const float4 v = bload4(rsQ, (qi < p.lq && col < p.dk) ? unsigned(qi * q_r + col) * 4u : OOB, 0);
+            qf[c] = f32x4{v.x * p.scale_log2e, v.y * p.scale_log2e, v.z * p.scale_log2e, v.w * p.scale_log2e};
+        }
         wait_vmcnt<0>();
         settle(mw0);
         __syncthreads();

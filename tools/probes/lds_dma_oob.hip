@@ -11,6 +11,19 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
+// the same with part of the offset in the instruction's SCALAR offset: does the range check see voffset + soffset?
+__global__ void probe_soffset(const float* src, unsigned bytes, float* out, unsigned soff) {
+    __shared__ __attribute__((aligned(16))) float buf[256];
+    const int l = threadIdx.x;
+    for (int i = 0; i < 4; ++i) buf[4 * l + i] = __builtin_nanf("");
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, int(bytes), 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)buf, 16, unsigned(l) * 16u, soff, 0, 0);   // lane l: bytes soff + 16 l ..
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = 0; i < 4; ++i) out[4 * l + i] = buf[4 * l + i];
+}
+
 __global__ void probe(const float* src, unsigned bytes, float* out) {
     __shared__ __attribute__((aligned(16))) float buf[256];
     const int l = threadIdx.x;
@@ -52,5 +65,17 @@ int main() {
     printf("in-range lanes wrong: %d; out-of-range values not zero: %d (NaN left in place: %d)\n", bad_in, nonzero_oob, nan_oob);
     printf("lane 16 (straddles the end): %g %g %g %g\n", r[64], r[65], r[66], r[67]);
     printf("%s\n", (bad_in == 0 && nonzero_oob == 0) ? "LDS-DMA writes ZEROS for range-checked lanes" : "LDS-DMA does NOT zero-fill");
+    // scalar offset: descriptor of 2048 bytes (the allocation is 4096), soffset 1536: lanes 0-31 in range, lanes 32-63 past num_records
+    hipLaunchKernelGGL(probe_soffset, dim3(1), dim3(64), 0, 0, src, 2048u, out, 1536u);
+    hipMemcpy(r.data(), out, 256 * 4, hipMemcpyDeviceToHost);
+    int ok_in = 0, zero_out = 0, data_out = 0;
+    for (int l = 0; l < 64; ++l)
+        for (int i = 0; i < 4; ++i) {
+            const float v = r[4 * l + i], want = float(1536 / 4 + 4 * l + i + 1);
+            if (l < 32) ok_in += v == want;
+            else { zero_out += v == 0.0f; data_out += v == want; }
+        }
+    printf("scalar offset: in-range values right %d / 128; past num_records: zeros %d / 128, memory contents %d / 128 -> the range check %s soffset\n",
+           ok_in, zero_out, data_out, zero_out == 128 ? "INCLUDES" : "does NOT include");
     return (bad_in == 0 && nonzero_oob == 0) ? 0 : 1;
 }
