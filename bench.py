@@ -443,7 +443,7 @@ def roofline_of(prof, n_steps, workload, live=None, chain_gflop=None, pmc=None, 
             by = sum((e['fetch_bytes'] + e['write_bytes']) * e['launches'] for e in a.values()) / n
             busy = [e['mfma_busy'] * e['launches'] for e in a.values() if e.get('mfma_busy') is not None]
             out['attention'] = {
-                'kernel': 'attn16_kernel / attn_kernel (masked softmax attention: scores never leave the CU)',
+                'kernel': 'attn16_kernel / attn_tile_kernel / attn_kernel (masked softmax attention: scores never leave the CU)',
                 'bound': 'mfma', 'hbm_gbs': by / (us * 1e-6) / 1e9, 'hbm_peak_gbs': PEAK_HBM_GBS, 'hbm_frac': by / (us * 1e-6) / 1e9 / PEAK_HBM_GBS,
                 'traffic_bytes_per_launch': by, 'avg_launch_us_under_profiler': us, 'mfma_busy': sum(busy) / n if busy else None,
                 'algorithmic_gbs': attn_prof.get('algorithmic_gbs') if attn_prof else None,

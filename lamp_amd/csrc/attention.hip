@@ -345,16 +345,17 @@ __global__ __launch_bounds__(256, (PM == 0 && MK != LAMP_MASK_KEY_TOKENS_I64) ? 
                         for (int r = 0; r < 16; ++r) o[e][r] *= alpha;
                 }
                 const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
-                // even and odd registers summed apart (two v_pk_add_f32 chains of eight: a vector instruction costs matrix-pipe
-                // time, profiles/r05_mfma_chain.txt), then the two halves of the row: attention_tile.hip sums in the same order
-                f32x2 ps = {0.f, 0.f};
+                // even and odd registers summed apart, then the two halves of the row: the order of attention_tile.hip, which
+                // does it in packed adds (a vector instruction costs matrix-pipe time, profiles/r05_mfma_chain.txt)
+                float pe = 0.f, po = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
                     s[r + 1] = __builtin_amdgcn_exp2f(s[r + 1] - m_use);
-                    ps += f32x2{s[r], s[r + 1]};
+                    pe += s[r];
+                    po += s[r + 1];
                 }
-                float psum = ps[0] + ps[1];
+                float psum = pe + po;
                 psum += xor32(psum);
                 l_run += psum;
 #ifdef ATTN_K_AFTER_PV0

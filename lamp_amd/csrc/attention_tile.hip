@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
     static_assert(MK == LAMP_MASK_NONE || MK == LAMP_MASK_BITS_U32, "the plan's masks");
     constexpr int DKC = 16, DVB = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef TILE_TRACE
+    const unsigned long long t_entry = wall_clock64();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int nqb = (p.lq + 127) / 128;
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
         t[0] = t_c0; t[1] = __builtin_readcyclecounter(); t[2] = t_w0; t[3] = wall_clock64(); t[4] = unsigned(n_act);
         t[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: bits 8-11 CU, 12 SH, 13-15 SE (placement)
         t[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // XCC_ID
+        t[7] = t_entry;
         unsigned long long* u = p.trace + size_t(gridDim.x) * (8 + 256) + size_t(blockIdx.x) * 4;
         u[0] = ph[0]; u[1] = ph[1] - ph[0]; u[2] = ph[2]; u[3] = ph[3];
     }
@@ -358,7 +362,11 @@ __global__ __launch_bounds__(256, 2) void attn_tile_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) o[e][r] *= inv_l;
 
     // ---- store: lane (query, hi), register r, block e  <->  O[query][4 * key(r, hi) + e] ----
+#if defined(TILE_ABL) && (TILE_ABL & 8)   // 8 = no output stores
+    if (wave_active && qi < p.lq && item == 0x7fffffff) {
+#else
     if (wave_active && qi < p.lq) {
+#endif
         float* Orow = p.O + int64_t(b) * p.lay.o_b + int64_t(h) * p.lay.o_h + int64_t(qi) * p.lay.o_r;
         const bool vec = ((p.lay.o_b | p.lay.o_h | p.lay.o_r) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.O) & 15u) == 0;
 #pragma unroll

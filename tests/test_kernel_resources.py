@@ -10,6 +10,7 @@ own resource report and in the ISA:
   * tools/check_untracked_loads.py finds no instruction that touches the destination of an inline-assembly load before a wait.
 """
 import os
+import re
 import sys
 
 import pytest
@@ -23,11 +24,11 @@ import check_untracked_loads as CUL  # noqa: E402
 
 # kernels allowed to spill: (translation unit, name) -> max bytes per lane.  Neither uses inline-assembly loads.
 KNOWN_SCRATCH = {
-    ('attention.hip', 'lamp::attn_kernel<128, 1, 0, 1>'): 16,        # u8-mask variant of the large attention (cold path: the forward
-                                                                     # hands the label graph over bit-packed)
+    ('attention.hip', 'lamp::attn_kernel<128, 1, 0, 1>'): 16,        # u8-mask variants of the large attention (cold path: the forward
+    ('attention.hip', 'lamp::attn_kernel<128, 2, 0, 1>'): 16,        # hands the label graph over bit-packed)
     ('backward.hip', 'lamp::layernorm_bwd_kernel<16, true, 3>'): 160,  # training only
 }
-FORWARD_UNITS = ['gemm.hip', 'chain.hip', 'attention.hip', 'attention_small.hip', 'attention_general.hip', 'pointwise.hip']
+FORWARD_UNITS = ['gemm.hip', 'chain.hip', 'attention.hip', 'attention_tile.hip', 'attention_small.hip', 'attention_general.hip', 'pointwise.hip']
 
 
 @pytest.mark.parametrize('tuning', [False, True])
@@ -44,9 +45,11 @@ def test_no_kernel_spills_and_the_chain_uses_no_agprs(tuning):
             if tuning and 'gemm_pair_kernel' in name:
                 allowed = 80   # the rejected counter-chained FFN pair (profiles/r04_rejected_experiments.txt #11): tuning build only
             assert r.get('scratch', 0) <= allowed, (unit, name, r)
-            if ('chain' in name or 'slab' in name) and 'kernel' in name:
+            if ('chain' in name or 'slab' in name or 'attn_tile' in name) and 'kernel' in name:
                 # the W stream's registers must stay where the in-flight loads will write them
                 assert r.get('agpr', 0) == 0 and r.get('scratch', 0) == 0, (name, r)
+            if 'attn_tile_kernel' in name:   # two workgroups per CU: the partner hides barrier and LDS latencies
+                assert r.get('occupancy', 0) >= 2 and r.get('vgpr', 999) <= 256, (name, r)
     assert seen > 100
     # the production chain kernels exist in the product build (what lamp_forward launches at batch 32)
     prod = B.kernel_resources('chain.hip', False)
@@ -100,11 +103,41 @@ _ZN4lamp16slab_gemm_kernelILi10EEEvNS_10SlabParamsE:
     assert len(CUL.check(bad.replace('v_readlane_b32 s8, v209, 5', 'v_readfirstlane_b32 s18, v86'))[2]) == 1   # a descriptor word
 
 
-@pytest.mark.parametrize('unit,flags,n_kernels', [('chain.hip', (), 12), ('chain.hip', ('-DLAMP_TUNING',), 12), ('slab.hip', ('-DLAMP_TUNING',), 1)])
-def test_no_instruction_touches_an_inline_assembly_load_before_a_wait(unit, flags, n_kernels):
+@pytest.mark.parametrize('unit,flags,n_kernels,n_loads', [('chain.hip', (), 12, 500), ('chain.hip', ('-DLAMP_TUNING',), 12, 500),
+                                                          ('slab.hip', ('-DLAMP_TUNING',), 1, 500), ('attention_tile.hip', (), 2, 3)])
+def test_no_instruction_touches_an_inline_assembly_load_before_a_wait(unit, flags, n_kernels, n_loads):
     """... nor does one overwrite a register in flight, nor does an inline-assembly memory instruction read a scalar the vector
     unit wrote fewer than five wait states earlier (tools/check_untracked_loads.py: the three rules)."""
     asm = CUL.device_asm(os.path.join(ROOT, 'lamp_amd', 'csrc', unit), flags)
-    kernels, loads, findings = CUL.check(asm)
-    assert kernels >= n_kernels and loads > 500
+    kernels, loads, findings = CUL.check(asm, ('chain', 'slab', 'attn_tile'))
+    assert kernels >= n_kernels and loads > n_loads
     assert findings == [], findings[:5]
+
+
+def test_checker_reads_the_half_selects_of_packed_instructions():
+    """`v_pk_mul_f32 v[14:15], v[92:93], v[14:15] op_sel_hi:[0,1]` broadcasts v92: it does not read v93 (where hipcc likes to
+    keep an in-flight mask word); with the default selects it does."""
+    tmpl = '''_ZN4lamp12_GLOBAL__N_116attn_tile_kernelILi3EEEvNS_10AttnParamsE:
+	;;#ASMSTART
+	buffer_load_dword v93, v64, s[12:15], 0 offen
+	;;#ASMEND
+	v_pk_mul_f32 v[14:15], v[92:93], v[14:15]%s
+	s_waitcnt vmcnt(0)
+	s_endpgm
+'''
+    assert CUL.check(tmpl % ' op_sel_hi:[0,1]', ('attn_tile',))[2] == []
+    assert len(CUL.check(tmpl % '', ('attn_tile',))[2]) == 1
+
+
+def test_the_tile_attention_kernel_owns_m0():
+    """attention_tile.hip sets m0 (the LDS address of an LDS-DMA request) inside inline assembly without declaring the clobber
+    (hipcc rejects m0 in a clobber list as reserved): sound as long as nothing else in the kernel uses m0 -- every mention of
+    it in the ISA must be an `s_mov_b32 m0` of ours, followed by s_nop and the buffer_load ... lds it belongs to."""
+    asm = CUL.device_asm(os.path.join(ROOT, 'lamp_amd', 'csrc', 'attention_tile.hip'))
+    lines = [l.strip() for l in asm.split('\n')]
+    uses = [i for i, l in enumerate(lines) if re.search(r'\bm0\b', l) and not l.startswith(';')]
+    assert len(uses) > 20
+    for i in uses:
+        assert lines[i].startswith('s_mov_b32 m0, s'), lines[i]
+        assert lines[i + 1].startswith('s_nop') and lines[i + 2].startswith('buffer_load_dwordx4') and lines[i + 2].endswith('lds'), lines[i:i + 3]
+    assert sum(l.endswith(' lds') and l.startswith('buffer_load') for l in lines) == len(uses)

@@ -569,13 +569,14 @@ def attn_tile(rounds=7):
             print('   loop duration us  p5 %.0f p25 %.0f p50 %.0f p75 %.0f p95 %.0f max %.0f | start us p25 %.0f p50 %.0f p75 %.0f max %.0f | '
                   'end us p50 %.0f p95 %.0f max %.0f' % (q(dur, .05), q(dur, .25), q(dur, .5), q(dur, .75), q(dur, .95), dur.max().item(),
                                                          q(st, .25), q(st, .5), q(st, .75), st.max().item(), q(en, .5), q(en, .95), en.max().item()))
+            print('   kernel entry -> first request of the first tile: median %.1f us' % statistics.median(((t[:, 2] - t[:, 7]) / 100.0).tolist()))
             cu = ((t[:, 6].long() & 15) << 8) | ((t[:, 5].long() >> 8) & 0xff)      # XCC, SE / SH / CU
             ids = cu.unique()
             busy = torch.tensor([dur[cu == i].sum().item() for i in ids])
             cnt = torch.tensor([(cu == i).sum().item() for i in ids])
             for i in ids[:3].tolist() + ids[-2:].tolist():
                 sel = (cu == i).nonzero().flatten().tolist()
-                print('   CU %03x: ' % i + '  '.join('[%4.0f, %4.0f]' % (st[j].item(), en[j].item()) for j in sorted(sel, key=lambda j: st[j].item())))
+                print('   CU %03x (entry | loop start, end): ' % i + '  '.join('[%4.0f | %4.0f, %4.0f]' % ((t[j, 7] - t0).item() / 100.0, st[j].item(), en[j].item()) for j in sorted(sel, key=lambda j: st[j].item())))
             # tile steps of the workgroups of one CU: us per 16 tiles along each workgroup's life (2 x 8192 MFMA cycles per SIMD and
             # pair of tiles = 6.86 us at 2.39 GHz when two workgroups share the CU, 3.43 us per tile for one alone)
             nt_ = min((lk + 31) // 32, 256)

@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 B=$ROOT/lamp_amd/build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden -Wno-unused-result -DLAMP_TUNING ${EXTRA:-}"
 OBJS=""
-for u in gemm gemm_gen attention attention_small attention_general pointwise backward chain slab api; do
+for u in gemm gemm_gen attention attention_tile attention_small attention_general pointwise backward chain slab api; do
   o=$B/$u.tuning.o; [ -f $o ] || o=$B/$u.o
   for v in "$@"; do
     if [ "$v" = "$u.hip" ]; then o=$B/$u.tuning.$NAME.o; /opt/rocm/bin/hipcc $FLAGS -c $ROOT/lamp_amd/csrc/$u.hip -o $o & fi
