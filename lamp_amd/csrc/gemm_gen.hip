@@ -73,6 +73,20 @@ __device__ __forceinline__ float4 stage_load(__amdgpu_buffer_rsrc_t rs, int tid,
     }
 }
 
+// The same load with NOTHING recomputed per k-tile: this thread's byte offset inside the operand's first k-tile is a loop
+// invariant (OOB for the threads without a share of a 32-row operand), the k-tile's base rides in the instruction's SCALAR offset
+// -- the descriptor's range check covers voffset + soffset (tools/probes/lds_dma_oob.hip).  The per-tile offset arithmetic and
+// bound selects of stage_load() were 36-66 vector instructions per two k-tiles, i.e. +17...+63 % on the MFMAs' time: on gfx950
+// a vector instruction is not hidden under fp32 MFMAs (profiles/r05_mfma_chain.txt).  Valid for 16-byte-aligned operands; a row
+// operand's LAST, partial k-tile still takes stage_load() (its k bound is not the descriptor's).
+template <bool COL, int ROWS>
+__device__ __forceinline__ unsigned stage_voff(int tid, int64_t ld) {
+    if (ROWS < 64 && tid >= ROWS * 4) return OOB;
+    if constexpr (!COL) return unsigned((tid >> 2) * int(ld) + 4 * (tid & 3)) * 4u;
+    constexpr int V4 = ROWS / 4;
+    return unsigned((tid / V4) * int(ld) + 4 * (tid % V4)) * 4u;
+}
+
 template <bool COL, int ROWS>
 __device__ __forceinline__ void stage_store(float* lds, int tid, float4 v) {
     if (ROWS < 64 && tid >= ROWS * 4) return;
@@ -96,7 +110,9 @@ __device__ __forceinline__ float4 frag(const float* lds, int row, int hi) {
     return v;
 }
 
-template <int GM, int GN, int WM, int WN, bool TA, bool TB>
+// FAST: both operands 16-byte loadable and every k-tile of every split whole (K a multiple of 16) -- the host's choice; the
+// loads then carry no per-tile vector arithmetic (stage_voff).
+template <int GM, int GN, int WM, int WN, bool TA, bool TB, bool FAST>
 __global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int WTM = GM / WM, WTN = GN / WN, MI = WTM / 16, NI = WTN / 16;
@@ -133,9 +149,17 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n)
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (k_end - k_begin + GK - 1) / GK;
+    const unsigned voffA = stage_voff<TA, GM>(tid, lda), voffB = stage_voff<TB, GN>(tid, ldb);
+    const unsigned kstepA = TA ? unsigned(lda) * 4u : 4u, kstepB = TB ? unsigned(ldb) * 4u : 4u;   // bytes per unit of k
     auto gload = [&](int kt, float4& ra, float4& rb) {
-        ra = stage_load<TA, GM>(rsA, tid, k_begin + kt * GK, k_end, lda, p.vecA);
-        rb = stage_load<TB, GN>(rsB, tid, k_begin + kt * GK, k_end, ldb, p.vecB);
+        const int k0 = k_begin + kt * GK;
+        if constexpr (FAST) {
+            ra = bload4(rsA, voffA, unsigned(k0) * kstepA);
+            rb = bload4(rsB, voffB, unsigned(k0) * kstepB);
+        } else {
+            ra = stage_load<TA, GM>(rsA, tid, k0, k_end, lda, p.vecA);
+            rb = stage_load<TB, GN>(rsB, tid, k0, k_end, ldb, p.vecB);
+        }
     };
     auto lstore = [&](int buf, const float4& ra, const float4& rb) {
         stage_store<TA, GM>(As[buf], tid, ra);
@@ -319,21 +343,27 @@ int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStrea
     const double bytes = 4.0 * double(batch) * (double(d.M) * d.K + double(d.N) * d.K + double(d.M) * d.N);
     ProfScope prof(LAMP_K_GEMM, flops, bytes, s);
     const dim3 grid((unsigned)tiles, (unsigned)batch, (unsigned)nsplit);
-#define LAMP_GEN_LAUNCH(GM_, WM_, WN_)                                                                               \
-    do {                                                                                                              \
-        if (ta && tb)                                                                                                 \
-            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, true, true>), grid, dim3(256), 0, s, p, tiles_n);   \
-        else if (ta)                                                                                                  \
-            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, true, false>), grid, dim3(256), 0, s, p, tiles_n);  \
-        else if (tb)                                                                                                  \
-            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, false, true>), grid, dim3(256), 0, s, p, tiles_n);  \
-        else                                                                                                          \
-            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, false, false>), grid, dim3(256), 0, s, p, tiles_n); \
+    // whole k-tiles everywhere (the split size is a multiple of GK, so only K itself can leave a partial one) and 16-byte loads
+    const bool fast = p.vecA && p.vecB && (d.K % GK) == 0;
+#define LAMP_GEN_LAUNCH(GM_, WM_, WN_, FAST_)                                                                               \
+    do {                                                                                                                     \
+        if (ta && tb)                                                                                                        \
+            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, true, true, FAST_>), grid, dim3(256), 0, s, p, tiles_n);   \
+        else if (ta)                                                                                                         \
+            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, true, false, FAST_>), grid, dim3(256), 0, s, p, tiles_n);  \
+        else if (tb)                                                                                                         \
+            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, false, true, FAST_>), grid, dim3(256), 0, s, p, tiles_n);  \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, false, false, FAST_>), grid, dim3(256), 0, s, p, tiles_n); \
     } while (0)
-    if (gm == 32)
-        LAMP_GEN_LAUNCH(32, 1, 4);
+    if (gm == 32 && fast)
+        LAMP_GEN_LAUNCH(32, 1, 4, true);
+    else if (gm == 32)
+        LAMP_GEN_LAUNCH(32, 1, 4, false);
+    else if (fast)
+        LAMP_GEN_LAUNCH(64, 2, 2, true);
     else
-        LAMP_GEN_LAUNCH(64, 2, 2);
+        LAMP_GEN_LAUNCH(64, 2, 2, false);
 #undef LAMP_GEN_LAUNCH
     if (int e = int(hipGetLastError())) return e;
     if (p.part) {
