@@ -163,13 +163,14 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     float vf[4][DV8];      // V[kt*16 + 4g + r][.]: block e of O^T holds the d_v columns given at load_v below
     unsigned mbits = 0;    // bit r = key (kt*16 + 4g + r) is blocked for this lane's query (one tile ahead)
 
+    // Loads of the key loop carry NO per-tile vector arithmetic (a vector instruction costs matrix-pipe time on gfx950,
+    // profiles/r05_mfma_chain.txt): the lane's offset inside a tile is a loop invariant with the head-dimension check folded in
+    // (OOB + anything < 2^31 stays out of range), the tile's / row's base rides in the SCALAR offset, which the descriptor's
+    // range check covers (tools/probes/lds_dma_oob.hip) -- rows past the sample's last key read as zeros without a test.
+    const unsigned k_voff = (lane % C4K) * 4 < p.dk ? unsigned((lane / C4K) * k_r + (lane % C4K) * 4) * 4u : OOB;
     auto load_k = [&](int kt) {
-        const int c = (lane % C4K) * 4;
 #pragma unroll
-        for (int i = 0; i < DKC; ++i) {
-            const int row = i * RPI + lane / C4K;
-            kg[i] = bload4(rsK, (kt < nt && c < p.dk) ? unsigned((kt * 16 + row) * k_r + c) * 4u : OOB, 0);
-        }
+        for (int i = 0; i < DKC; ++i) kg[i] = bload4(rsK, k_voff, unsigned((kt * 16 + i * RPI) * k_r) * 4u);
     };
     auto stage_k = [&]() {   // registers -> this wave's LDS block (its reads of the previous tile are behind us: in order)
         const int c = (lane % C4K) * 4;
@@ -180,33 +181,33 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     // row and instruction).  d = 128 takes two such loads 64 columns apart: block e of O^T then holds the d_v columns
     // {4 i + e} (e < 4) and {64 + 4 i + e - 4} (e >= 4), i = the block's row index -- see the store at the end.
     constexpr int DVW = DV8 == 8 ? 4 : DV8;
+    // d_v is a multiple of 4: all-or-nothing per load; second half (d = 128 only) 64 columns on
+    const unsigned v_voff = DVW * l15 < p.dv ? unsigned(4 * g * v_r + DVW * l15) * 4u : OOB;
+    const unsigned v_voff2 = 64 + DVW * l15 < p.dv ? unsigned(4 * g * v_r + DVW * l15) * 4u + 256u : OOB;
     auto load_v = [&](int kt) {
-        const bool col_ok = kt < nt && DVW * l15 < p.dv;         // d_v is a multiple of 4: all-or-nothing per load
-        const bool col_ok2 = kt < nt && 64 + DVW * l15 < p.dv;   // second half (d = 128 only)
-        const unsigned base = unsigned((kt * 16 + 4 * g) * v_r + DVW * l15) * 4u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const unsigned off = col_ok ? base + unsigned(r * v_r) * 4u : OOB;
+            const unsigned off = v_voff, so = unsigned((kt * 16 + r) * v_r) * 4u;
             if constexpr (DV8 == 8) {
-                const float4 a = bload4(rsV, off, 0);
-                const float4 c2 = bload4(rsV, col_ok2 ? base + unsigned(r * v_r) * 4u + 256u : OOB, 0);
+                const float4 a = bload4(rsV, off, so);
+                const float4 c2 = bload4(rsV, v_voff2, so);
                 vf[r][0] = a.x; vf[r][1] = a.y; vf[r][2] = a.z; vf[r][3] = a.w;
                 vf[r][4] = c2.x; vf[r][5] = c2.y; vf[r][6] = c2.z; vf[r][7] = c2.w;
             } else if constexpr (DV8 == 4) {
-                const float4 a = bload4(rsV, off, 0);
+                const float4 a = bload4(rsV, off, so);
                 vf[r][0] = a.x; vf[r][1] = a.y; vf[r][2] = a.z; vf[r][3] = a.w;
             } else {
-                const f32x2 a = bload2(rsV, off);
+                const f32x2 a = bload2(rsV, off + so);
                 vf[r][0] = a.x; vf[r][1] = a.y;
             }
         }
     };
+    const unsigned m_voff = unsigned(int64_t(qc) * p.m_sq) * 4u;
     auto load_mask = [&](int kt) {
         const int kbase = kt * 16 + 4 * g;
         if constexpr (MK == LAMP_MASK_BITS_U32) {
-            const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(
-                rsM, kt < nt ? unsigned(int64_t(qc) * p.m_sq + (kt >> 1)) * 4u : OOB, 0, 0);
-            mbits = (w >> ((kt & 1) * 16 + 4 * g)) & 0xFu;
+            // the row's mask word (two tiles per word); the lane group's four bits are taken in scores()
+            mbits = __builtin_amdgcn_raw_buffer_load_b32(rsM, m_voff, unsigned(kt >> 1) * 4u, 0);
         } else if constexpr (MK == LAMP_MASK_U8) {
             const unsigned mo = unsigned(int64_t(qc) * p.m_sq) + unsigned(kbase);
             unsigned m = 0;
@@ -224,7 +225,20 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
     // S^T = K Q^T for the tile in kf (two accumulator chains, summed: the dependent-issue latency of the 16x16x4 MFMA
     // is 40 cycles against 32 of issue), then -inf where blocked / past lk.
     auto scores = [&](int kt, f32x4& s) {
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        // Blocked keys -- the mask's, and those past the sample's last key, OR-ed in as a scalar -- enter as the first chain's
+        // INITIAL value: -inf + anything finite = -inf, 0 + x as before (two instructions per score, none after the product).
+        const int valid = lk_b - kt * 16;
+        const unsigned tail = valid >= 16 ? 0u : (0xffffu << (valid > 0 ? valid : 0)) & 0xffffu;   // scalar
+        unsigned word = tail;
+        if constexpr (MK == LAMP_MASK_BITS_U32) word |= mbits >> ((kt & 1) * 16);
+        const int mine = MK == LAMP_MASK_BITS_U32 || MK == LAMP_MASK_NONE ? int(word >> (4 * g)) : int(mbits | (tail >> (4 * g)));
+        f32x4 s0, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int t;
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t) : "v"(mine), "n"(r));
+            s0[r] = __int_as_float(t & int(0xff800000u));
+        }
 #ifdef LAMP_SETPRIO   // experiment (profiles/r04_setprio.txt): raised wave priority around the QK^T and PV MFMA runs
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -248,13 +262,8 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
 #ifdef LAMP_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
-        const int kbase = kt * 16 + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = s0[r] + s1[r];
-            const bool blk = (MK != LAMP_MASK_NONE && ((mbits >> r) & 1u)) || kbase + r >= lk_b;
-            s[r] = blk ? -INFINITY : v;
-        }
+        for (int r = 0; r < 4; ++r) s[r] = s0[r] + s1[r];
     };
 
     f32x4 o[DV8];
