@@ -301,7 +301,7 @@ def attn():
         force.argtypes = [ctypes.c_int]
         small = lq <= 256
         # 0 = heuristic; bits 0-2 forced key split, bits 4-6 query blocks per workgroup (small-shape kernel)
-        for mode in ((0, 0x14, 0x24, 0x34, 0x12, 0x22, 0x32, 0x42, 0x41) if small else (0, 1, 2, 4, 0xc1, 0x92, 0x94)):
+        for mode in ((0, 0x14, 0x24, 0x34, 0x12, 0x22, 0x32, 0x42, 0x41) if small else (0, 0x100, 1, 2, 4, 0xc1, 0x92, 0x94)):   # 0x100: attn_kernel instead of attention_tile.hip
           bits = N.pack_mask_bits(mask).to(dev)
           toks = (torch.rand(B, lk, device=dev) < 0.9).long()
           masks = (('none', None), ('shared-u8', N.Mask(N.LAMP_MASK_U8, 0, mask.data_ptr(), 0, lk)),

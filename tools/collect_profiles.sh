@@ -32,6 +32,9 @@ python tools/bench_kernels.py chain 2880 17 0,12,17 2>&1 | grep -v amdgpu.ids > 
 for m in 720 1440 2048 2400 2880 3072 3600 4096 4320 5120 5760 6144; do python tools/bench_kernels.py chain $m 0 0,12,15,16,17,19,20 2>&1 | grep "five\|chain launch" | tr "\n" ";" >> "$OUT/chain_rows.txt"; echo " M=$m" >> "$OUT/chain_rows.txt"; done
 python tools/bench_kernels.py slab 2>&1 | grep -v amdgpu.ids > "$OUT/slab.txt"
 tools/probes/mfma_korder > "$OUT/mfma_korder.txt" 2>&1
+tools/probes/mfma_chain > "$OUT/mfma_chain_raw.txt" 2>&1
+tools/probes/lds_dma_oob > "$OUT/lds_dma_oob.txt" 2>&1
+python tools/bench_kernels.py attn_tile 2>&1 | grep -v amdgpu.ids > "$OUT/attn_tile.txt"
 python tools/batch_sweep.py > "$OUT/batch_sweep.txt" 2>/dev/null
 tools/probes/mfma_issue 20 > "$OUT/mfma_issue.txt" 2>&1
 LAMP_BENCH_BACKEND=gloo python bench.py --gpus 8 --steps 20 --warmup 5 --no-pipelined > "$OUT/bench_eight_ranks_one_gpu_gloo.json" 2>/dev/null
