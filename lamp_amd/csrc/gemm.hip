@@ -580,36 +580,54 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
 
     const __amdgpu_buffer_rsrc_t rsC =
         make_rsrc(p.C[seg] + m0 * p.ldc + n0, (uint64_t(rows_m - 1) * ldc + rows_n) * 4u);
-#pragma unroll
-    for (int i = 0; i < T::MI; ++i) {
-        const int lrow = lrow0 + i * MF;
-#pragma unroll
-        for (int j = 0; j < T::NI; ++j)   // the blocks of one row back to back: adjacent 64-byte pieces of its lines
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int lcol = lcol0 + j * MF + 8 * q;
-                float4 bv, res = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (RPRE) {
-                    bv = pre_b[j * NQ + q];
-                    res = pre_r[(j * T::MI + i) * NQ + q];
-                } else {
-                    bv = load4(rsBias, unsigned(lcol), lcol);
-                    if (has_r) res = load4(rsR, unsigned(lrow * ldr + lcol), lcol);
+    // The epilogue in four straight-line copies (residual or not, ReLU or not), chosen by two scalar branches: as selects on the
+    // two flags it carried 16 v_cndmask and 16 canonicalising v_max per tile and wave, and a vector instruction is matrix-pipe
+    // time on gfx950 (profiles/r05_mfma_chain.txt).  relu1: one v_max_f32 (fmaxf() quiets its operand with a second one first).
+    auto relu1 = [](float x) {
+        float y;
+        asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+        return y;
+    };
+    auto emit = [&](auto with_r, auto with_relu) {
+        constexpr bool WITH_R = decltype(with_r)::value, WITH_RELU = decltype(with_relu)::value;
+    #pragma unroll
+        for (int i = 0; i < T::MI; ++i) {
+            const int lrow = lrow0 + i * MF;
+    #pragma unroll
+            for (int j = 0; j < T::NI; ++j)   // the blocks of one row back to back: adjacent 64-byte pieces of its lines
+    #pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int lcol = lcol0 + j * MF + 8 * q;
+                    float4 bv, res = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (RPRE) {
+                        bv = pre_b[j * NQ + q];
+                        res = pre_r[(j * T::MI + i) * NQ + q];
+                    } else {
+                        bv = load4(rsBias, unsigned(lcol), lcol);
+                        if constexpr (WITH_R) res = load4(rsR, unsigned(lrow * ldr + lcol), lcol);
+                    }
+                    float4 v = make_float4(acc[i][j][4 * q + 0] + bv.x, acc[i][j][4 * q + 1] + bv.y,
+                                           acc[i][j][4 * q + 2] + bv.z, acc[i][j][4 * q + 3] + bv.w);
+                    if constexpr (WITH_RELU) v = make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w));
+                    if constexpr (WITH_R) v = make_float4(v.x + res.x, v.y + res.y, v.z + res.z, v.w + res.w);
+                    const unsigned off = unsigned(lrow * ldc + lcol);
+                    if constexpr (vec) {
+                        bstore4(rsC, lcol < rows_n ? off * 4u : OOB, v);
+                    } else {
+                        bstore1(rsC, lcol + 0 < rows_n ? (off + 0) * 4u : OOB, v.x);
+                        bstore1(rsC, lcol + 1 < rows_n ? (off + 1) * 4u : OOB, v.y);
+                        bstore1(rsC, lcol + 2 < rows_n ? (off + 2) * 4u : OOB, v.z);
+                        bstore1(rsC, lcol + 3 < rows_n ? (off + 3) * 4u : OOB, v.w);
+                    }
                 }
-                float4 v = make_float4(acc[i][j][4 * q + 0] + bv.x, acc[i][j][4 * q + 1] + bv.y,
-                                       acc[i][j][4 * q + 2] + bv.z, acc[i][j][4 * q + 3] + bv.w);
-                if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                if (has_r) v = make_float4(v.x + res.x, v.y + res.y, v.z + res.z, v.w + res.w);
-                const unsigned off = unsigned(lrow * ldc + lcol);
-                if constexpr (vec) {
-                    bstore4(rsC, lcol < rows_n ? off * 4u : OOB, v);
-                } else {
-                    bstore1(rsC, lcol + 0 < rows_n ? (off + 0) * 4u : OOB, v.x);
-                    bstore1(rsC, lcol + 1 < rows_n ? (off + 1) * 4u : OOB, v.y);
-                    bstore1(rsC, lcol + 2 < rows_n ? (off + 2) * 4u : OOB, v.z);
-                    bstore1(rsC, lcol + 3 < rows_n ? (off + 3) * 4u : OOB, v.w);
-                }
-            }
+        }
+    };
+    if (has_r) {
+        if (p.relu) emit(std::true_type{}, std::true_type{});
+        else emit(std::true_type{}, std::false_type{});
+    } else {
+        if (p.relu) emit(std::false_type{}, std::true_type{});
+        else emit(std::false_type{}, std::false_type{});
     }
 #ifdef LAMP_TUNING
     if (p.trace && tid == 0) {

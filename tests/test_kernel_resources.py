@@ -21,6 +21,7 @@ from lamp_amd import build as B
 
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import check_untracked_loads as CUL  # noqa: E402
+import count_loop_valu as CLV  # noqa: E402
 
 # kernels allowed to spill: (translation unit, name) -> max bytes per lane.  Neither uses inline-assembly loads.
 KNOWN_SCRATCH = {
@@ -141,3 +142,46 @@ def test_the_tile_attention_kernel_owns_m0():
         assert lines[i].startswith('s_mov_b32 m0, s'), lines[i]
         assert lines[i + 1].startswith('s_nop') and lines[i + 2].startswith('buffer_load_dwordx4') and lines[i + 2].endswith('lds'), lines[i:i + 3]
     assert sum(l.endswith(' lds') and l.startswith('buffer_load') for l in lines) == len(uses)
+
+
+# ---- vector instructions in the MFMA loops: matrix-pipe time on gfx950 (profiles/r05_mfma_chain.txt) ----
+def _loops(unit, want, flags=()):
+    asm = CLV.device_asm(os.path.join(ROOT, 'lamp_amd', 'csrc', unit), flags)
+    found = {n: CLV.mfma_loops(l) for n, l in CLV.kernels(asm).items() if want in n}
+    assert found, (unit, want)
+    return asm, found
+
+
+def test_gemm_main_loops_carry_no_vector_instructions():
+    """Forward tile GEMMs (LDS staging through registers / LDS-DMA: offsets advance in scalar registers) and the general GEMM's
+    FAST instantiations (loop-invariant per-lane offsets, the k-tile's base in the scalar offset): the innermost loop of every
+    product-path instantiation holds MFMAs, LDS / memory instructions and scalar bookkeeping only.  (Before round 5 gemm_gen
+    carried 36-66 vector instructions per two k-tiles: +17...+63 % on the MFMAs' time.)"""
+    _, gen = _loops('gemm_gen.hip', 'gemm_gen_kernel<')
+    fast = {n: l for n, l in gen.items() if n.split('>')[0].endswith('true')}
+    assert len(fast) == 8
+    for name, loops in fast.items():
+        inner = loops[0][2]
+        assert inner['valu'] + inner['trans'] <= 6, (name, dict(inner))     # one instantiation keeps a 6-instruction waterfall
+    assert sum(l[0][2]['valu'] == 0 for l in fast.values()) >= 7
+    _, nt = _loops('gemm.hip', 'gemm_nt_kernel<')
+    for name, loops in nt.items():
+        if ', 16, 2, 2, false, ' in name:   # the 16-deep tiles of the forward (64x64x16, 128x64x16), K a multiple of the tile depth
+            assert loops[0][2]['valu'] == 0 and loops[0][2]['mfma'] >= 16, (name, dict(loops[0][2]))
+
+
+def test_attention_key_loops_stay_within_their_vector_instruction_budget():
+    """attention_tile.hip: two tile steps per loop trip, 256 MFMAs; the executed path carries ~79 vector instructions + 16 v_exp
+    per tile with the bit mask (the static count below also holds the rescale branch's 32 v_pk_mul per step).  attn16_kernel:
+    <= 40 per 64-MFMA tile (91 before round 5)."""
+    _, tile = _loops('attention_tile.hip', 'attn_tile_kernel<')
+    for name, loops in tile.items():
+        main = [c for a, b, c in loops if c['mfma'] in (256, 384)]   # without a mask: the unbiased QK^T and the last tile's biased one
+        assert main, name
+        c = min(main, key=lambda c: c['valu'])
+        assert c['valu'] - c['v_pk_mul_f32'] <= 180 and c['trans'] <= 36, (name, dict(c))
+        assert c['v_cndmask_b32_e32'] + c['v_cndmask_b32_e64'] <= 8, (name, dict(c))    # the mask is NOT applied by selects
+    _, small = _loops('attention_small.hip', 'attn16_kernel<128, 1, 4, 0, 3>')
+    for name, loops in small.items():
+        c = [c for a, b, c in loops if c['mfma'] == 64][0]
+        assert c['valu'] + c['trans'] <= 40, (name, dict(c))
