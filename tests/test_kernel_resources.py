@@ -44,7 +44,7 @@ def test_no_kernel_spills_and_the_chain_uses_no_agprs(tuning):
             seen += 1
             allowed = KNOWN_SCRATCH.get((unit, name), 0)
             if tuning and 'gemm_pair_kernel' in name:
-                allowed = 80   # the rejected counter-chained FFN pair (profiles/r04_rejected_experiments.txt #11): tuning build only
+                allowed = 96   # (84 since the straight-line epilogue) the rejected counter-chained FFN pair (profiles/r04_rejected_experiments.txt #11): tuning build only
             assert r.get('scratch', 0) <= allowed, (unit, name, r)
             if ('chain' in name or 'slab' in name or 'attn_tile' in name) and 'kernel' in name:
                 # the W stream's registers must stay where the in-flight loads will write them
