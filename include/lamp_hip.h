@@ -39,7 +39,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define LAMP_HIP_ABI_VERSION 3
+#define LAMP_HIP_ABI_VERSION 4   /* 4: + lamp_gemm_grouped, lamp_{ffn,mha}_train_fwd / _bwd (additive) */
 
 typedef void* lamp_stream_t; /* hipStream_t */
 
@@ -302,6 +302,81 @@ typedef struct lamp_gemm_desc {
 } lamp_gemm_desc;
 size_t lamp_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t batch);
 int lamp_gemm(const lamp_gemm_desc* d, void* workspace, size_t workspace_bytes, lamp_stream_t stream);
+
+/* n independent lamp_gemm products in ONE launch (descs: host array; batch0 = batch1 = 1, relu_mask NULL, the same operand
+ * form -- which of A / B is k-contiguous -- in all of them, distinct C).  No K split, no workspace: every 64 x 64 output
+ * tile accumulates k in ascending order, so the results are those of lamp_gemm without workspace, whatever the grouping.
+ * Meant for the weight gradients of a whole backward pass (train.py:40 `loss.backward()`: dW = dY^T.X of every nn.Linear /
+ * Conv1d(k=1) on the path, lamp/SubLayers.py:60-64,129-130), which are off the critical path of the data gradients and fill
+ * the chip together where each alone would need a K split.  Order descs deepest K first. */
+int lamp_gemm_grouped(const lamp_gemm_desc* descs, int32_t n, lamp_stream_t stream);
+
+/* ---- training-mode sub-layers, ONE call each ------------------------------------------------------------------
+ * The launches that lamp_amd/training.py's autograd functions would issue one Python round trip at a time (a reuters
+ * training step is ~190 launches and was bound by the issuing thread, not the device), issued by the library.  Same
+ * kernels, same order, same bits as the per-launch route.  All buffers are the caller's ([rows, cols] row-major, fp32):
+ * "saved" ones must live until the matching backward call, gradients of weights may be NULL = the caller computes them
+ * later from the buffers this call leaves behind (lamp_gemm_grouped). */
+
+/* Second stage of a column reduction (LayerNorm-parameter and bias gradients): out[c] = sum over n_partials rows of
+ * partial[p * n_total + c], c < n_total, in a fixed order; columns [i * n_seg, (i + 1) * n_seg) go to out[i] (n_total <= 3 n_seg).
+ * lamp_ffn_bwd / lamp_mha_bwd describe theirs in such jobs instead of launching them when given a `partials` buffer, so that
+ * ONE lamp_reduce_partials_grouped launch can run the jobs of a whole backward pass: 17 tiny dependent launches per reuters
+ * step become one.  A job's partials and outputs are the caller's buffers and must stay live until that launch. */
+typedef struct lamp_reduce_job {
+    const float* partial;
+    int64_t n_total, n_seg;
+    float* out[3];
+    int32_t n_partials;
+    int32_t reserved;
+} lamp_reduce_job;
+int lamp_reduce_partials_grouped(const lamp_reduce_job* jobs, int32_t n, lamp_stream_t stream);
+
+/* PositionwiseFeedForward.forward in train() mode (lamp/SubLayers.py:133-142):
+ *   h = relu(x W1^T + b1) [M, d_inner] (saved), o = h W2^T + b2 [M, d_model] (saved), y = LayerNorm(dropout(o) + x). */
+int lamp_ffn_train_fwd(const float* x, int64_t M, int32_t d_model, int32_t d_inner, const lamp_ffn_weights* w,
+                       float dropout_p, uint32_t seed, float* h, float* o, float* y, lamp_stream_t stream);
+/* Its backward.  dx [M, d_model] = gradient of x; d_o [M, d_model] = gradient of o (required iff dropout_p > 0; without
+ * dropout it IS dx before the last accumulation, and dW2 must then be requested here); dh [M, d_inner] = gradient of the
+ * pre-ReLU hidden; dW1 [d_inner, d_model] = dh^T x and dW2 [d_model, d_inner] = d_o^T h nullable (deferred);
+ * db1 [d_inner], db2, dgamma, dbeta [d_model].
+ * partials (nullable, lamp_ffn_bwd_partials_bytes): when given, db1 / db2 / dgamma / dbeta are NOT final on return -- jobs[0..1]
+ * describe the two reductions that finish them (see lamp_reduce_job). */
+size_t lamp_ffn_bwd_workspace_bytes(int64_t M, int32_t d_model, int32_t d_inner);
+size_t lamp_ffn_bwd_partials_bytes(int64_t M, int32_t d_model, int32_t d_inner);
+int lamp_ffn_bwd(const float* x, const float* h, const float* o, const float* dy, int64_t M, int32_t d_model,
+                 int32_t d_inner, const lamp_ffn_weights* w, float dropout_p, uint32_t seed, float* dx, float* d_o, float* dh,
+                 float* dW1, float* dW2, float* db1, float* db2, float* dgamma, float* dbeta, void* workspace,
+                 size_t workspace_bytes, void* partials, size_t partials_bytes, lamp_reduce_job* jobs, lamp_stream_t stream);
+
+typedef struct lamp_mha_train_desc {
+    int32_t B, lq, lk, d_model, n_head, d_k, d_v;   /* d_k, d_v <= 128 */
+    float inv_temperature;                          /* 1 / sqrt(d_k) (lamp/SubLayers.py:62) */
+    float p_attn, p_out;                            /* dropout of the probabilities (SubLayers.py:40) and of the output (:113) */
+    uint32_t seed_attn, seed_out;
+} lamp_mha_train_desc;
+/* MultiHeadAttention.forward in train() mode (lamp/SubLayers.py:77-121) on xq [B, lq, d_model], xk / xv [B, lk, d_model]
+ * (the same pointer for both in every layer of the reference).  Saved: q [B, lq, H*d_k], k, v [B, lk, H*d_*], a [B, lq, H*d_v]
+ * (concatenated head outputs, computed from the DROPPED probabilities), P [H*B, lq, lk] (softmax, index head * B + b),
+ * o [B*lq, d_model] (fc output; unused when w->fc is NULL).  Pd [H*B, lq, lk] = dropout(P), required iff p_attn > 0 -- what
+ * the reference returns as the attention map.  lse: H*B*lq floats of scratch.  y = LayerNorm(dropout(o) + xq). */
+int lamp_mha_train_fwd(const lamp_mha_train_desc* c, const lamp_mha_weights* w, const float* xq, const float* xk,
+                       const float* xv, const lamp_mask* mask, float* q, float* k, float* v, float* a, float* P, float* Pd,
+                       float* lse, float* o, float* y, lamp_stream_t stream);
+/* Its backward.  Outputs: dxq [B*lq, d_model]; dxk [B*lk, d_model] (+ the value branch when dxv is NULL, else dxv gets it);
+ * dgamma, dbeta.  Left behind for deferred weight gradients: d_o [B*lq, d_model] (required iff p_out > 0), dq [B*lq, H*d_k],
+ * dk [B*lk, H*d_k], dv [B*lk, H*d_v]; dwq / dwk / dwv [H*d_*, d_model], dfc [d_model, H*d_v] nullable (dfc required when
+ * w->fc is set and p_out == 0).  Pd: the forward's dropout(P) (saved; required iff p_attn > 0).  Scratch: da [B*lq, H*d_v]
+ * (iff w->fc), dP [H*B, lq, lk].  partials (nullable, lamp_mha_bwd_partials_bytes): when given, dgamma / dbeta are NOT final on
+ * return -- job[0] describes the reduction that finishes them (see lamp_reduce_job). */
+size_t lamp_mha_bwd_workspace_bytes(const lamp_mha_train_desc* c);
+size_t lamp_mha_bwd_partials_bytes(const lamp_mha_train_desc* c);
+int lamp_mha_bwd(const lamp_mha_train_desc* c, const lamp_mha_weights* w, const float* xq, const float* xk, const float* xv,
+                 const float* q, const float* k, const float* v, const float* a, const float* P, const float* Pd,
+                 const float* o, const float* dy, float* dxq, float* d_o, float* da, float* dP, float* dq, float* dk, float* dv,
+                 float* dxk, float* dxv, float* dgamma, float* dbeta, float* dwq, float* dwk, float* dwv, float* dfc,
+                 void* workspace, size_t workspace_bytes, void* partials, size_t partials_bytes, lamp_reduce_job* job,
+                 lamp_stream_t stream);
 
 /* y = LayerNorm(dropout(x) + residual[row % residual_rows]) (residual nullable; residual_rows 0 = one residual row
  * per x row): the dropout, add & norm that closes every sub-layer (lamp/SubLayers.py:113-115,138-140), with neither

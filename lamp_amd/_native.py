@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LAMP_HIP_LIBRARY') or os.path.join(_HERE, 'liblamp_hip.so')
 TUNING_LIB_PATH = os.path.join(_HERE, 'liblamp_hip_tuning.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 LAMP_MASK_NONE, LAMP_MASK_U8, LAMP_MASK_KEY_TOKENS_I64, LAMP_MASK_BITS_U32 = 0, 1, 2, 3
 K_EMBED, K_GEMM, K_ATTN, K_LAYERNORM, K_DIAG, K_COUNT = 0, 1, 2, 3, 4, 5
 KERNEL_CLASS_NAMES = ('embed', 'gemm', 'attention', 'layernorm', 'diag_readout')
@@ -83,6 +83,17 @@ class GemmDesc(C.Structure):  # include/lamp_hip.h: lamp_gemm_desc
                 ('relu_mask', _vp), ('ld_mask', C.c_int64), ('alpha', C.c_float), ('reserved', C.c_int32)]
 
 
+class ReduceJob(C.Structure):  # include/lamp_hip.h: lamp_reduce_job
+    _fields_ = [('partial', _vp), ('n_total', C.c_int64), ('n_seg', C.c_int64), ('out', _vp * 3),
+                ('n_partials', C.c_int32), ('reserved', C.c_int32)]
+
+
+class MhaTrainDesc(C.Structure):  # include/lamp_hip.h: lamp_mha_train_desc
+    _fields_ = [('B', C.c_int32), ('lq', C.c_int32), ('lk', C.c_int32), ('d_model', C.c_int32), ('n_head', C.c_int32),
+                ('d_k', C.c_int32), ('d_v', C.c_int32), ('inv_temperature', C.c_float), ('p_attn', C.c_float),
+                ('p_out', C.c_float), ('seed_attn', C.c_uint32), ('seed_out', C.c_uint32)]
+
+
 class Aux(C.Structure):
     _fields_ = [('enc_self_attn', C.POINTER(_vp)), ('dec_self_attn', C.POINTER(_vp)),
                 ('dec_enc_attn', C.POINTER(_vp)), ('int_preds', C.POINTER(_vp)),
@@ -110,6 +121,19 @@ PROTOTYPES = {
     'lamp_pack_weight': (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp]),
     'lamp_gemm_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'lamp_gemm': (C.c_int, [C.POINTER(GemmDesc), _vp, _sz, _vp]),
+    'lamp_gemm_grouped': (C.c_int, [C.POINTER(GemmDesc), _i32, _vp]),
+    'lamp_ffn_train_fwd': (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(FfnWeights), _f, C.c_uint32, _vp, _vp, _vp, _vp]),
+    'lamp_reduce_partials_grouped': (C.c_int, [C.POINTER(ReduceJob), _i32, _vp]),
+    'lamp_ffn_bwd_workspace_bytes': (_sz, [_i64, _i32, _i32]),
+    'lamp_ffn_bwd_partials_bytes': (_sz, [_i64, _i32, _i32]),
+    'lamp_ffn_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, C.POINTER(FfnWeights), _f, C.c_uint32] + [_vp] * 9 +
+                     [_vp, _sz, _vp, _sz, C.POINTER(ReduceJob), _vp]),
+    'lamp_mha_train_fwd': (C.c_int, [C.POINTER(MhaTrainDesc), C.POINTER(MhaWeights), _vp, _vp, _vp, C.POINTER(Mask)] +
+                           [_vp] * 9 + [_vp]),
+    'lamp_mha_bwd_workspace_bytes': (_sz, [C.POINTER(MhaTrainDesc)]),
+    'lamp_mha_bwd_partials_bytes': (_sz, [C.POINTER(MhaTrainDesc)]),
+    'lamp_mha_bwd': (C.c_int, [C.POINTER(MhaTrainDesc), C.POINTER(MhaWeights)] + [_vp] * 11 + [_vp] * 15 +
+                     [_vp, _sz, _vp, _sz, C.POINTER(ReduceJob), _vp]),
     'lamp_layernorm_residual_fwd': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _f, _f, C.c_uint32, _vp, _vp]),
     'lamp_layernorm_bwd_workspace_bytes': (_sz, [_i64, _i32]),
     'lamp_layernorm_bwd': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _f, _f, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -143,9 +167,10 @@ def load_library(path):
     handle = C.CDLL(path)
     handle.lamp_version.restype = C.c_int
     version = handle.lamp_version()
-    # A/B runs against a build of an earlier round (tools/build_variant.sh): ABI 2 is a prefix of ABI 3 -- lamp_model
-    # grew one trailing member an older library never reads, lamp_pack_weight is absent (weight_pack() then returns None)
-    old_ok = version == 2 and os.environ.get('LAMP_ALLOW_OLD_ABI') == '1'
+    # A/B runs against a build of an earlier round (tools/build_variant.sh): ABI 2 and 3 are prefixes of ABI 4 -- lamp_model
+    # grew one trailing member an older library never reads, lamp_pack_weight / the training composites are absent
+    # (weight_pack() then returns None)
+    old_ok = version in (2, 3) and os.environ.get('LAMP_ALLOW_OLD_ABI') == '1'
     if version != ABI_VERSION and not old_ok:
         raise RuntimeError('lamp_amd: ABI version mismatch in ' + path)
     for name, (res, args) in PROTOTYPES.items():
@@ -505,6 +530,159 @@ def matmul_nt(a, b, out=None, alpha=1.0, accumulate=False, relu_mask=None):
     ws = workspace(nb, a.device) if nb else None
     check(L.lamp_gemm(C.byref(d), ptr(ws), nb, stream()), 'lamp_gemm')
     return out
+
+
+def matmul_nt_grouped(problems):
+    """[(a, b, out, accumulate)] -> every out[m, n] (+)= sum_k a[m, k] * b[n, k] in ONE launch per operand form
+    (lamp_gemm_grouped): 2-D fp32 device views as in matmul_nt, distinct outs.  Deepest K first inside a launch."""
+    groups = {}
+    for a, b, out, accumulate in problems:
+        if not (a.is_cuda and b.is_cuda and out.is_cuda):
+            require_device(a, b, out)
+        if a.dtype != torch.float32 or b.dtype != torch.float32 or out.dtype != torch.float32:
+            raise TypeError('matmul_nt_grouped needs float32 operands')
+        if a.dim() != 2 or b.dim() != 2 or out.dim() != 2:
+            raise ValueError('matmul_nt_grouped takes 2-D operands')
+        A, ash, ars, acs, _ = _operand(a)
+        Bm, bsh, brs, bcs, _ = _operand(b)
+        M, K, Nn = ash[2], ash[3], bsh[2]
+        if bsh[3] != K or tuple(out.shape) != (M, Nn) or (out.stride(1) != 1 and Nn != 1):
+            raise ValueError('shapes: a %s, b %s, out %s' % (tuple(a.shape), tuple(b.shape), tuple(out.shape)))
+        d = GemmDesc(A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, Nn, K, 1, 1, 1 if accumulate else 0,
+                     ars, acs, 0, 0, brs, bcs, 0, 0, out.stride(0), 0, 0, None, 0, 1.0, 0)
+        form = (ars == 1 and acs != 1, brs == 1 and bcs != 1)
+        groups.setdefault(form, []).append((K, d, A, Bm))
+    L, st = lib(), stream()
+    for form, items in groups.items():
+        items.sort(key=lambda it: -it[0])
+        arr = (GemmDesc * len(items))(*[it[1] for it in items])
+        check(L.lamp_gemm_grouped(arr, len(items), st), 'lamp_gemm_grouped')
+
+
+def _dp(t):
+    """data pointer of a contiguous fp32 device tensor (or 0): the composite calls below take no copies."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise TypeError('contiguous float32 device tensor expected, got %s %s' % (t.dtype, tuple(t.shape)))
+    return t.data_ptr()
+
+
+def ffn_train_fwd(x2, w1, b1, w2, b2, ln_g, ln_b, p, seed):
+    """lamp_ffn_train_fwd: x2 (M, d) -> (h, o, y); see include/lamp_hip.h."""
+    M, d = x2.shape
+    dff = w1.size(0)
+    e = torch.empty
+    h = e((M, dff), dtype=torch.float32, device=x2.device)
+    o = e((M, d), dtype=torch.float32, device=x2.device)
+    y = e((M, d), dtype=torch.float32, device=x2.device)
+    wts = FfnWeights(_dp(w1), _dp(b1), _dp(w2), _dp(b2), _dp(ln_g), _dp(ln_b))
+    check(lib().lamp_ffn_train_fwd(_dp(x2), M, d, dff, C.byref(wts), float(p), int(seed) & 0xffffffff, h.data_ptr(),
+                                   o.data_ptr(), y.data_ptr(), stream()), 'lamp_ffn_train_fwd')
+    return h, o, y
+
+
+def reduce_partials_grouped(jobs):
+    """lamp_reduce_partials_grouped over a list of ReduceJob (their buffers kept alive by the caller)."""
+    if jobs:
+        arr = (ReduceJob * len(jobs))(*jobs)
+        check(lib().lamp_reduce_partials_grouped(arr, len(jobs), stream()), 'lamp_reduce_partials_grouped')
+
+
+def ffn_bwd(x2, h, o, dy, w1, w2, ln_g, p, seed, want_dw1, want_dw2, defer_reduce=False):
+    """lamp_ffn_bwd -> (dx, d_o, dh, dW1 | None, dW2 | None, db1, db2, dgamma, dbeta, pending); d_o is dx when p == 0.
+    defer_reduce: db1 / db2 / dgamma / dbeta are finished by reduce_partials_grouped(pending[0]) later; pending[1] keeps the
+    partial sums alive until then.  pending is None otherwise."""
+    M, d = x2.shape
+    dff = w1.size(0)
+    dev = x2.device
+    e = torch.empty
+    dx = e((M, d), dtype=torch.float32, device=dev)
+    d_o = e((M, d), dtype=torch.float32, device=dev) if p > 0 else None
+    dh = e((M, dff), dtype=torch.float32, device=dev)
+    dW1 = e((dff, d), dtype=torch.float32, device=dev) if want_dw1 else None
+    dW2 = e((d, dff), dtype=torch.float32, device=dev) if want_dw2 else None
+    vec = e((2 * dff + 3 * d,), dtype=torch.float32, device=dev)   # db1 | db2 | dgamma | dbeta (one allocation)
+    db1, db2, dg, db = vec[:dff], vec[dff:dff + d], vec[dff + d:dff + 2 * d], vec[dff + 2 * d:dff + 3 * d]
+    L = lib()
+    nb = L.lamp_ffn_bwd_workspace_bytes(M, d, dff)
+    ws = workspace(nb, dev)
+    wts = FfnWeights(_dp(w1), None, _dp(w2), None, _dp(ln_g), None)
+    pending, part, npb, jobs = None, None, 0, None
+    if defer_reduce:
+        npb = L.lamp_ffn_bwd_partials_bytes(M, d, dff)
+        part = e((npb,), dtype=torch.uint8, device=dev)
+        jobs = (ReduceJob * 2)()
+    check(L.lamp_ffn_bwd(_dp(x2), _dp(h), _dp(o), _dp(dy), M, d, dff, C.byref(wts), float(p), int(seed) & 0xffffffff,
+                         dx.data_ptr(), _dp(d_o), dh.data_ptr(), _dp(dW1), _dp(dW2), db1.data_ptr(), db2.data_ptr(),
+                         dg.data_ptr(), db.data_ptr(), ptr(ws), nb, ptr(part), npb, jobs, stream()), 'lamp_ffn_bwd')
+    if defer_reduce:
+        pending = ([jobs[0], jobs[1]], (part, vec))
+    return dx, (d_o if d_o is not None else dx), dh, dW1, dW2, db1, db2, dg, db, pending
+
+
+def mha_train_fwd(desc, xq, xk, xv, wq, wk, wv, fc, ln_g, ln_b, mask_struct):
+    """lamp_mha_train_fwd -> (q, k, v, a, P, Pd | None, o | None, y)."""
+    B, lq, lk, d, H, dk, dv = desc.B, desc.lq, desc.lk, desc.d_model, desc.n_head, desc.d_k, desc.d_v
+    dev = xq.device
+    e = torch.empty
+    q = e((B, lq, H * dk), dtype=torch.float32, device=dev)
+    k = e((B, lk, H * dk), dtype=torch.float32, device=dev)
+    v = e((B, lk, H * dv), dtype=torch.float32, device=dev)
+    a = e((B, lq, H * dv), dtype=torch.float32, device=dev)
+    P = e((H * B, lq, lk), dtype=torch.float32, device=dev)
+    Pd = e((H * B, lq, lk), dtype=torch.float32, device=dev) if desc.p_attn > 0 else None
+    lse = e((H * B * lq,), dtype=torch.float32, device=dev)
+    o = e((B * lq, d), dtype=torch.float32, device=dev) if fc is not None else None
+    y = e((B, lq, d), dtype=torch.float32, device=dev)
+    wts = MhaWeights(_dp(wq), _dp(wk), _dp(wv), _dp(fc), _dp(ln_g), _dp(ln_b), H, 1)
+    m = C.byref(mask_struct) if mask_struct is not None else None
+    check(lib().lamp_mha_train_fwd(C.byref(desc), C.byref(wts), _dp(xq), _dp(xk), _dp(xv), m, q.data_ptr(), k.data_ptr(),
+                                   v.data_ptr(), a.data_ptr(), P.data_ptr(), _dp(Pd), lse.data_ptr(), _dp(o), y.data_ptr(),
+                                   stream()), 'lamp_mha_train_fwd')
+    return q, k, v, a, P, Pd, o, y
+
+
+def mha_bwd(desc, xq, xk, xv, q, k, v, a, P, Pd, o, dy, wq, wk, wv, fc, ln_g, separate_value_source, want_dw, want_dfc,
+            defer_reduce=False):
+    """lamp_mha_bwd -> dict of gradients and of the buffers deferred weight gradients are computed from; with defer_reduce,
+    r['pending'] = ([job], buffers to keep alive): dgamma / dbeta are finished by reduce_partials_grouped later."""
+    B, lq, lk, d, H, dk, dv = desc.B, desc.lq, desc.lk, desc.d_model, desc.n_head, desc.d_k, desc.d_v
+    dev = xq.device
+    e = torch.empty
+    f = dict(dtype=torch.float32, device=dev)
+    r = {}
+    r['dxq'] = e((B * lq, d), **f)
+    r['d_o'] = e((B * lq, d), **f) if desc.p_out > 0 else None
+    da = e((B * lq, H * dv), **f) if fc is not None else None
+    dP = e((H * B, lq, lk), **f)
+    r['dq'], r['dk'], r['dv'] = e((B * lq, H * dk), **f), e((B * lk, H * dk), **f), e((B * lk, H * dv), **f)
+    r['dxk'] = e((B * lk, d), **f)
+    r['dxv'] = e((B * lk, d), **f) if separate_value_source else None
+    vec = e((2 * d,), **f)
+    r['dgamma'], r['dbeta'] = vec[:d], vec[d:]
+    r['dwq'] = e((H * dk, d), **f) if want_dw else None
+    r['dwk'] = e((H * dk, d), **f) if want_dw else None
+    r['dwv'] = e((H * dv, d), **f) if want_dw else None
+    r['dfc'] = e((d, H * dv), **f) if (want_dfc and fc is not None) else None
+    L = lib()
+    nb = L.lamp_mha_bwd_workspace_bytes(C.byref(desc))
+    ws = workspace(nb, dev)
+    wts = MhaWeights(_dp(wq), _dp(wk), _dp(wv), _dp(fc), _dp(ln_g), None, H, 1)
+    part, npb, job = None, 0, None
+    if defer_reduce:
+        npb = L.lamp_mha_bwd_partials_bytes(C.byref(desc))
+        part = e((npb,), dtype=torch.uint8, device=dev)
+        job = (ReduceJob * 1)()
+    check(L.lamp_mha_bwd(C.byref(desc), C.byref(wts), _dp(xq), _dp(xk), _dp(xv), _dp(q), _dp(k), _dp(v), _dp(a), _dp(P),
+                         _dp(Pd), _dp(o), _dp(dy), r['dxq'].data_ptr(), _dp(r['d_o']), _dp(da), dP.data_ptr(),
+                         r['dq'].data_ptr(), r['dk'].data_ptr(), r['dv'].data_ptr(), r['dxk'].data_ptr(), _dp(r['dxv']),
+                         r['dgamma'].data_ptr(), r['dbeta'].data_ptr(), _dp(r['dwq']), _dp(r['dwk']), _dp(r['dwv']),
+                         _dp(r['dfc']), ptr(ws), nb, ptr(part), npb, job, stream()), 'lamp_mha_bwd')
+    r['pending'] = ([job[0]], (part, vec)) if defer_reduce else None
+    if r['d_o'] is None:
+        r['d_o'] = r['dxq']
+    return r
 
 
 def layernorm_residual(x, residual, gamma, beta, eps=1e-5, dropout_p=0.0, seed=0):

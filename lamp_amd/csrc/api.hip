@@ -468,6 +468,10 @@ int lamp_gemm(const lamp_gemm_desc* d, void* workspace, size_t workspace_bytes, 
     return launch_gemm_gen(*d, workspace, workspace_bytes, hipStream_t(stream));
 }
 
+int lamp_gemm_grouped(const lamp_gemm_desc* descs, int32_t n, lamp_stream_t stream) {
+    return launch_gemm_group(descs, n, hipStream_t(stream));
+}
+
 int lamp_layernorm_residual_fwd(const float* x, const float* residual, int64_t residual_rows, int64_t M, int32_t d,
                                 const float* gamma, const float* beta, float eps, float dropout_p, uint32_t seed,
                                 float* y, lamp_stream_t stream) {
@@ -514,6 +518,256 @@ int lamp_diag_logits_bwd(const float* y, const float* w_out, const float* dlogit
 int lamp_embed_bwd(const int64_t* src_seq, int64_t n_tokens, const float* dout, int32_t d_model, int32_t n_vocab,
                    int64_t pad_idx, float* d_emb, lamp_stream_t stream) {
     return launch_embed_bwd(src_seq, n_tokens, dout, d_model, n_vocab, pad_idx, d_emb, hipStream_t(stream));
+}
+
+// ---- training-mode sub-layers, one call each (lamp_amd/training.py) -------------------------------------------------------
+namespace {
+// C_z[m, n] (+)= sum_k A_z(m, k) B_z(n, k) through gemm_gen; strides in elements, (row, col) per operand
+struct Opd {
+    const float* p;
+    int64_t rs, cs, b0, b1;
+};
+int gg(const Opd& A, const Opd& B, float* C, int64_t ldc, int64_t cb0, int64_t cb1, int M, int N, int K, int nb0, int nb1,
+       bool accumulate, const float* relu_mask, void* ws, size_t ws_bytes, hipStream_t s) {
+    lamp_gemm_desc d{};
+    d.A = A.p; d.B = B.p; d.C = C;
+    d.M = M; d.N = N; d.K = K;
+    d.batch0 = nb0; d.batch1 = nb1;
+    d.accumulate = accumulate ? 1 : 0;
+    d.a_row_stride = A.rs; d.a_col_stride = A.cs; d.a_batch0 = A.b0; d.a_batch1 = A.b1;
+    d.b_row_stride = B.rs; d.b_col_stride = B.cs; d.b_batch0 = B.b0; d.b_batch1 = B.b1;
+    d.ldc = ldc; d.c_batch0 = cb0; d.c_batch1 = cb1;
+    d.relu_mask = relu_mask; d.ld_mask = N;
+    d.alpha = 1.f;
+    const size_t need = gemm_gen_workspace_bytes(M, N, K, nb0 * nb1);
+    return launch_gemm_gen(d, need <= ws_bytes ? ws : nullptr, need <= ws_bytes ? ws_bytes : 0, s);
+}
+inline Opd rows(const float* p, int64_t ld) { return Opd{p, ld, 1, 0, 0}; }        // [m, k], k contiguous
+inline Opd cols(const float* p, int64_t ld) { return Opd{p, 1, ld, 0, 0}; }        // stored [k, m]: the transposed read
+inline size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+}  // namespace
+
+int lamp_ffn_train_fwd(const float* x, int64_t M, int32_t d_model, int32_t d_inner, const lamp_ffn_weights* w,
+                       float dropout_p, uint32_t seed, float* h, float* o, float* y, lamp_stream_t stream) {
+    if (!x || !w || !h || !o || !y) return LAMP_E_NULL;
+    if (!w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->ln_g || !w->ln_b) return LAMP_E_NULL;
+    if (M <= 0 || d_model <= 0 || d_inner <= 0) return LAMP_E_DIMS;
+    if (!(dropout_p >= 0.f) || !(dropout_p < 1.f)) return LAMP_E_UNSUPPORTED;
+    hipStream_t s = hipStream_t(stream);
+    {
+        const float* W[1] = {w->w1};
+        const float* b[1] = {w->b1};
+        float* C[1] = {h};
+        LAMP_CK(linear(x, M, d_model, d_model, W, 1, d_inner, d_model, b, nullptr, 0, 1, C, d_inner, s));
+    }
+    {
+        const float* W[1] = {w->w2};
+        const float* b[1] = {w->b2};
+        float* C[1] = {o};
+        LAMP_CK(linear(h, M, d_inner, d_inner, W, 1, d_model, d_inner, b, nullptr, 0, 0, C, d_model, s));
+    }
+    const DropoutSpec ds = make_dropout(dropout_p, seed);
+    return launch_layernorm(o, M, d_model, w->ln_g, w->ln_b, 1e-5f, x, 0, y, s, nullptr, 0, nullptr,
+                            dropout_p > 0.f ? &ds : nullptr);
+}
+
+size_t lamp_ffn_bwd_workspace_bytes(int64_t M, int32_t d_model, int32_t d_inner) {
+    if (M <= 0 || M > 0x7fffffff || d_model <= 0 || d_inner <= 0) return 0;
+    return max3(layernorm_bwd_workspace_bytes(M, d_model), colsum_workspace_bytes(M, d_inner),
+                gemm_gen_workspace_bytes(d_model > d_inner ? d_model : d_inner, d_model > d_inner ? d_model : d_inner,
+                                         int(M), 1));
+}
+
+size_t lamp_ffn_bwd_partials_bytes(int64_t M, int32_t d_model, int32_t d_inner) {
+    if (M <= 0 || d_model <= 0 || d_inner <= 0) return 0;
+    return align_up(layernorm_bwd_workspace_bytes(M, d_model), 256) + colsum_workspace_bytes(M, d_inner);
+}
+
+int lamp_reduce_partials_grouped(const lamp_reduce_job* jobs, int32_t n, lamp_stream_t stream) {
+    return launch_reduce_group(jobs, n, hipStream_t(stream));
+}
+
+int lamp_ffn_bwd(const float* x, const float* h, const float* o, const float* dy, int64_t M, int32_t d_model,
+                 int32_t d_inner, const lamp_ffn_weights* w, float dropout_p, uint32_t seed, float* dx, float* d_o, float* dh,
+                 float* dW1, float* dW2, float* db1, float* db2, float* dgamma, float* dbeta, void* workspace,
+                 size_t workspace_bytes, void* partials, size_t partials_bytes, lamp_reduce_job* jobs, lamp_stream_t stream) {
+    if (partials && (!jobs || partials_bytes < lamp_ffn_bwd_partials_bytes(M, d_model, d_inner))) return LAMP_E_WORKSPACE;
+    if (!x || !h || !o || !dy || !w || !dx || !dh || !db1 || !db2 || !dgamma || !dbeta) return LAMP_E_NULL;
+    if (!w->w1 || !w->w2 || !w->ln_g) return LAMP_E_NULL;
+    if (M <= 0 || M > 0x7fffffff || d_model <= 0 || d_inner <= 0) return LAMP_E_DIMS;
+    if (!(dropout_p >= 0.f) || !(dropout_p < 1.f)) return LAMP_E_UNSUPPORTED;
+    const bool drop = dropout_p > 0.f;
+    if (drop && !d_o) return LAMP_E_NULL;
+    if (!drop && !dW2) return LAMP_E_UNSUPPORTED;   // without dropout d_o IS dx, which is accumulated into: dW2 cannot wait
+    if (workspace_bytes < lamp_ffn_bwd_workspace_bytes(M, d_model, d_inner) || (!workspace && workspace_bytes))
+        return LAMP_E_WORKSPACE;
+    hipStream_t s = hipStream_t(stream);
+    const DropoutSpec ds = make_dropout(dropout_p, seed);
+    const int Mi = int(M);
+    const size_t ln_bytes = align_up(layernorm_bwd_workspace_bytes(M, d_model), 256);
+    char* keep = static_cast<char*>(partials);
+    if (keep)
+        LAMP_CK(launch_layernorm_bwd(o, x, 0, M, d_model, w->ln_g, 1e-5f, drop ? &ds : nullptr, dy, dx, drop ? d_o : nullptr,
+                                     dgamma, dbeta, db2, keep, ln_bytes, s, &jobs[0]));
+    else
+        LAMP_CK(launch_layernorm_bwd(o, x, 0, M, d_model, w->ln_g, 1e-5f, drop ? &ds : nullptr, dy, dx, drop ? d_o : nullptr,
+                                     dgamma, dbeta, db2, workspace, workspace_bytes, s));
+    const float* g_o = drop ? d_o : dx;
+    if (dW2)   // dW2 = d_o^T h
+        LAMP_CK(gg(cols(g_o, d_model), cols(h, d_inner), dW2, d_inner, 0, 0, d_model, d_inner, Mi, 1, 1, false, nullptr,
+                   workspace, workspace_bytes, s));
+    // dh = relu'(h) * (d_o W2)
+    LAMP_CK(gg(rows(g_o, d_model), cols(w->w2, d_inner), dh, d_inner, 0, 0, Mi, d_inner, d_model, 1, 1, false, h, workspace,
+               workspace_bytes, s));
+    if (keep)
+        LAMP_CK(launch_colsum(dh, M, d_inner, d_inner, db1, keep + ln_bytes, partials_bytes - ln_bytes, s, &jobs[1]));
+    else
+        LAMP_CK(launch_colsum(dh, M, d_inner, d_inner, db1, workspace, workspace_bytes, s));
+    if (dW1)   // dW1 = dh^T x
+        LAMP_CK(gg(cols(dh, d_inner), cols(x, d_model), dW1, d_model, 0, 0, d_inner, d_model, Mi, 1, 1, false, nullptr,
+                   workspace, workspace_bytes, s));
+    // dx = residual branch + dh W1
+    return gg(rows(dh, d_inner), cols(w->w1, d_model), dx, d_model, 0, 0, Mi, d_model, d_inner, 1, 1, true, nullptr, workspace,
+              workspace_bytes, s);
+}
+
+int lamp_mha_train_fwd(const lamp_mha_train_desc* c, const lamp_mha_weights* w, const float* xq, const float* xk,
+                       const float* xv, const lamp_mask* mask, float* q, float* k, float* v, float* a, float* P, float* Pd,
+                       float* lse, float* o, float* y, lamp_stream_t stream) {
+    if (!c || !w || !xq || !xk || !xv || !q || !k || !v || !a || !P || !lse || !y) return LAMP_E_NULL;
+    if (!w->w_qs || !w->w_ks || !w->w_vs || !w->ln_g || !w->ln_b) return LAMP_E_NULL;
+    const int B = c->B, lq = c->lq, lk = c->lk, d = c->d_model, H = c->n_head, dk = c->d_k, dv = c->d_v;
+    if (B <= 0 || lq <= 0 || lk <= 0 || d <= 0 || H <= 0 || dk <= 0 || dv <= 0) return LAMP_E_DIMS;
+    if (H != w->n_head) return LAMP_E_DIMS;
+    if (dk > 128 || dv > 128) return LAMP_E_UNSUPPORTED;   // wide heads keep their scores in the map buffer: per-launch route
+    if (!(c->p_attn >= 0.f) || !(c->p_attn < 1.f) || !(c->p_out >= 0.f) || !(c->p_out < 1.f)) return LAMP_E_UNSUPPORTED;
+    const bool has_fc = w->fc != nullptr;
+    if (has_fc ? !o : (H * dv != d)) return has_fc ? LAMP_E_NULL : LAMP_E_DIMS;
+    if (c->p_attn > 0.f && !Pd) return LAMP_E_NULL;
+    hipStream_t s = hipStream_t(stream);
+    const int hdk = H * dk, hdv = H * dv;
+    const int64_t Mq = int64_t(B) * lq, Mk = int64_t(B) * lk;
+    if (xq == xk && xk == xv && hdk == hdv) {   // self-attention: the three projections as segments of one launch (same bits)
+        const float* W[3] = {w->w_qs, w->w_ks, w->w_vs};
+        float* C[3] = {q, k, v};
+        LAMP_CK(linear(xq, Mq, d, d, W, 3, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
+    } else {
+        const float* W[1] = {w->w_qs};
+        float* C[1] = {q};
+        LAMP_CK(linear(xq, Mq, d, d, W, 1, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
+    }
+    if (xq == xk && xk == xv && hdk == hdv) {
+    } else if (xk == xv && hdk == hdv) {
+        const float* W[2] = {w->w_ks, w->w_vs};
+        float* C[2] = {k, v};
+        LAMP_CK(linear(xk, Mk, d, d, W, 2, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
+    } else {
+        const float* Wk[1] = {w->w_ks};
+        float* Ck[1] = {k};
+        LAMP_CK(linear(xk, Mk, d, d, Wk, 1, hdk, d, nullptr, nullptr, 0, 0, Ck, hdk, s));
+        const float* Wv[1] = {w->w_vs};
+        float* Cv[1] = {v};
+        LAMP_CK(linear(xv, Mk, d, d, Wv, 1, hdv, d, nullptr, nullptr, 0, 0, Cv, hdv, s));
+    }
+    const lamp_attn_layout lay{int64_t(lq) * hdk, dk, hdk, int64_t(lk) * hdk, dk, hdk, int64_t(lk) * hdv, dv, hdv,
+                               int64_t(lq) * hdv, dv, hdv};
+    LAMP_CK(sdpa_impl(q, k, v, a, P, lse, B, H, lq, lk, dk, dv, c->inv_temperature, mask, &lay, stream));
+    if (c->p_attn > 0.f) {   // the reference drops probabilities AFTER the softmax (lamp/SubLayers.py:40-41): a = dropout(P) V
+        LAMP_CK(launch_dropout(P, int64_t(H) * B * lq * lk, c->p_attn, c->seed_attn, Pd, s));
+        LAMP_CK(gg(Opd{Pd, lk, 1, int64_t(B) * lq * lk, int64_t(lq) * lk}, Opd{v, 1, hdv, dv, int64_t(lk) * hdv}, a, hdv, dv,
+                   int64_t(lq) * hdv, lq, dv, lk, H, B, false, nullptr, nullptr, 0, s));
+    }
+    const DropoutSpec ds = make_dropout(c->p_out, c->seed_out);
+    const float* pre = a;
+    if (has_fc) {
+        const float* W[1] = {w->fc};
+        float* C[1] = {o};
+        LAMP_CK(linear(a, Mq, hdv, hdv, W, 1, d, hdv, nullptr, nullptr, 0, 0, C, d, s));
+        pre = o;
+    }
+    return launch_layernorm(pre, Mq, d, w->ln_g, w->ln_b, 1e-5f, xq, 0, y, s, nullptr, 0, nullptr,
+                            c->p_out > 0.f ? &ds : nullptr);
+}
+
+size_t lamp_mha_bwd_workspace_bytes(const lamp_mha_train_desc* c) {
+    if (!c || c->B <= 0 || c->lq <= 0 || c->lk <= 0 || c->d_model <= 0) return 0;
+    const int64_t Mq = int64_t(c->B) * c->lq, Mk = int64_t(c->B) * c->lk;
+    const int hd = c->n_head * (c->d_k > c->d_v ? c->d_k : c->d_v);
+    const int big = hd > c->d_model ? hd : c->d_model;
+    return max3(layernorm_bwd_workspace_bytes(Mq, c->d_model), gemm_gen_workspace_bytes(big, big, int(Mq), 1),
+                gemm_gen_workspace_bytes(big, big, int(Mk), 1));
+}
+
+size_t lamp_mha_bwd_partials_bytes(const lamp_mha_train_desc* c) {
+    if (!c || c->B <= 0 || c->lq <= 0 || c->d_model <= 0) return 0;
+    return layernorm_bwd_workspace_bytes(int64_t(c->B) * c->lq, c->d_model);
+}
+
+int lamp_mha_bwd(const lamp_mha_train_desc* c, const lamp_mha_weights* w, const float* xq, const float* xk, const float* xv,
+                 const float* q, const float* k, const float* v, const float* a, const float* P, const float* Pd,
+                 const float* o, const float* dy, float* dxq, float* d_o, float* da, float* dP, float* dq, float* dk_,
+                 float* dv_, float* dxk, float* dxv, float* dgamma, float* dbeta, float* dwq, float* dwk, float* dwv, float* dfc,
+                 void* workspace, size_t workspace_bytes, void* partials, size_t partials_bytes, lamp_reduce_job* job,
+                 lamp_stream_t stream) {
+    if (partials && (!job || partials_bytes < lamp_mha_bwd_partials_bytes(c))) return LAMP_E_WORKSPACE;
+    if (!c || !w || !xq || !xk || !xv || !q || !k || !v || !a || !P || !dy) return LAMP_E_NULL;
+    if (!dxq || !dP || !dq || !dk_ || !dv_ || !dxk || !dgamma || !dbeta) return LAMP_E_NULL;
+    if (!w->w_qs || !w->w_ks || !w->w_vs || !w->ln_g) return LAMP_E_NULL;
+    const int B = c->B, lq = c->lq, lk = c->lk, d = c->d_model, H = c->n_head, dk = c->d_k, dv = c->d_v;
+    if (B <= 0 || lq <= 0 || lk <= 0 || d <= 0 || H <= 0 || dk <= 0 || dv <= 0 || H != w->n_head) return LAMP_E_DIMS;
+    const int64_t Mq64 = int64_t(B) * lq, Mk64 = int64_t(B) * lk;
+    if (Mq64 > 0x7fffffff || Mk64 > 0x7fffffff || int64_t(H) * B > 65535) return LAMP_E_DIMS;
+    if (!(c->p_attn >= 0.f) || !(c->p_attn < 1.f) || !(c->p_out >= 0.f) || !(c->p_out < 1.f)) return LAMP_E_UNSUPPORTED;
+    const bool has_fc = w->fc != nullptr, drop_o = c->p_out > 0.f, drop_a = c->p_attn > 0.f;
+    if (has_fc && (!o || !da)) return LAMP_E_NULL;
+    if (drop_o && !d_o) return LAMP_E_NULL;
+    if (drop_a && !Pd) return LAMP_E_NULL;
+    if (has_fc && !drop_o && !dfc) return LAMP_E_UNSUPPORTED;   // d_o IS dxq then, which is accumulated into: dfc cannot wait
+    if (workspace_bytes < lamp_mha_bwd_workspace_bytes(c) || (!workspace && workspace_bytes)) return LAMP_E_WORKSPACE;
+    hipStream_t s = hipStream_t(stream);
+    const int hdk = H * dk, hdv = H * dv, Mq = int(Mq64), Mk = int(Mk64);
+    const DropoutSpec ds = make_dropout(c->p_out, c->seed_out);
+    void* ws = workspace;
+    const size_t wsb = workspace_bytes;
+    // add & norm (+ output dropout): dxq <- the residual branch, d_o <- the gradient of the fc output
+    if (partials)
+        LAMP_CK(launch_layernorm_bwd(has_fc ? o : a, xq, 0, Mq64, d, w->ln_g, 1e-5f, drop_o ? &ds : nullptr, dy, dxq,
+                                     drop_o ? d_o : nullptr, dgamma, dbeta, nullptr, partials, partials_bytes, s, job));
+    else
+        LAMP_CK(launch_layernorm_bwd(has_fc ? o : a, xq, 0, Mq64, d, w->ln_g, 1e-5f, drop_o ? &ds : nullptr, dy, dxq,
+                                     drop_o ? d_o : nullptr, dgamma, dbeta, nullptr, ws, wsb, s));
+    const float* g_o = drop_o ? d_o : dxq;
+    const float* g_a = g_o;   // gradient of the concatenated head outputs [Mq, H*dv]
+    if (has_fc) {
+        if (dfc) LAMP_CK(gg(cols(g_o, d), cols(a, hdv), dfc, hdv, 0, 0, d, hdv, Mq, 1, 1, false, nullptr, ws, wsb, s));
+        LAMP_CK(gg(rows(g_o, d), cols(w->fc, hdv), da, hdv, 0, 0, Mq, hdv, d, 1, 1, false, nullptr, ws, wsb, s));
+        g_a = da;
+    }   // (single head without output dropout: g_a IS dxq; every product that reads it is issued before (*) accumulates into it)
+    // head views: index (h, b) -> batch0 = head, batch1 = sample
+    const int64_t PB0 = int64_t(B) * lq * lk, PB1 = int64_t(lq) * lk;
+    const float* Pu = drop_a ? Pd : P;
+    const DropoutSpec da_spec = make_dropout(c->p_attn, c->seed_attn);
+    // dV = Pd^T dA
+    LAMP_CK(gg(Opd{Pu, 1, lk, PB0, PB1}, Opd{g_a, 1, hdv, dv, int64_t(lq) * hdv}, dv_, hdv, dv, int64_t(lk) * hdv, lk, dv, lq,
+               H, B, false, nullptr, nullptr, 0, s));
+    // dPd = dA V^T
+    LAMP_CK(gg(Opd{g_a, hdv, 1, dv, int64_t(lq) * hdv}, Opd{v, hdv, 1, dv, int64_t(lk) * hdv}, dP, lk, PB0, PB1, lq, lk, dv, H,
+               B, false, nullptr, nullptr, 0, s));
+    // dS = softmax backward of dropout-backward(dPd), in place (the mask is applied on load)
+    LAMP_CK(launch_softmax_bwd(P, dP, int64_t(H) * B * lq, lk, c->inv_temperature, dP, s, drop_a ? &da_spec : nullptr));
+    // dQ = dS K, dK = dS^T Q
+    LAMP_CK(gg(Opd{dP, lk, 1, PB0, PB1}, Opd{k, 1, hdk, dk, int64_t(lk) * hdk}, dq, hdk, dk, int64_t(lq) * hdk, lq, dk, lk, H, B,
+               false, nullptr, nullptr, 0, s));
+    LAMP_CK(gg(Opd{dP, 1, lk, PB0, PB1}, Opd{q, 1, hdk, dk, int64_t(lq) * hdk}, dk_, hdk, dk, int64_t(lk) * hdk, lk, dk, lq, H, B,
+               false, nullptr, nullptr, 0, s));
+    if (dwq) LAMP_CK(gg(cols(dq, hdk), cols(xq, d), dwq, d, 0, 0, hdk, d, Mq, 1, 1, false, nullptr, ws, wsb, s));
+    if (dwk) LAMP_CK(gg(cols(dk_, hdk), cols(xk, d), dwk, d, 0, 0, hdk, d, Mk, 1, 1, false, nullptr, ws, wsb, s));
+    if (dwv) LAMP_CK(gg(cols(dv_, hdv), cols(xv, d), dwv, d, 0, 0, hdv, d, Mk, 1, 1, false, nullptr, ws, wsb, s));
+    // (*) data gradients of the three projections
+    LAMP_CK(gg(rows(dq, hdk), cols(w->w_qs, d), dxq, d, 0, 0, Mq, d, hdk, 1, 1, true, nullptr, ws, wsb, s));
+    LAMP_CK(gg(rows(dk_, hdk), cols(w->w_ks, d), dxk, d, 0, 0, Mk, d, hdk, 1, 1, false, nullptr, ws, wsb, s));
+    if (dxv) return gg(rows(dv_, hdv), cols(w->w_vs, d), dxv, d, 0, 0, Mk, d, hdv, 1, 1, false, nullptr, ws, wsb, s);
+    return gg(rows(dv_, hdv), cols(w->w_vs, d), dxk, d, 0, 0, Mk, d, hdv, 1, 1, true, nullptr, ws, wsb, s);
 }
 
 int lamp_prior_graph_build(const int64_t* label_ids, const int64_t* offsets, int64_t n_samples, int32_t L, float* adj,

@@ -148,12 +148,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 // out[c] = sum_p partial[p][c] for c in [0, n_total); segment c / n_seg goes to out0 / out1 / out2.  A workgroup
 // owns 32 columns; its 8 thread slices each add every 8th partial, and the slices are combined in a fixed order.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int P, int64_t n_total,
-                                                              int64_t n_seg, float* __restrict__ out0,
-                                                              float* __restrict__ out1, float* __restrict__ out2) {
+__device__ __forceinline__ void reduce_partials_block(const float* __restrict__ partial, int P, int64_t n_total,
+                                                      int64_t n_seg, float* __restrict__ out0, float* __restrict__ out1,
+                                                      float* __restrict__ out2, int64_t block) {
     __shared__ float red[8][32];
     const int cx = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    const int64_t c = int64_t(blockIdx.x) * 32 + cx;
+    const int64_t c = block * 32 + cx;
     float s0 = 0.f, s1 = 0.f;
     if (c < n_total) {
         int p = slice;
@@ -173,6 +173,27 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
         o[c - seg * n_seg] = s;
     }
 }
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int P, int64_t n_total,
+                                                              int64_t n_seg, float* __restrict__ out0,
+                                                              float* __restrict__ out1, float* __restrict__ out2) {
+    reduce_partials_block(partial, P, n_total, n_seg, out0, out1, out2, blockIdx.x);
+}
+// Up to REDUCE_GROUP_MAX such reductions in one launch (lamp_reduce_partials_grouped): the second stages of a whole backward
+// pass's LayerNorm-parameter and bias gradients.  Same summation order per output as the single launch.
+constexpr int REDUCE_GROUP_MAX = 32;
+struct ReduceGroup {
+    lamp_reduce_job job[REDUCE_GROUP_MAX];
+    int block_begin[REDUCE_GROUP_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void reduce_group_kernel(ReduceGroup g) {
+    int idx = 0;
+    for (int i = 1; i < g.n; ++i)
+        if (int(blockIdx.x) >= g.block_begin[i]) idx = i;
+    const lamp_reduce_job& j = g.job[idx];
+    reduce_partials_block(j.partial, j.n_partials, j.n_total, j.n_seg, j.out[0], j.out[1], j.out[2],
+                          int(blockIdx.x) - g.block_begin[idx]);
+}
 
 // Counter-based dropout (mix32 / DropoutSpec in lamp_kernels.h).  The same call with the same seed applied to the
 // gradient is the backward pass.
@@ -185,18 +206,23 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 }
 
 // dS = scale * P * (dP - sum_k P * dP) per row (softmax backward; P = 0 on blocked entries keeps them at 0)
+// DROP: dP is the gradient of the DROPPED probabilities (lamp/SubLayers.py:40); its dropout backward -- lamp_dropout's mask for
+// element index row * lk + c -- is applied on load (the same values a separate lamp_dropout launch would have stored).
+template <bool DROP>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dP,
-                                                          int64_t rows, int lk, float scale, float* __restrict__ dS) {
+                                                          int64_t rows, int lk, float scale, float* __restrict__ dS,
+                                                          DropoutSpec ds) {
     const int lane = threadIdx.x & 63;
     const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* p = P + row * lk;
     const float* g = dP + row * lk;
+    auto grad = [&](int c) { return DROP ? drop1(g[c], row * lk + c, ds) : g[c]; };
     float s = 0.f;
-    for (int c = lane; c < lk; c += 64) s += p[c] * g[c];
+    for (int c = lane; c < lk; c += 64) s += p[c] * grad(c);
     s = wsum(s);
     float* o = dS + row * lk;
-    for (int c = lane; c < lk; c += 64) o[c] = scale * p[c] * (g[c] - s);
+    for (int c = lane; c < lk; c += 64) o[c] = scale * p[c] * (grad(c) - s);
 }
 
 // Read-out backward (lamp/Models.py:124-126): dy[b,i,:] = dl[b,i] * w[i,:];  dw[i,:] = sum_b dl[b,i] * y[b,i,:]
@@ -250,7 +276,7 @@ size_t layernorm_bwd_workspace_bytes(int64_t M, int d) { return size_t(lnb_grid(
 
 int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_t M, int d, const float* g, float eps,
                          const DropoutSpec* drop, const float* dy, float* dz, float* dz_drop, float* dgamma, float* dbeta,
-                         float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
+                         float* dbias, void* ws, size_t ws_bytes, hipStream_t s, lamp_reduce_job* job_out) {
     if (M <= 0 || d <= 0) return LAMP_E_DIMS;
     if ((d & 3) || d > 4096) return LAMP_E_UNSUPPORTED;
     const bool dr = drop && drop->threshold > 0;
@@ -293,6 +319,10 @@ int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_
 #undef LAMP_LNB_NV
 #undef LAMP_LNB
     if (int e = int(hipGetLastError())) return e;
+    if (job_out) {   // the caller reduces later (lamp_reduce_partials_grouped); ws stays live until then
+        *job_out = lamp_reduce_job{partial, int64_t(np) * d, int64_t(d), {dgamma, dbeta, dbias}, grid, 0};
+        return 0;
+    }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((np * d + 31) / 32), dim3(256), 0, s, partial, grid, int64_t(np) * d,
                        int64_t(d), dgamma, dbeta, dbias);
     return int(hipGetLastError());
@@ -300,7 +330,8 @@ int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_
 
 size_t colsum_workspace_bytes(int64_t M, int64_t N) { return size_t(colsum_chunks(M)) * N * sizeof(float); }
 
-int launch_colsum(const float* x, int64_t M, int64_t N, int64_t ldx, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+int launch_colsum(const float* x, int64_t M, int64_t N, int64_t ldx, float* out, void* ws, size_t ws_bytes, hipStream_t s,
+                  lamp_reduce_job* job_out) {
     if (M <= 0 || N <= 0 || ldx < N) return LAMP_E_DIMS;
     if (!x || !out || !ws) return LAMP_E_NULL;
     if (ws_bytes < colsum_workspace_bytes(M, N)) return LAMP_E_WORKSPACE;
@@ -313,8 +344,36 @@ int launch_colsum(const float* x, int64_t M, int64_t N, int64_t ldx, float* out,
     if (int e = int(hipGetLastError())) return e;
     const int64_t gr = (N + 31) / 32;
     if (gr > 0x7fffffffLL) return LAMP_E_DIMS;
+    if (job_out) {
+        *job_out = lamp_reduce_job{partial, N, N, {out, out, out}, chunks, 0};
+        return 0;
+    }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)gr), dim3(256), 0, s, partial, chunks, N, N, out, out, out);
     return int(hipGetLastError());
+}
+
+int launch_reduce_group(const lamp_reduce_job* jobs, int n, hipStream_t s) {
+    if (n < 0) return LAMP_E_DIMS;
+    if (n && !jobs) return LAMP_E_NULL;
+    for (int first = 0; first < n; first += REDUCE_GROUP_MAX) {
+        const int cnt = n - first < REDUCE_GROUP_MAX ? n - first : REDUCE_GROUP_MAX;
+        ReduceGroup g;
+        g.n = cnt;
+        g.block_begin[0] = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const lamp_reduce_job& j = jobs[first + i];
+            if (j.n_partials <= 0 || j.n_total <= 0 || j.n_seg <= 0 || j.n_total > 3 * j.n_seg || j.n_total > (1 << 26))
+                return LAMP_E_DIMS;
+            if (!j.partial || !j.out[0] || (j.n_total > j.n_seg && !j.out[1]) || (j.n_total > 2 * j.n_seg && !j.out[2]))
+                return LAMP_E_NULL;
+            g.job[i] = j;
+            g.block_begin[i + 1] = g.block_begin[i] + int((j.n_total + 31) / 32);
+        }
+        for (int i = cnt; i < REDUCE_GROUP_MAX; ++i) g.block_begin[i + 1] = g.block_begin[cnt];
+        hipLaunchKernelGGL(reduce_group_kernel, dim3(unsigned(g.block_begin[cnt])), dim3(256), 0, s, g);
+        if (int e = int(hipGetLastError())) return e;
+    }
+    return 0;
 }
 
 int launch_dropout(const float* x, int64_t n, float p, uint32_t seed, float* y, hipStream_t s) {
@@ -328,12 +387,17 @@ int launch_dropout(const float* x, int64_t n, float p, uint32_t seed, float* y, 
     return int(hipGetLastError());
 }
 
-int launch_softmax_bwd(const float* P, const float* dP, int64_t rows, int lk, float scale, float* dS, hipStream_t s) {
+int launch_softmax_bwd(const float* P, const float* dP, int64_t rows, int lk, float scale, float* dS, hipStream_t s,
+                       const DropoutSpec* drop) {
     if (rows <= 0 || lk <= 0) return LAMP_E_DIMS;
     if (!P || !dP || !dS) return LAMP_E_NULL;
     const int64_t g = (rows + 3) / 4;
     if (g > 0x7fffffffLL) return LAMP_E_DIMS;
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)g), dim3(256), 0, s, P, dP, rows, lk, scale, dS);
+    if (drop && drop->threshold > 0)
+        hipLaunchKernelGGL(softmax_bwd_kernel<true>, dim3((unsigned)g), dim3(256), 0, s, P, dP, rows, lk, scale, dS, *drop);
+    else
+        hipLaunchKernelGGL(softmax_bwd_kernel<false>, dim3((unsigned)g), dim3(256), 0, s, P, dP, rows, lk, scale, dS,
+                           DropoutSpec{0u, 1.f, 0u});
     return int(hipGetLastError());
 }
 

@@ -112,21 +112,20 @@ __device__ __forceinline__ float4 frag(const float* lds, int row, int hi) {
 
 // FAST: both operands 16-byte loadable and every k-tile of every split whole (K a multiple of 16) -- the host's choice; the
 // loads then carry no per-tile vector arithmetic (stage_voff).
+// One output tile: `tile` of the problem's tiles_m x tiles_n grid, batch index zy, K split `split`.
 template <int GM, int GN, int WM, int WN, bool TA, bool TB, bool FAST>
-__global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n) {
+__device__ __forceinline__ void gemm_gen_tile(const GenParams& p, int tiles_n, int tile, int zy, int split) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int WTM = GM / WM, WTN = GN / WN, MI = WTM / 16, NI = WTN / 16;
     __shared__ __attribute__((aligned(16))) float As[2][lds_operand(GM)];
     __shared__ __attribute__((aligned(16))) float Bs[2][lds_operand(GN)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l15 = lane & 15, hi = lane >> 4;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * GM, n0 = tn * GN;
     const int rows_m = p.M - m0 < GM ? p.M - m0 : GM;
     const int rows_n = p.N - n0 < GN ? p.N - n0 : GN;
-    const int z0 = blockIdx.y / p.nb1, z1 = blockIdx.y - z0 * p.nb1;
-    const int split = blockIdx.z;
+    const int z0 = zy / p.nb1, z1 = zy - z0 * p.nb1;
     const int k_begin = split * p.k_chunk;
     const int k_end = k_begin + p.k_chunk < p.K ? k_begin + p.k_chunk : p.K;
 
@@ -239,6 +238,67 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n)
                 bstore1(rsC, off, v);
             }
         }
+}
+
+template <int GM, int GN, int WM, int WN, bool TA, bool TB, bool FAST>
+__global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n) {
+    gemm_gen_tile<GM, GN, WM, WN, TA, TB, FAST>(p, tiles_n, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y, blockIdx.z);
+}
+
+// Grouped launch: up to GROUP_MAX independent products (no batch dims, no K split, no ReLU mask) share ONE grid of 64 x 64
+// tiles -- the weight gradients of a whole backward pass (dW = dY^T.X: 64 tiles each at d_model = 512) fill the chip
+// together instead of one by one through split-K partials and a reduce launch each.  The problem table rides in the kernel
+// arguments.  Workgroup b runs on XCD b % 8 (round-robin dispatch): every XCD takes an eighth of EVERY problem's tiles
+// (consecutive tiles, i.e. whole row panels sharing their A columns in that XCD's L2), so the XCDs stay balanced whatever
+// the mix of K depths, and within an XCD the host's order (deepest K first) is the dispatch order.  Every output tile is owned
+// by exactly one workgroup and accumulates k in ascending order: results do not depend on the grouping.
+constexpr int GROUP_MAX = 32;
+struct GroupProblem {
+    const float* A;
+    const float* B;
+    float* C;
+    int lda, ldb, ldc;   // lda / ldb: the non-unit stride of the operand
+    int M, N, K;
+    int tiles_n, tiles;
+    int vec;             // bit 0: A 16-byte loadable, bit 1: B
+    float alpha;
+    int accumulate;
+};
+struct GroupParams {
+    GroupProblem prob[GROUP_MAX];
+    int share_begin[GROUP_MAX + 1];   // prefix sums of ceil(tiles / 8): a problem's tiles per XCD
+    int n;
+};
+
+template <bool TA, bool TB, bool FAST>
+__global__ __launch_bounds__(256) void gemm_group_kernel(GroupParams g) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    int idx = 0;
+    for (int i = 1; i < g.n; ++i)
+        if (j >= g.share_begin[i]) idx = i;
+    const GroupProblem& q = g.prob[idx];
+    const int share = g.share_begin[idx + 1] - g.share_begin[idx];
+    const int tile = xcd * share + (j - g.share_begin[idx]);
+    if (tile >= q.tiles) return;
+    GenParams p;
+    p.A = Operand{q.A, TA ? 1 : q.lda, TA ? q.lda : 1, 0, 0};
+    p.B = Operand{q.B, TB ? 1 : q.ldb, TB ? q.ldb : 1, 0, 0};
+    p.C = q.C;
+    p.ldc = q.ldc;
+    p.c_b0 = p.c_b1 = 0;
+    p.M = q.M;
+    p.N = q.N;
+    p.K = q.K;
+    p.nb1 = 1;
+    p.vecA = q.vec & 1;
+    p.vecB = (q.vec >> 1) & 1;
+    p.alpha = q.alpha;
+    p.accumulate = q.accumulate;
+    p.mask = nullptr;
+    p.ldm = 0;
+    p.k_chunk = q.K;
+    p.part = nullptr;
+    gemm_gen_tile<64, 64, 2, 2, TA, TB, FAST>(p, q.tiles_n, tile, 0, 0);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, int M, int N,
@@ -372,6 +432,79 @@ int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStrea
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p.part, nsplit, d.M, d.N, d.alpha, d.relu_mask,
                            d.ld_mask, d.accumulate, d.C, d.ldc);
         return int(hipGetLastError());
+    }
+    return 0;
+}
+
+int launch_gemm_group(const lamp_gemm_desc* descs, int n, hipStream_t s) {
+    if (n <= 0) return n == 0 ? 0 : LAMP_E_DIMS;
+    if (!descs) return LAMP_E_NULL;
+    for (int first = 0; first < n; first += GROUP_MAX) {
+        const int cnt = n - first < GROUP_MAX ? n - first : GROUP_MAX;
+        GroupParams g;
+        g.n = cnt;
+        g.share_begin[0] = 0;
+        bool ta0 = false, tb0 = false, fast = true;
+        double flops = 0, bytes = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const lamp_gemm_desc& d = descs[first + i];
+            if (d.M <= 0 || d.N <= 0 || d.K <= 0) return LAMP_E_DIMS;
+            if (!d.A || !d.B || !d.C) return LAMP_E_NULL;
+            if (d.batch0 != 1 || d.batch1 != 1 || d.relu_mask) return LAMP_E_UNSUPPORTED;
+            const bool ta = d.a_row_stride == 1 && d.a_col_stride != 1, tb = d.b_row_stride == 1 && d.b_col_stride != 1;
+            if ((!ta && d.a_col_stride != 1) || (!tb && d.b_col_stride != 1)) return LAMP_E_UNSUPPORTED;
+            if (i == 0) ta0 = ta, tb0 = tb;
+            if (ta != ta0 || tb != tb0) return LAMP_E_UNSUPPORTED;   // one operand form per call
+            const int64_t lda = ta ? d.a_col_stride : d.a_row_stride, ldb = tb ? d.b_col_stride : d.b_row_stride;
+            if (lda < 1 || ldb < 1 || d.ldc < d.N) return LAMP_E_DIMS;
+            const int64_t span_a = ta ? int64_t(d.K) * lda : int64_t(64) * lda + d.K;
+            const int64_t span_b = tb ? int64_t(d.K) * ldb : int64_t(64) * ldb + d.K;
+            if (span_a * 4 >= 0x7fffffffLL || span_b * 4 >= 0x7fffffffLL || int64_t(64) * d.ldc * 4 >= 0x7fffffffLL)
+                return LAMP_E_UNSUPPORTED;
+            const bool va = aligned16(d.A) && (lda & 3) == 0 && ((ta ? d.M : d.K) & 3) == 0;
+            const bool vb = aligned16(d.B) && (ldb & 3) == 0 && ((tb ? d.N : d.K) & 3) == 0;
+            fast = fast && va && vb && (d.K % GK) == 0;
+            GroupProblem& q = g.prob[i];
+            q.A = d.A;
+            q.B = d.B;
+            q.C = d.C;
+            q.lda = int(lda);
+            q.ldb = int(ldb);
+            q.ldc = int(d.ldc);
+            q.M = d.M;
+            q.N = d.N;
+            q.K = d.K;
+            q.tiles_n = (d.N + 63) / 64;
+            const int64_t tiles = int64_t((d.M + 63) / 64) * q.tiles_n;
+            if (tiles > (1 << 24)) return LAMP_E_DIMS;
+            q.tiles = int(tiles);
+            q.vec = (va ? 1 : 0) | (vb ? 2 : 0);
+            q.alpha = d.alpha;
+            q.accumulate = d.accumulate;
+            g.share_begin[i + 1] = g.share_begin[i] + (q.tiles + 7) / 8;
+            flops += 2.0 * double(d.M) * d.N * d.K;
+            bytes += 4.0 * (double(d.M) * d.K + double(d.N) * d.K + double(d.M) * d.N);
+        }
+        for (int i = cnt; i < GROUP_MAX; ++i) g.share_begin[i + 1] = g.share_begin[cnt];
+        ProfScope prof(LAMP_K_GEMM, flops, bytes, s);
+        const dim3 grid(unsigned(g.share_begin[cnt]) * 8u);
+#define LAMP_GROUP_LAUNCH(FAST_)                                                                                   \
+    do {                                                                                                            \
+        if (ta0 && tb0)                                                                                             \
+            hipLaunchKernelGGL((gemm_group_kernel<true, true, FAST_>), grid, dim3(256), 0, s, g);                   \
+        else if (ta0)                                                                                               \
+            hipLaunchKernelGGL((gemm_group_kernel<true, false, FAST_>), grid, dim3(256), 0, s, g);                  \
+        else if (tb0)                                                                                               \
+            hipLaunchKernelGGL((gemm_group_kernel<false, true, FAST_>), grid, dim3(256), 0, s, g);                  \
+        else                                                                                                        \
+            hipLaunchKernelGGL((gemm_group_kernel<false, false, FAST_>), grid, dim3(256), 0, s, g);                 \
+    } while (0)
+        if (fast)
+            LAMP_GROUP_LAUNCH(true);
+        else
+            LAMP_GROUP_LAUNCH(false);
+#undef LAMP_GROUP_LAUNCH
+        if (int e = int(hipGetLastError())) return e;
     }
     return 0;
 }

@@ -85,6 +85,7 @@ bool attn_tile_applies(const AttnParams& p);
 int launch_attn_tile(const AttnParams& p, hipStream_t s);
 size_t gemm_gen_workspace_bytes(int M, int N, int K, int batch);
 int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_gemm_group(const lamp_gemm_desc* descs, int n, hipStream_t s);
 // Counter-based dropout (lamp_dropout): element e of a site is kept iff mix32(e, seed) >= threshold, kept values are
 // multiplied by scale = 1 / (1 - p).  threshold == 0: dropout off.
 struct DropoutSpec {
@@ -156,11 +157,16 @@ int launch_pack_weight(const float* W, int N, int K, int64_t ldw, int format, fl
 size_t layernorm_bwd_workspace_bytes(int64_t M, int d);
 int launch_layernorm_bwd(const float* x, const float* res, int64_t r_mod, int64_t M, int d, const float* g, float eps,
                          const DropoutSpec* drop, const float* dy, float* dz, float* dz_drop, float* dgamma, float* dbeta,
-                         float* dbias, void* ws, size_t ws_bytes, hipStream_t s);
+                         float* dbias, void* ws, size_t ws_bytes, hipStream_t s, lamp_reduce_job* job_out = nullptr);
 size_t colsum_workspace_bytes(int64_t M, int64_t N);
-int launch_colsum(const float* x, int64_t M, int64_t N, int64_t ldx, float* out, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_colsum(const float* x, int64_t M, int64_t N, int64_t ldx, float* out, void* ws, size_t ws_bytes, hipStream_t s,
+                  lamp_reduce_job* job_out = nullptr);
+// job_out (both above): skip the second-stage launch and describe it instead -- the partials in ws then have to outlive the
+// call until launch_reduce_group has run them (lamp_reduce_partials_grouped)
+int launch_reduce_group(const lamp_reduce_job* jobs, int n, hipStream_t s);
 int launch_dropout(const float* x, int64_t n, float p, uint32_t seed, float* y, hipStream_t s);
-int launch_softmax_bwd(const float* P, const float* dP, int64_t rows, int lk, float scale, float* dS, hipStream_t s);
+int launch_softmax_bwd(const float* P, const float* dP, int64_t rows, int lk, float scale, float* dS, hipStream_t s,
+                       const DropoutSpec* drop = nullptr);   // drop: dP is the gradient of dropout(P), mask applied on load
 int launch_diag_bwd(const float* y, const float* w, const float* dl, int B, int L, int d, float* dy, float* dw,
                     hipStream_t s);
 int launch_embed_bwd(const int64_t* seq, int64_t n_tok, const float* dout, int d, int n_vocab, int64_t pad_idx,

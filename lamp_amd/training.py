@@ -13,11 +13,121 @@ from torch's Philox stream (the reference is not reproducible across devices eit
 
 Attention backward uses the probability maps the forward kernel writes (its exact two-pass variant) and five
 ``lamp_gemm`` products on head-split VIEWS of the fused [B, l, h*d] projections -- no head split/merge copies.
+
+Weight gradients are DEFERRED (``DEFER_WEIGHT_GRADS``): dW = dY^T.X of a projection is not needed by anything else in the
+backward pass, and alone it is 64 output tiles at d_model = 512 -- a K split over partial buffers plus a reduce launch
+each.  The sub-layers' backward functions therefore only queue (parameter, dY, X); when the engine has run the whole
+graph, one ``lamp_gemm_grouped`` launch computes every queued product (28 of them for the 2+2-layer model) and the results
+are stored in (or accumulated into) the parameters' ``.grad`` -- what ``optimizer.step()`` reads next (train.py:40-48).
+Only leaf parameters are deferred; anything else (``nn.DataParallel`` replicas, ``torch.autograd.grad`` on a sub-module
+called directly) gets its gradient through autograd as before.
 """
+import threading
+
 import torch
 
 from . import Constants
 from . import _native as N
+
+DEFER_WEIGHT_GRADS = True
+# One library call per sub-layer and direction (lamp_ffn_train_fwd / lamp_ffn_bwd / lamp_mha_train_fwd / lamp_mha_bwd) instead
+# of one Python round trip per launch: the reuters step is ~190 launches and was bound by the issuing thread
+# (tools/bench_train.py: host_issue_ms_per_step).  Same kernels, same bits; False = the per-launch route below.
+COMPOSITE_CALLS = True
+
+
+def _plain(*tensors):
+    """Composite calls take contiguous fp32 device tensors as they are."""
+    for t in tensors:
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            return False
+    return True
+
+
+class _WeightGrads(object):
+    """The queue of deferred weight gradients; flushed by the autograd engine's end-of-backward callback."""
+
+    def __init__(self):
+        self.items = []
+        self.jobs = []
+        self.armed = False
+        self.lock = threading.Lock()
+
+    def add_reductions(self, pending, grads):
+        """pending = (jobs, buffers) from N.ffn_bwd / N.mha_bwd(defer_reduce=True); grads = [(parameter, tensor the jobs fill)]."""
+        with self.lock:
+            self.jobs.append((pending, grads))
+            self._arm()
+
+    def _arm(self):
+        if not self.armed:
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+            self.armed = True
+
+    def add(self, param, dy2, x2):
+        """param.grad (+)= dy2^T x2  (dy2 (rows, out), x2 (rows, in); param is (out, in) or Conv1d's (out, in, 1))."""
+        with self.lock:
+            self.items.append((param, dy2, x2))
+            self._arm()
+
+    def flush(self):
+        with self.lock:
+            items, self.items, jobs, self.jobs, self.armed = self.items, [], self.jobs, [], False
+        jobs_by_dev = {}
+        for pending, grads in jobs:
+            jobs_by_dev.setdefault(grads[0][1].device, []).append((pending, grads))
+        for dev, todo in jobs_by_dev.items():   # the second stages of every LayerNorm-parameter / bias gradient: one launch
+            with torch.cuda.device(dev), torch.no_grad():
+                N.reduce_partials_grouped([j for pending, _ in todo for j in pending[0]])
+                for _, grads in todo:
+                    for param, t in grads:
+                        if param.grad is None:
+                            param.grad = t.view(param.shape)
+                        else:
+                            param.grad.add_(t.view(param.shape))
+        by_dev = {}
+        for it in items:
+            by_dev.setdefault(it[1].device, []).append(it)
+        for dev, todo in by_dev.items():
+            with torch.cuda.device(dev), torch.no_grad():
+                while todo:
+                    seen, batch, rest = set(), [], []
+                    for it in todo:   # a parameter used twice: its second product accumulates in a later launch
+                        (rest if id(it[0]) in seen else batch).append(it)
+                        seen.add(id(it[0]))
+                    problems, fresh, detour = [], [], []
+                    for param, dy2, x2 in batch:
+                        shape2 = (dy2.size(1), x2.size(1))
+                        g = param.grad
+                        if g is None:
+                            out = torch.empty(shape2, dtype=torch.float32, device=dev)
+                            fresh.append((param, out))
+                            problems.append((dy2.t(), x2.t(), out, False))
+                        elif g.is_contiguous() and g.dtype == torch.float32:
+                            problems.append((dy2.t(), x2.t(), g.view(shape2), True))
+                        else:
+                            out = torch.empty(shape2, dtype=torch.float32, device=dev)
+                            detour.append((g, out))
+                            problems.append((dy2.t(), x2.t(), out, False))
+                    N.matmul_nt_grouped(problems)
+                    for param, out in fresh:
+                        param.grad = out.view(param.shape)
+                    for g, out in detour:
+                        g.add_(out.view(g.shape))
+                    todo = rest
+
+
+_weight_grads = _WeightGrads()
+
+
+def _deferrable(*params):
+    """The parameters themselves if their gradients may bypass autograd (see the module docstring), else None."""
+    if not DEFER_WEIGHT_GRADS:
+        return None
+    for p in params:
+        if p is not None and not (p.is_leaf and p.requires_grad and p.is_cuda):
+            return None
+    return params
 
 
 class _Seeds(object):
@@ -70,11 +180,17 @@ class _FFNFn(torch.autograd.Function):
     """LayerNorm(dropout(W2 relu(W1 x + b1) + b2) + x)   (lamp/SubLayers.py:133-142)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, ln_g, ln_b, p, seed):
+    def forward(ctx, x, w1, b1, w2, b2, ln_g, ln_b, p, seed, defer=None):
+        ctx.defer = defer   # (w1, w2) as the leaf Parameters, or None
         x2 = x.reshape(-1, x.size(-1))
-        h = N.linear(x2, _w2d(w1), b1, relu=True)
-        o = N.linear(h, _w2d(w2), b2)
-        y = N.layernorm_residual(o, x2, ln_g, ln_b, dropout_p=p, seed=seed)  # dropout + add & norm in one kernel
+        ctx.composite = COMPOSITE_CALLS and _plain(x2, w1, b1, w2, b2, ln_g, ln_b)
+        if ctx.composite:
+            N.require_device(x2)
+            h, o, y = N.ffn_train_fwd(x2, _w2d(w1), b1, _w2d(w2), b2, ln_g, ln_b, p, seed)
+        else:
+            h = N.linear(x2, _w2d(w1), b1, relu=True)
+            o = N.linear(h, _w2d(w2), b2)
+            y = N.layernorm_residual(o, x2, ln_g, ln_b, dropout_p=p, seed=seed)  # dropout + add & norm in one kernel
         ctx.save_for_backward(x2, h, o, w1, w2, ln_g)
         ctx.p, ctx.seed, ctx.shape = p, seed, x.shape
         return y.view(x.shape)
@@ -83,14 +199,39 @@ class _FFNFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, h, o, w1, w2, ln_g = ctx.saved_tensors
         W1, W2 = _w2d(w1), _w2d(w2)
+        if ctx.composite:
+            defer = ctx.defer
+            wait1, wait2 = defer is not None, defer is not None and ctx.p > 0
+            dx, d_o, dh, dW1, dW2, db1, db2, dg, db, pending = N.ffn_bwd(
+                x2, h, o, dy.reshape(x2.shape).contiguous(), W1, W2, ln_g, ctx.p, ctx.seed, not wait1, not wait2,
+                defer_reduce=defer is not None)
+            if wait1:
+                _weight_grads.add(defer[0], dh, x2)
+            if wait2:
+                _weight_grads.add(defer[1], d_o, h)
+            if pending is not None:
+                _weight_grads.add_reductions(pending, [(defer[2], db1), (defer[3], db2), (defer[4], dg), (defer[5], db)])
+                db1 = db2 = dg = db = None
+            return (dx.view(ctx.shape), None if wait1 else dW1.view_as(w1), db1, None if wait2 else dW2.view_as(w2), db2,
+                    dg, db, None, None, None)
         dz, do, dg, db, db2 = N.layernorm_bwd(o, x2, ln_g, dy.reshape(x2.shape), dropout_p=ctx.p, seed=ctx.seed,
                                               want_dbias=True)
-        dW2 = N.matmul_nt(do.t(), h.t())
+        defer = ctx.defer
+        # do IS dz when there is no dropout, and dz is accumulated into below: that product cannot wait
+        if defer is not None and do is not dz:
+            _weight_grads.add(defer[1], do, h)
+            dW2 = None
+        else:
+            dW2 = N.matmul_nt(do.t(), h.t()).view_as(w2)
         dh = N.matmul_nt(do, W2.t(), relu_mask=h)
         db1 = N.colsum(dh)
-        dW1 = N.matmul_nt(dh.t(), x2.t())
-        dx = N.matmul_nt(dh, W1.t(), out=dz, accumulate=True)  # + the residual branch (do is dead by now)
-        return dx.view(ctx.shape), dW1.view_as(w1), db1, dW2.view_as(w2), db2, dg, db, None, None
+        if defer is not None:
+            _weight_grads.add(defer[0], dh, x2)
+            dW1 = None
+        else:
+            dW1 = N.matmul_nt(dh.t(), x2.t()).view_as(w1)
+        dx = N.matmul_nt(dh, W1.t(), out=dz, accumulate=True)  # + the residual branch (do is dead by now, or queued)
+        return dx.view(ctx.shape), dW1, db1, dW2, db2, dg, db, None, None, None
 
 
 class _MHAFn(torch.autograd.Function):
@@ -98,17 +239,33 @@ class _MHAFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xkv, wq, wk, wv, fc, ln_g, ln_b, n_head, mask, keep, p_attn, p_out, seed_attn, seed_out,
-                xv=None):
+                xv=None, defer=None):
         """xkv: the key source and, unless ``xv`` is given, the value source too (every layer of the reference passes one
         tensor for both, lamp/Layers.py:16,35,40; the module itself accepts two, lamp/SubLayers.py:77-93)."""
+        ctx.defer = defer   # (wq, wk, wv, fc) as the leaf Parameters, or None
         B, lq, d = xq.shape
         lk = xkv.size(1)
         H = n_head
         dk, dv = wq.size(0) // H, wv.size(0) // H
+        inv_t = 1.0 / float(dk) ** 0.5
+        ctx.composite = (COMPOSITE_CALLS and dk <= 128 and dv <= 128 and
+                         _plain(xq, xkv, xv, wq, wk, wv, fc, ln_g, ln_b) and (fc is not None or H * dv == d))
+        if ctx.composite:
+            N.require_device(xq, xkv)
+            desc = N.MhaTrainDesc(B, lq, lk, d, H, dk, dv, inv_t, p_attn, p_out, seed_attn & 0xffffffff,
+                                  seed_out & 0xffffffff)
+            q, k, v, a, P, Pd, o, y = N.mha_train_fwd(desc, xq, xkv, xkv if xv is None else xv, wq, wk, wv, fc, ln_g, ln_b,
+                                                     mask)
+            ctx.save_for_backward(xq, xkv, wq, wk, wv, fc if fc is not None else wq.new_empty(0), ln_g, q, k, v, a, P,
+                                  o if o is not None else a, xv if xv is not None else wq.new_empty(0))
+            ctx.cfg = (B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, fc is not None, xv is not None)
+            attn = Pd if p_attn > 0 else P.clone()
+            ctx.Pd = Pd   # the dropped map is what the value product used: kept for the backward instead of recomputed
+            ctx.mark_non_differentiable(attn)
+            return y, attn
         q = N.linear(xq, wq)
         k = N.linear(xkv, wk)
         v = N.linear(xkv if xv is None else xv, wv)
-        inv_t = 1.0 / float(dk) ** 0.5
         a, P = N.sdpa_fused(q, k, v, H, mask, inv_t, need_attn=True, fast_maps=True)
         Pd = P
         if p_attn > 0:  # the reference drops probabilities AFTER the softmax; the value product uses the dropped map
@@ -129,13 +286,38 @@ class _MHAFn(torch.autograd.Function):
         xq, xkv, wq, wk, wv, fc, ln_g, q, k, v, a, P, o, xv = ctx.saved_tensors
         B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, has_fc, has_xv = ctx.cfg
         d = xq.size(-1)
+        if ctx.composite:
+            defer = ctx.defer
+            wait, wait_fc = defer is not None, defer is not None and p_out > 0
+            desc = N.MhaTrainDesc(B, lq, lk, d, H, dk, dv, inv_t, p_attn, p_out, seed_attn & 0xffffffff,
+                                  seed_out & 0xffffffff)
+            r = N.mha_bwd(desc, xq, xkv, xv if has_xv else xkv, q, k, v, a, P, ctx.Pd, o if has_fc else None,
+                          dy.reshape(B * lq, d).contiguous(), wq, wk, wv, fc if has_fc else None, ln_g, has_xv, not wait,
+                          not wait_fc, defer_reduce=wait)
+            if r['pending'] is not None:
+                _weight_grads.add_reductions(r['pending'], [(defer[4], r['dgamma']), (defer[5], r['dbeta'])])
+                r['dgamma'] = r['dbeta'] = None
+            if wait:
+                xq2, xkv2 = xq.view(-1, d), xkv.view(-1, d)
+                _weight_grads.add(defer[0], r['dq'], xq2)
+                _weight_grads.add(defer[1], r['dk'], xkv2)
+                _weight_grads.add(defer[2], r['dv'], xv.view(-1, d) if has_xv else xkv2)
+            if wait_fc and has_fc:
+                _weight_grads.add(defer[3], r['d_o'], a.view(-1, H * dv))
+            return (r['dxq'].view(xq.shape), r['dxk'].view(xkv.shape), r['dwq'], r['dwk'], r['dwv'], r['dfc'], r['dgamma'],
+                    r['dbeta']) + (None,) * 7 + (r['dxv'].view(xv.shape) if has_xv else None, None)
         xq2, xkv2 = xq.reshape(-1, d), xkv.reshape(-1, d)
         xv2 = xv.reshape(-1, d) if has_xv else xkv2
         dz, do, dg, db, _ = N.layernorm_bwd(o.view(xq2.shape), xq2, ln_g, dy.reshape(xq2.shape), dropout_p=p_out,
                                             seed=seed_out)
         a2 = a.view(-1, H * dv)
+        defer = ctx.defer
         if has_fc:
-            dfc = N.matmul_nt(do.t(), a2.t())
+            if defer is not None and do is not dz:   # do IS dz without dropout, and dz is accumulated into below
+                _weight_grads.add(defer[3], do, a2)
+                dfc = None
+            else:
+                dfc = N.matmul_nt(do.t(), a2.t())
             da = N.matmul_nt(do, fc.t())
         else:
             dfc, da = None, do
@@ -153,9 +335,15 @@ class _MHAFn(torch.autograd.Function):
         N.matmul_nt(dP, kh.transpose(-1, -2), out=heads(dq_buf, lq, dk))                          # dQ = dS K
         N.matmul_nt(dP.transpose(-1, -2), qh.transpose(-1, -2), out=heads(dk_buf, lk, dk))        # dK = dS^T Q
         dq2, dk2, dv2 = dq_buf.view(-1, H * dk), dk_buf.view(-1, H * dk), dv_buf.view(-1, H * dv)
-        dwq = N.matmul_nt(dq2.t(), xq2.t())
-        dwk = N.matmul_nt(dk2.t(), xkv2.t())
-        dwv = N.matmul_nt(dv2.t(), xv2.t())
+        if defer is not None:
+            _weight_grads.add(defer[0], dq2, xq2)
+            _weight_grads.add(defer[1], dk2, xkv2)
+            _weight_grads.add(defer[2], dv2, xv2)
+            dwq = dwk = dwv = None
+        else:
+            dwq = N.matmul_nt(dq2.t(), xq2.t())
+            dwk = N.matmul_nt(dk2.t(), xkv2.t())
+            dwv = N.matmul_nt(dv2.t(), xv2.t())
         dxq = N.matmul_nt(dq2, wq.t(), out=dz, accumulate=True)  # + the residual branch
         dxkv = N.matmul_nt(dk2, wk.t())
         dxv = None
@@ -163,7 +351,7 @@ class _MHAFn(torch.autograd.Function):
             dxv = N.matmul_nt(dv2, wv.t()).view(xv.shape)
         else:
             N.matmul_nt(dv2, wv.t(), out=dxkv, accumulate=True)
-        return (dxq.view(xq.shape), dxkv.view(xkv.shape), dwq, dwk, dwv, dfc, dg, db) + (None,) * 7 + (dxv,)
+        return (dxq.view(xq.shape), dxkv.view(xkv.shape), dwq, dwk, dwv, dfc, dg, db) + (None,) * 7 + (dxv, None)
 
 
 class _ReadoutFn(torch.autograd.Function):
@@ -182,14 +370,18 @@ class _ReadoutFn(torch.autograd.Function):
 
 def ffn_train(mod, x, seeds):
     return _FFNFn.apply(x, mod.w_1.weight, mod.w_1.bias, mod.w_2.weight, mod.w_2.bias, mod.layer_norm.weight,
-                        mod.layer_norm.bias, float(mod.dropout.p), seeds.next())
+                        mod.layer_norm.bias, float(mod.dropout.p), seeds.next(),
+                        _deferrable(mod.w_1.weight, mod.w_2.weight, mod.w_1.bias, mod.w_2.bias, mod.layer_norm.weight,
+                                    mod.layer_norm.bias))
 
 
 def mha_train(mod, xq, xkv, mask, keep, seeds, xv=None):
     fc = mod.fc.weight if hasattr(mod, 'fc') else None
     return _MHAFn.apply(xq, xkv, mod.w_qs.weight, mod.w_ks.weight, mod.w_vs.weight, fc, mod.layer_norm.weight,
                         mod.layer_norm.bias, mod.n_head, mask, keep, float(mod.attention.dropout.p),
-                        float(mod.dropout.p), seeds.next(), seeds.next(), xv)
+                        float(mod.dropout.p), seeds.next(), seeds.next(), xv,
+                        _deferrable(mod.w_qs.weight, mod.w_ks.weight, mod.w_vs.weight, fc, mod.layer_norm.weight,
+                                    mod.layer_norm.bias))
 
 
 class _LinearFn(torch.autograd.Function):

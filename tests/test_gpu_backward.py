@@ -46,6 +46,55 @@ def test_matmul_nt_split_k_is_deterministic_and_exact(dev):
     assert N_.lib().lamp_gemm_workspace_bytes(512, 384, 2880, 1) > 0
 
 
+def _gemm_one_launch_no_split(N_, a, b, accumulate_into=None):
+    """lamp_gemm without a workspace: no K split -- the summation order lamp_gemm_grouped promises."""
+    import ctypes as C
+    A, ash, ars, acs, _ = N_._operand(a)
+    Bm, bsh, brs, bcs, _ = N_._operand(b)
+    M, K, Nn = ash[2], ash[3], bsh[2]
+    out = accumulate_into if accumulate_into is not None else torch.empty(M, Nn, device=a.device)
+    d = N_.GemmDesc(A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, Nn, K, 1, 1, 1 if accumulate_into is not None else 0,
+                    ars, acs, 0, 0, brs, bcs, 0, 0, out.stride(0), 0, 0, None, 0, 1.0, 0)
+    N_.check(N_.lib().lamp_gemm(C.byref(d), None, 0, N_.stream()), 'lamp_gemm')
+    return out
+
+
+@pytest.mark.parametrize('ta,tb', [(True, True), (False, False), (True, False), (False, True)])
+def test_grouped_gemm_equals_the_single_launches_bit_for_bit(dev, ta, tb):
+    """lamp_gemm_grouped: many products in one launch (the deferred weight gradients of lamp_amd/training.py) -- every
+    result equal to lamp_gemm's unsplit launch of the same product, whatever shares the grid: mixed K depths (whole and
+    partial k-tiles, scalar-load rows), ragged tile edges, a lone tile, accumulation into an existing gradient, and
+    more problems than one kernel-argument table holds (32)."""
+    from lamp_amd import _native as N_
+    g = torch.Generator().manual_seed(11 + 2 * ta + tb)
+    shapes = [(512, 512, 2880), (512, 512, 9664), (512, 384, 2880), (64, 64, 16), (70, 130, 1000), (5, 129, 1030),
+              (1, 1, 4), (512, 512, 37), (90, 200, 333)] + [(128, 64, 160 + 16 * i) for i in range(30)]
+    ops = []
+    for M, Nn, K in shapes:
+        a = (_rand(g, K, M).t() if ta else _rand(g, M, K)).to(dev)
+        b = (_rand(g, K, Nn).t() if tb else _rand(g, Nn, K)).to(dev)
+        ops.append((a, b))
+    want = [_gemm_one_launch_no_split(N_, a, b) for a, b in ops]
+    outs = [torch.full((a.size(0), b.size(0)), float('nan'), device=dev) for a, b in ops]
+    N_.matmul_nt_grouped([(a, b, o, False) for (a, b), o in zip(ops, outs)])
+    for (M, Nn, K), o, w, (a, b) in zip(shapes, outs, want, ops):
+        assert torch.equal(o, w), (M, Nn, K)
+        assert max_abs_diff(o, a.double() @ b.double().t()) < 3e-5 * max(1.0, K ** 0.5) * 4
+    # the whole-k-tile, 16-byte-loadable subset alone takes the kernel without per-tile address arithmetic: same bits
+    fast = [i for i, (M, Nn, K) in enumerate(shapes) if K % 16 == 0 and M % 4 == 0 and Nn % 4 == 0]
+    outs2 = [torch.empty_like(outs[i]) for i in fast]
+    N_.matmul_nt_grouped([(ops[i][0], ops[i][1], o, False) for i, o in zip(fast, outs2)])
+    assert len(fast) >= 30 and all(torch.equal(o, want[i]) for i, o in zip(fast, outs2))
+    # accumulate
+    base = [_rand(g, *o.shape).to(dev) for o in outs[:9]]
+    acc = [t.clone() for t in base]
+    N_.matmul_nt_grouped([(a, b, o, True) for (a, b), o in zip(ops[:9], acc)])
+    for (a, b), t, o in zip(ops[:9], base, acc):
+        assert torch.equal(o, _gemm_one_launch_no_split(N_, a, b, accumulate_into=t.clone()))
+    with pytest.raises(ValueError):
+        N_.matmul_nt_grouped([(ops[0][0], ops[0][1], torch.empty(3, 3, device=dev), False)])
+
+
 def test_matmul_nt_batched_head_views(dev):
     """Attention-backward products straight on head-split views of [B, l, h*d] buffers and (h*B, lq, lk) maps."""
     from lamp_amd import _native as N_

@@ -83,6 +83,63 @@ def test_every_parameter_gradient_matches_oracle_autograd(dev, name):
     assert max_abs_diff(ev, logits.detach()) < 2e-5
 
 
+@pytest.mark.parametrize('dropout', [0.0, 0.1])
+def test_deferred_weight_gradients_equal_the_autograd_route(dev, dropout):
+    """lamp_amd/training.py queues dW = dY^T.X of every projection and computes them in one grouped launch when the
+    backward pass has run (train.py:40): same gradients as the per-layer route (up to the K-split's summation order),
+    identical data gradients, `.grad` accumulation across two backward passes, and nothing deferred for non-leaf
+    weights."""
+    from lamp_amd import training
+    m, sd, blocked, seq, spos, h, tgt = build(CASES['reuters_like'], dev, dropout=dropout)
+    m.train()
+
+    def grads(defer, passes=1, composite=True):
+        training.DEFER_WEIGHT_GRADS, training.COMPOSITE_CALLS = defer, composite
+        try:
+            m.zero_grad(set_to_none=True)
+            for _ in range(passes):
+                torch.manual_seed(3)
+                logits, enc, _ = m((seq.to(dev), spos.to(dev)), None, None, tgt.to(dev))
+                F.binary_cross_entropy_with_logits(logits, tgt.to(dev)).backward()
+                assert not training._weight_grads.items and not training._weight_grads.armed
+            return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            training.DEFER_WEIGHT_GRADS = training.COMPOSITE_CALLS = True
+
+    now, later, twice = grads(False), grads(True), grads(True, passes=2)
+    # one library call per sub-layer and direction (lamp_ffn_bwd, lamp_mha_bwd, ...) issues the launches of the per-launch
+    # route: every gradient bit for bit, with and without the queue
+    for defer in (False, True):
+        per_launch = grads(defer, composite=False)
+        want = later if defer else now
+        assert per_launch.keys() == want.keys()
+        for n in want:
+            if n == 'encoder.src_word_emb.weight':   # scatter-add of repeated tokens through atomics: order not fixed
+                assert max_abs_diff(per_launch[n], want[n]) <= 1e-6 * want[n].abs().max().item()
+                continue
+            assert torch.equal(per_launch[n], want[n]), (n, defer)
+    assert now.keys() == later.keys() == twice.keys() and len(now) >= 40
+    n_weights = 0
+    for n in now:
+        scale = now[n].abs().max().item()
+        assert max_abs_diff(now[n], later[n]) <= 2e-5 * scale + 1e-9, n
+        assert max_abs_diff(twice[n], 2 * later[n]) <= 4e-6 * scale + 1e-9, n
+        if n.endswith(('w_qs.weight', 'w_ks.weight', 'w_vs.weight', 'w_1.weight')) and 'encoder.layer_stack.0.slf' not in n:
+            n_weights += 1
+        else:
+            continue
+    assert n_weights >= 18
+    # biases, LayerNorm parameters, embeddings never go through the queue: bitwise the same either way
+    for n in now:
+        if n.endswith('bias') or 'layer_norm' in n or 'tgt_word' in n:
+            assert torch.equal(now[n], later[n]), n
+
+    # a non-leaf weight (what nn.DataParallel's replicas hold) keeps the autograd route
+    ffn = m.decoder.layer_stack[0].pos_ffn1
+    assert training._deferrable(ffn.w_1.weight, ffn.w_2.weight) is not None
+    assert training._deferrable(ffn.w_1.weight * 1.0, ffn.w_2.weight) is None
+
+
 def test_optimizer_step_reduces_the_loss_and_invalidates_cached_query(dev):
     """A few Adam steps of the reference's train loop (train.py:34-48) on one batch."""
     m, sd, blocked, seq, spos, h, tgt = build(CASES['tiny_prior_h4'], dev)

@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(N.PROTOTYPES) == names  # the ctypes binding covers the whole header
-    assert N.lib().lamp_version() == N.ABI_VERSION == 3
+    assert N.lib().lamp_version() == N.ABI_VERSION == 4
     # the product library exports no tuning / debug hook (those live in the -DLAMP_TUNING build only)
     exported = subprocess.run(['nm', '-D', '--defined-only', N.LIB_PATH], capture_output=True, text=True).stdout
     assert 'lamp_debug' not in exported and 'lamp_set_forward_streams' not in exported

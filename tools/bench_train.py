@@ -28,6 +28,10 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--host-profile', default=None, help='write a cProfile listing of 20 steps to this file')
+    ap.add_argument('--per-launch', action='store_true', help='one Python round trip per launch instead of one library call per sub-layer')
+    ap.add_argument('--no-defer', action='store_true', help='weight gradients through autograd, one launch (+ split-K reduce) each')
+    ap.add_argument('--fused-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of the reference's call (main.py:99)")
     a = ap.parse_args()
     from lamp_amd import _native as N
     dev = torch.device('cuda:0')
@@ -38,7 +42,11 @@ def main():
             mod.p = a.dropout
     seq, pos = seq.to(dev), pos.to(dev)
     tgt = (torch.rand(a.batch, w['L'], device=dev) < 0.05).float()
-    opt = torch.optim.Adam(model.get_trainable_parameters(), lr=2e-4, betas=(0.9, 0.98), eps=1e-9)
+    from lamp_amd import training
+    training.DEFER_WEIGHT_GRADS = not a.no_defer
+    training.COMPOSITE_CALLS = not a.per_launch
+    opt = torch.optim.Adam(model.get_trainable_parameters(), lr=2e-4, betas=(0.9, 0.98), eps=1e-9,
+                           **({'fused': True} if a.fused_adam else {}))
     model.train()
 
     def step(timers=None):
@@ -63,8 +71,21 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+    host = (time.perf_counter() - t0) / a.steps   # the issuing thread's share: what the step costs when the device never blocks it
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    if a.host_profile:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(20):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+        with open(a.host_profile, 'w') as f:
+            pstats.Stats(pr, stream=f).sort_stats('tottime').print_stats(45)
+            pstats.Stats(pr, stream=f).sort_stats('cumulative').print_stats(60)
     timers = []
     for _ in range(5):
         step(timers)
@@ -75,8 +96,9 @@ def main():
     N.prof_enable(False)
     prof = N.prof_read()
     out = {'metric': 'training samples/sec (forward + backward + Adam), %s' % a.workload, 'value': a.batch / dt,
-           'unit': 'samples/s', 'ms_per_step': dt * 1e3, 'batch': a.batch, 'dropout': a.dropout, 'steps': a.steps,
+           'unit': 'samples/s', 'ms_per_step': dt * 1e3, 'host_issue_ms_per_step': host * 1e3, 'batch': a.batch, 'dropout': a.dropout, 'steps': a.steps,
            'final_loss': float(loss.detach()), 'dtype': 'f32', 'data': 'synthetic',
+           'deferred_weight_gradients': not a.no_defer, 'composite_calls': not a.per_launch, 'optimizer': 'torch.optim.Adam' + ('(fused=True)' if a.fused_adam else ''),
            'synchronised_split_ms': {'forward': fwd * 1e3, 'backward': bwd * 1e3, 'optimizer': optim * 1e3},
            'hip_kernels_one_step': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
                                         'tflops': round(v['flops'] / v['ms'] / 1e9, 1) if v['ms'] > 0 and v['flops'] else 0.0}
