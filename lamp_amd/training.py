@@ -45,34 +45,42 @@ def _plain(*tensors):
 
 
 class _WeightGrads(object):
-    """The queue of deferred weight gradients; flushed by the autograd engine's end-of-backward callback."""
+    """The queues of deferred weight gradients, one per running backward pass (autograd graph task: a re-entrant backward
+    inside a checkpointed region is its own task); each is flushed by its task's end-of-backward callback."""
+
+    MAX_TASKS = 4   # a pass that raised never runs its callback: its queue is dropped once this many newer passes exist
 
     def __init__(self):
-        self.items = []
-        self.jobs = []
-        self.armed = False
+        self.tasks = {}   # graph-task id -> (items, jobs)
         self.lock = threading.Lock()
+
+    def _queue(self):
+        """Called under the lock from inside a backward pass: this pass's queue, its flush registered on first use."""
+        task = torch._C._current_graph_task_id()
+        q = self.tasks.get(task)
+        if q is None:
+            q = self.tasks[task] = ([], [])
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+            while len(self.tasks) > self.MAX_TASKS:
+                del self.tasks[min(self.tasks)]
+        return q
+
+    def pending(self):
+        return sum(len(i) + len(j) for i, j in self.tasks.values())
 
     def add_reductions(self, pending, grads):
         """pending = (jobs, buffers) from N.ffn_bwd / N.mha_bwd(defer_reduce=True); grads = [(parameter, tensor the jobs fill)]."""
         with self.lock:
-            self.jobs.append((pending, grads))
-            self._arm()
-
-    def _arm(self):
-        if not self.armed:
-            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
-            self.armed = True
+            self._queue()[1].append((pending, grads))
 
     def add(self, param, dy2, x2):
         """param.grad (+)= dy2^T x2  (dy2 (rows, out), x2 (rows, in); param is (out, in) or Conv1d's (out, in, 1))."""
         with self.lock:
-            self.items.append((param, dy2, x2))
-            self._arm()
+            self._queue()[0].append((param, dy2, x2))
 
     def flush(self):
         with self.lock:
-            items, self.items, jobs, self.jobs, self.armed = self.items, [], self.jobs, [], False
+            items, jobs = self.tasks.pop(torch._C._current_graph_task_id(), ([], []))
         jobs_by_dev = {}
         for pending, grads in jobs:
             jobs_by_dev.setdefault(grads[0][1].device, []).append((pending, grads))

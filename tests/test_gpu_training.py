@@ -93,7 +93,7 @@ def test_deferred_weight_gradients_equal_the_autograd_route(dev, dropout):
     m, sd, blocked, seq, spos, h, tgt = build(CASES['reuters_like'], dev, dropout=dropout)
     m.train()
 
-    def grads(defer, passes=1, composite=True):
+    def grads(defer, passes=1, composite=True, stale=0):
         training.DEFER_WEIGHT_GRADS, training.COMPOSITE_CALLS = defer, composite
         try:
             m.zero_grad(set_to_none=True)
@@ -101,7 +101,7 @@ def test_deferred_weight_gradients_equal_the_autograd_route(dev, dropout):
                 torch.manual_seed(3)
                 logits, enc, _ = m((seq.to(dev), spos.to(dev)), None, None, tgt.to(dev))
                 F.binary_cross_entropy_with_logits(logits, tgt.to(dev)).backward()
-                assert not training._weight_grads.items and not training._weight_grads.armed
+                assert training._weight_grads.pending() == stale
             return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
         finally:
             training.DEFER_WEIGHT_GRADS = training.COMPOSITE_CALLS = True
@@ -133,6 +133,20 @@ def test_deferred_weight_gradients_equal_the_autograd_route(dev, dropout):
     for n in now:
         if n.endswith('bias') or 'layer_norm' in n or 'tgt_word' in n:
             assert torch.equal(now[n], later[n]), n
+
+    # a backward pass that raised never ran its callback and leaves its queue behind: later passes are not disturbed by it,
+    # and it is dropped once MAX_TASKS newer passes have queued
+    want = grads(True)
+    training._weight_grads.tasks[-7] = ([('left over by a failed pass',)], [])
+    again = grads(True, stale=1)
+    for n in want:
+        if n != 'encoder.src_word_emb.weight':
+            assert torch.equal(want[n], again[n]), n
+    for k in range(training._WeightGrads.MAX_TASKS):
+        training._weight_grads.tasks[-6 + k] = ([('another',)], [])
+    grads(True, stale=training._WeightGrads.MAX_TASKS - 1)
+    assert -7 not in training._weight_grads.tasks
+    training._weight_grads.tasks.clear()
 
     # a non-leaf weight (what nn.DataParallel's replicas hold) keeps the autograd route
     ffn = m.decoder.layer_stack[0].pos_ffn1
