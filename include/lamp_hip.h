@@ -363,7 +363,8 @@ typedef struct lamp_mha_train_desc {
 int lamp_mha_train_fwd(const lamp_mha_train_desc* c, const lamp_mha_weights* w, const float* xq, const float* xk,
                        const float* xv, const lamp_mask* mask, float* q, float* k, float* v, float* a, float* P, float* Pd,
                        float* lse, float* o, float* y, lamp_stream_t stream);
-/* Its backward.  Outputs: dxq [B*lq, d_model]; dxk [B*lk, d_model] (+ the value branch when dxv is NULL, else dxv gets it);
+/* Its backward.  Outputs: dxq [B*lq, d_model]; dxk [B*lk, d_model] (+ the value branch when dxv is NULL, else dxv gets it;
+ * dxk == dxq is allowed when lq == lk -- self-attention, xq and xk one tensor: dxq then holds the SUM of the three branches);
  * dgamma, dbeta.  Left behind for deferred weight gradients: d_o [B*lq, d_model] (required iff p_out > 0), dq [B*lq, H*d_k],
  * dk [B*lk, H*d_k], dv [B*lk, H*d_v]; dwq / dwk / dwv [H*d_*, d_model], dfc [d_model, H*d_v] nullable (dfc required when
  * w->fc is set and p_out == 0).  Pd: the forward's dropout(P) (saved; required iff p_attn > 0).  Scratch: da [B*lq, H*d_v]

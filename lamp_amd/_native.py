@@ -644,8 +644,9 @@ def mha_train_fwd(desc, xq, xk, xv, wq, wk, wv, fc, ln_g, ln_b, mask_struct):
 
 
 def mha_bwd(desc, xq, xk, xv, q, k, v, a, P, Pd, o, dy, wq, wk, wv, fc, ln_g, separate_value_source, want_dw, want_dfc,
-            defer_reduce=False):
-    """lamp_mha_bwd -> dict of gradients and of the buffers deferred weight gradients are computed from; with defer_reduce,
+            defer_reduce=False, shared_qk=False):
+    """lamp_mha_bwd -> dict of gradients and of the buffers deferred weight gradients are computed from; shared_qk: xq and xk
+    are one tensor (self-attention) -- r['dxq'] is then its whole gradient and r['dxk'] None; with defer_reduce,
     r['pending'] = ([job], buffers to keep alive): dgamma / dbeta are finished by reduce_partials_grouped later."""
     B, lq, lk, d, H, dk, dv = desc.B, desc.lq, desc.lk, desc.d_model, desc.n_head, desc.d_k, desc.d_v
     dev = xq.device
@@ -657,7 +658,7 @@ def mha_bwd(desc, xq, xk, xv, q, k, v, a, P, Pd, o, dy, wq, wk, wv, fc, ln_g, se
     da = e((B * lq, H * dv), **f) if fc is not None else None
     dP = e((H * B, lq, lk), **f)
     r['dq'], r['dk'], r['dv'] = e((B * lq, H * dk), **f), e((B * lk, H * dk), **f), e((B * lk, H * dv), **f)
-    r['dxk'] = e((B * lk, d), **f)
+    r['dxk'] = r['dxq'] if shared_qk else e((B * lk, d), **f)
     r['dxv'] = e((B * lk, d), **f) if separate_value_source else None
     vec = e((2 * d,), **f)
     r['dgamma'], r['dbeta'] = vec[:d], vec[d:]
@@ -680,6 +681,8 @@ def mha_bwd(desc, xq, xk, xv, q, k, v, a, P, Pd, o, dy, wq, wk, wv, fc, ln_g, se
                          r['dgamma'].data_ptr(), r['dbeta'].data_ptr(), _dp(r['dwq']), _dp(r['dwk']), _dp(r['dwv']),
                          _dp(r['dfc']), ptr(ws), nb, ptr(part), npb, job, stream()), 'lamp_mha_bwd')
     r['pending'] = ([job[0]], (part, vec)) if defer_reduce else None
+    if shared_qk:   # r['dxq'] is the gradient of the one tensor behind xq and xk
+        r['dxk'] = None
     if r['d_o'] is None:
         r['d_o'] = r['dxq']
     return r

@@ -765,7 +765,8 @@ int lamp_mha_bwd(const lamp_mha_train_desc* c, const lamp_mha_weights* w, const 
     if (dwv) LAMP_CK(gg(cols(dv_, hdv), cols(xv, d), dwv, d, 0, 0, hdv, d, Mk, 1, 1, false, nullptr, ws, wsb, s));
     // (*) data gradients of the three projections
     LAMP_CK(gg(rows(dq, hdk), cols(w->w_qs, d), dxq, d, 0, 0, Mq, d, hdk, 1, 1, true, nullptr, ws, wsb, s));
-    LAMP_CK(gg(rows(dk_, hdk), cols(w->w_ks, d), dxk, d, 0, 0, Mk, d, hdk, 1, 1, false, nullptr, ws, wsb, s));
+    // dxk == dxq (self-attention: query and key source are one tensor): its gradient is the sum, accumulated in place
+    LAMP_CK(gg(rows(dk_, hdk), cols(w->w_ks, d), dxk, d, 0, 0, Mk, d, hdk, 1, 1, dxk == dxq, nullptr, ws, wsb, s));
     if (dxv) return gg(rows(dv_, hdv), cols(w->w_vs, d), dxv, d, 0, 0, Mk, d, hdv, 1, 1, false, nullptr, ws, wsb, s);
     return gg(rows(dv_, hdv), cols(w->w_vs, d), dxk, d, 0, 0, Mk, d, hdv, 1, 1, true, nullptr, ws, wsb, s);
 }

@@ -250,7 +250,10 @@ class _MHAFn(torch.autograd.Function):
                 xv=None, defer=None):
         """xkv: the key source and, unless ``xv`` is given, the value source too (every layer of the reference passes one
         tensor for both, lamp/Layers.py:16,35,40; the module itself accepts two, lamp/SubLayers.py:77-93)."""
-        ctx.defer = defer   # (wq, wk, wv, fc) as the leaf Parameters, or None
+        ctx.defer = defer   # (wq, wk, wv, fc, ln_g, ln_b) as the leaf Parameters, or None
+        # self-attention: one tensor is query, key and value source -- its three gradient branches are summed in place by the
+        # backward call instead of by an autograd add launch
+        ctx.shared_qk = xq is xkv and xv is None
         B, lq, d = xq.shape
         lk = xkv.size(1)
         H = n_head
@@ -301,7 +304,7 @@ class _MHAFn(torch.autograd.Function):
                                   seed_out & 0xffffffff)
             r = N.mha_bwd(desc, xq, xkv, xv if has_xv else xkv, q, k, v, a, P, ctx.Pd, o if has_fc else None,
                           dy.reshape(B * lq, d).contiguous(), wq, wk, wv, fc if has_fc else None, ln_g, has_xv, not wait,
-                          not wait_fc, defer_reduce=wait)
+                          not wait_fc, defer_reduce=wait, shared_qk=ctx.shared_qk)
             if r['pending'] is not None:
                 _weight_grads.add_reductions(r['pending'], [(defer[4], r['dgamma']), (defer[5], r['dbeta'])])
                 r['dgamma'] = r['dbeta'] = None
@@ -312,7 +315,7 @@ class _MHAFn(torch.autograd.Function):
                 _weight_grads.add(defer[2], r['dv'], xv.view(-1, d) if has_xv else xkv2)
             if wait_fc and has_fc:
                 _weight_grads.add(defer[3], r['d_o'], a.view(-1, H * dv))
-            return (r['dxq'].view(xq.shape), r['dxk'].view(xkv.shape), r['dwq'], r['dwk'], r['dwv'], r['dfc'], r['dgamma'],
+            return (r['dxq'].view(xq.shape), None if ctx.shared_qk else r['dxk'].view(xkv.shape), r['dwq'], r['dwk'], r['dwv'], r['dfc'], r['dgamma'],
                     r['dbeta']) + (None,) * 7 + (r['dxv'].view(xv.shape) if has_xv else None, None)
         xq2, xkv2 = xq.reshape(-1, d), xkv.reshape(-1, d)
         xv2 = xv.reshape(-1, d) if has_xv else xkv2
@@ -353,6 +356,10 @@ class _MHAFn(torch.autograd.Function):
             dwk = N.matmul_nt(dk2.t(), xkv2.t())
             dwv = N.matmul_nt(dv2.t(), xv2.t())
         dxq = N.matmul_nt(dq2, wq.t(), out=dz, accumulate=True)  # + the residual branch
+        if ctx.shared_qk:   # one tensor behind query, key and value: the three branches summed in place (as lamp_mha_bwd does)
+            N.matmul_nt(dk2, wk.t(), out=dxq, accumulate=True)
+            N.matmul_nt(dv2, wv.t(), out=dxq, accumulate=True)
+            return (dxq.view(xq.shape), None, dwq, dwk, dwv, dfc, dg, db) + (None,) * 7 + (None, None)
         dxkv = N.matmul_nt(dk2, wk.t())
         dxv = None
         if has_xv:

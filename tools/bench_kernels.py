@@ -226,6 +226,25 @@ def gemm_gen():
         for name, fn, m_, n_, k_ in cases:
             us = time_fn(fn, iters=20)
             print('%-34s %10.1f %10.1f   (%d x %d x %d)' % (name, us, 2.0 * m_ * n_ * k_ / us / 1e6, m_, n_, k_))
+    # the weight gradients of one reuters training step (28 products: 8 over the 9664 token rows, 20 over the 2880 label
+    # rows, 512 x 512 each): one split-K launch + reduce each, against ONE grouped launch (lamp_gemm_grouped)
+    ops = []
+    for rows_, count in ((9664, 8), (2880, 20)):
+        for _ in range(count):
+            ops.append((torch.randn(rows_, 512, device=dev), torch.randn(rows_, 512, device=dev)))
+    outs = [torch.empty(512, 512, device=dev) for _ in ops]
+    flop = sum(2.0 * 512 * 512 * a.size(0) for a, _ in ops)
+
+    def one_by_one():
+        for (dy_, x_), o in zip(ops, outs):
+            N.matmul_nt(dy_.t(), x_.t(), out=o)
+
+    def grouped():
+        N.matmul_nt_grouped([(dy_.t(), x_.t(), o, False) for (dy_, x_), o in zip(ops, outs)])
+
+    for name, fn in (('28 wgrads, split-K + reduce each', one_by_one), ('28 wgrads, one grouped launch', grouped)):
+        us = time_fn(fn, iters=10)
+        print('%-34s %10.1f %10.1f   (%.1f GFLOP)' % (name, us, flop / us / 1e6, flop / 1e9))
 
 
 def steady():

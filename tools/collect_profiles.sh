@@ -51,6 +51,11 @@ for wl in reuters bibtex delicious; do
   done
 done
 python tools/bench_train.py > "$OUT/train_reuters.json" 2>/dev/null
+python tools/bench_train.py --per-launch --no-defer > "$OUT/train_reuters_per_launch_autograd_route.json" 2>/dev/null
+python tools/bench_train.py --per-launch > "$OUT/train_reuters_per_launch_deferred.json" 2>/dev/null
+python tools/bench_train.py --no-defer > "$OUT/train_reuters_composite_not_deferred.json" 2>/dev/null
+python tools/bench_train.py --fused-adam > "$OUT/train_reuters_fused_adam.json" 2>/dev/null
+python tools/bench_train.py --host-profile "$OUT/train_host_profile.txt" > /dev/null 2>&1
 python tests/time_oracle_train_step.py > "$OUT/train_reuters_cpu_oracle.json" 2>/dev/null
 python tools/bench_train.py --workload delicious --steps 5 --warmup 2 > "$OUT/train_delicious.json" 2>/dev/null
 python tools/bench_kernels.py gemm_gen 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_gen.txt"
