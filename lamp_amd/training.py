@@ -22,6 +22,7 @@ are stored in (or accumulated into) the parameters' ``.grad`` -- what ``optimize
 Only leaf parameters are deferred; anything else (``nn.DataParallel`` replicas, ``torch.autograd.grad`` on a sub-module
 called directly) gets its gradient through autograd as before.
 """
+import contextlib
 import threading
 
 import torch
@@ -42,6 +43,10 @@ def _plain(*tensors):
         if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             return False
     return True
+
+
+def _on(dev):
+    return torch.cuda.device(dev) if dev.type == 'cuda' else contextlib.nullcontext()
 
 
 class _WeightGrads(object):
@@ -85,7 +90,7 @@ class _WeightGrads(object):
         for pending, grads in jobs:
             jobs_by_dev.setdefault(grads[0][1].device, []).append((pending, grads))
         for dev, todo in jobs_by_dev.items():   # the second stages of every LayerNorm-parameter / bias gradient: one launch
-            with torch.cuda.device(dev), torch.no_grad():
+            with _on(dev), torch.no_grad():
                 N.reduce_partials_grouped([j for pending, _ in todo for j in pending[0]])
                 for _, grads in todo:
                     for param, t in grads:
@@ -97,7 +102,7 @@ class _WeightGrads(object):
         for it in items:
             by_dev.setdefault(it[1].device, []).append(it)
         for dev, todo in by_dev.items():
-            with torch.cuda.device(dev), torch.no_grad():
+            with _on(dev), torch.no_grad():
                 while todo:
                     seen, batch, rest = set(), [], []
                     for it in todo:   # a parameter used twice: its second product accumulates in a later launch
