@@ -95,6 +95,39 @@ def test_grouped_gemm_equals_the_single_launches_bit_for_bit(dev, ta, tb):
         N_.matmul_nt_grouped([(ops[0][0], ops[0][1], torch.empty(3, 3, device=dev), False)])
 
 
+def test_training_composites_validate_their_arguments(dev):
+    """lamp_ffn_bwd / lamp_mha_bwd / lamp_reduce_partials_grouped return status codes, never launch on bad input."""
+    import ctypes as C
+    from lamp_amd import _native as N_
+    L = N_.lib()
+    M, d, dff = 24, 32, 64
+    t = lambda *s: torch.randn(*s, device=dev)   # noqa: E731
+    x, h, o, dy, w1, w2, g = t(M, d), t(M, dff), t(M, d), t(M, d), t(dff, d), t(d, dff), t(d)
+    with pytest.raises(N_.LampError) as e:
+        N_.ffn_bwd(x, h, o, dy, w1, w2, g, 1.5, 0, True, True)
+    assert e.value.status == -4                                   # LAMP_E_UNSUPPORTED: dropout probability
+    with pytest.raises(N_.LampError) as e:
+        N_.ffn_bwd(x, h, o, dy, w1, w2, g, 0.0, 0, True, False)   # without dropout d_o IS dx: dW2 cannot be deferred
+    assert e.value.status == -4
+    wts = N_.FfnWeights(w1.data_ptr(), None, w2.data_ptr(), None, g.data_ptr(), None)
+    out = [t(M, d), t(M, d), t(M, dff), t(dff), t(d), t(d), t(d)]
+    rc = L.lamp_ffn_bwd(x.data_ptr(), h.data_ptr(), o.data_ptr(), dy.data_ptr(), M, d, dff, C.byref(wts), 0.1, 7,
+                        out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None, None, out[3].data_ptr(),
+                        out[4].data_ptr(), out[5].data_ptr(), out[6].data_ptr(), None, 0, None, 0, None, N_.stream())
+    assert rc == -3                                               # LAMP_E_WORKSPACE
+    desc = N_.MhaTrainDesc(2, 5, 7, 32, 2, 16, 16, 0.25, 0.0, 0.0, 1, 2)
+    assert L.lamp_mha_bwd_workspace_bytes(C.byref(desc)) > 0 and L.lamp_mha_bwd_partials_bytes(C.byref(desc)) > 0
+    desc_wide = N_.MhaTrainDesc(2, 5, 7, 32, 1, 256, 256, 0.25, 0.0, 0.0, 1, 2)
+    q = t(2, 5, 256)
+    wts = N_.MhaWeights(q.data_ptr(), q.data_ptr(), q.data_ptr(), None, g.data_ptr(), g.data_ptr(), 1, 1)
+    rc = L.lamp_mha_train_fwd(C.byref(desc_wide), C.byref(wts), *([q.data_ptr()] * 3), None, *([q.data_ptr()] * 9),
+                              N_.stream())
+    assert rc == -4                                               # wide heads: the per-launch route
+    job = N_.ReduceJob(x.data_ptr(), 0, 8, (C.c_void_p * 3)(x.data_ptr(), None, None), 4, 0)
+    assert L.lamp_reduce_partials_grouped((N_.ReduceJob * 1)(job), 1, N_.stream()) == -1   # LAMP_E_DIMS
+    assert L.lamp_reduce_partials_grouped(None, 0, N_.stream()) == 0
+
+
 def test_matmul_nt_batched_head_views(dev):
     """Attention-backward products straight on head-split views of [B, l, h*d] buffers and (h*B, lq, lk) maps."""
     from lamp_amd import _native as N_
