@@ -36,7 +36,6 @@ struct GenParams {
     int64_t ldc, c_b0, c_b1;
     int M, N, K;
     int nb1;          // z = z0 * nb1 + z1
-    int vecA, vecB;   // 16-byte loads legal for this operand
     float alpha;
     int accumulate;
     const float* mask;  // relu'(mask > 0) applied to the result, same indexing as C (ld = ldm), or nullptr
@@ -77,8 +76,8 @@ __device__ __forceinline__ float4 stage_load(__amdgpu_buffer_rsrc_t rs, int tid,
 // invariant (OOB for the threads without a share of a 32-row operand), the k-tile's base rides in the instruction's SCALAR offset
 // -- the descriptor's range check covers voffset + soffset (tools/probes/lds_dma_oob.hip).  The per-tile offset arithmetic and
 // bound selects of stage_load() were 36-66 vector instructions per two k-tiles, i.e. +17...+63 % on the MFMAs' time: on gfx950
-// a vector instruction is not hidden under fp32 MFMAs (profiles/r05_mfma_chain.txt).  Valid for 16-byte-aligned operands; a row
-// operand's LAST, partial k-tile still takes stage_load() (its k bound is not the descriptor's).
+// a vector instruction is not hidden under fp32 MFMAs (profiles/r05_mfma_chain.txt).  Any dword-aligned operand (see TAIL below); a
+// row operand's LAST, partial k-tile still takes stage_load() (its k bound is not the descriptor's).
 template <bool COL, int ROWS>
 __device__ __forceinline__ unsigned stage_voff(int tid, int64_t ld) {
     if (ROWS < 64 && tid >= ROWS * 4) return OOB;
@@ -110,10 +109,15 @@ __device__ __forceinline__ float4 frag(const float* lds, int row, int hi) {
     return v;
 }
 
-// FAST: both operands 16-byte loadable and every k-tile of every split whole (K a multiple of 16) -- the host's choice; the
-// loads then carry no per-tile vector arithmetic (stage_voff).
-// One output tile: `tile` of the problem's tiles_m x tiles_n grid, batch index zy, K split `split`.
-template <int GM, int GN, int WM, int WN, bool TA, bool TB, bool FAST>
+// TAIL: K leaves a partial last k-tile AND at least one operand is a row operand (k contiguous): that one tile of that operand
+// takes stage_load()'s per-element bounds (its k bound is not the descriptor's); a column operand's rows past K fail the range
+// check by themselves.  Every other load is stage_voff()'s: no per-tile vector arithmetic.  16-byte loads need only dword
+// alignment on gfx950 (tools/probes/unaligned_b128.hip, profiles/r05_unaligned_b128.txt) and are range-checked dword by dword
+// (a float4 that straddles the end of the descriptor returns its valid part: profiles/r05_lds_dma_oob.txt), so there is no
+// alignment condition left: the probability maps of 302 keys (1208-byte rows), head-split views, ragged edges all load this way.
+// A float4 of a column operand that overshoots the tile's valid columns reads its in-range neighbours: they only feed output rows
+// / columns that are never stored.
+template <int GM, int GN, int WM, int WN, bool TA, bool TB, bool TAIL>
 __device__ __forceinline__ void gemm_gen_tile(const GenParams& p, int tiles_n, int tile, int zy, int split) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int WTM = GM / WM, WTN = GN / WN, MI = WTM / 16, NI = WTN / 16;
@@ -152,12 +156,12 @@ __device__ __forceinline__ void gemm_gen_tile(const GenParams& p, int tiles_n, i
     const unsigned kstepA = TA ? unsigned(lda) * 4u : 4u, kstepB = TB ? unsigned(ldb) * 4u : 4u;   // bytes per unit of k
     auto gload = [&](int kt, float4& ra, float4& rb) {
         const int k0 = k_begin + kt * GK;
-        if constexpr (FAST) {
+        if (TAIL && k0 + GK > k_end) {   // wave-uniform: the one partial k-tile (the last tile of the last split)
+            ra = TA ? bload4(rsA, voffA, unsigned(k0) * kstepA) : stage_load<TA, GM>(rsA, tid, k0, k_end, lda, false);
+            rb = TB ? bload4(rsB, voffB, unsigned(k0) * kstepB) : stage_load<TB, GN>(rsB, tid, k0, k_end, ldb, false);
+        } else {
             ra = bload4(rsA, voffA, unsigned(k0) * kstepA);
             rb = bload4(rsB, voffB, unsigned(k0) * kstepB);
-        } else {
-            ra = stage_load<TA, GM>(rsA, tid, k0, k_end, lda, p.vecA);
-            rb = stage_load<TB, GN>(rsB, tid, k0, k_end, ldb, p.vecB);
         }
     };
     auto lstore = [&](int buf, const float4& ra, const float4& rb) {
@@ -240,9 +244,9 @@ __device__ __forceinline__ void gemm_gen_tile(const GenParams& p, int tiles_n, i
         }
 }
 
-template <int GM, int GN, int WM, int WN, bool TA, bool TB, bool FAST>
+template <int GM, int GN, int WM, int WN, bool TA, bool TB, bool TAIL>
 __global__ __launch_bounds__(256) void gemm_gen_kernel(GenParams p, int tiles_n) {
-    gemm_gen_tile<GM, GN, WM, WN, TA, TB, FAST>(p, tiles_n, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y, blockIdx.z);
+    gemm_gen_tile<GM, GN, WM, WN, TA, TB, TAIL>(p, tiles_n, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y, blockIdx.z);
 }
 
 // Grouped launch: up to GROUP_MAX independent products (no batch dims, no K split, no ReLU mask) share ONE grid of 64 x 64
@@ -260,7 +264,6 @@ struct GroupProblem {
     int lda, ldb, ldc;   // lda / ldb: the non-unit stride of the operand
     int M, N, K;
     int tiles_n, tiles;
-    int vec;             // bit 0: A 16-byte loadable, bit 1: B
     float alpha;
     int accumulate;
 };
@@ -270,7 +273,7 @@ struct GroupParams {
     int n;
 };
 
-template <bool TA, bool TB, bool FAST>
+template <bool TA, bool TB, bool TAIL>
 __global__ __launch_bounds__(256) void gemm_group_kernel(GroupParams g) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     int idx = 0;
@@ -290,15 +293,13 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GroupParams g) {
     p.N = q.N;
     p.K = q.K;
     p.nb1 = 1;
-    p.vecA = q.vec & 1;
-    p.vecB = (q.vec >> 1) & 1;
     p.alpha = q.alpha;
     p.accumulate = q.accumulate;
     p.mask = nullptr;
     p.ldm = 0;
     p.k_chunk = q.K;
     p.part = nullptr;
-    gemm_gen_tile<64, 64, 2, 2, TA, TB, FAST>(p, q.tiles_n, tile, 0, 0);
+    gemm_gen_tile<64, 64, 2, 2, TA, TB, TAIL>(p, q.tiles_n, tile, 0, 0);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, int M, int N,
@@ -370,12 +371,6 @@ int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStrea
     p.N = d.N;
     p.K = d.K;
     p.nb1 = d.batch1;
-    // 16-byte loads: aligned rows, and no float4 may straddle the valid edge of its contiguous index
-    auto vec_ok = [&](const float* ptr, int64_t ld, int64_t b0, int64_t b1, int contiguous_extent) {
-        return aligned16(ptr) && (ld & 3) == 0 && (b0 & 3) == 0 && (b1 & 3) == 0 && (contiguous_extent & 3) == 0;
-    };
-    p.vecA = vec_ok(d.A, lda, d.a_batch0, d.a_batch1, ta ? d.M : d.K);
-    p.vecB = vec_ok(d.B, ldb, d.b_batch0, d.b_batch1, tb ? d.N : d.K);
     p.alpha = d.alpha;
     p.accumulate = d.accumulate;
     p.mask = d.relu_mask;
@@ -403,24 +398,24 @@ int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStrea
     const double bytes = 4.0 * double(batch) * (double(d.M) * d.K + double(d.N) * d.K + double(d.M) * d.N);
     ProfScope prof(LAMP_K_GEMM, flops, bytes, s);
     const dim3 grid((unsigned)tiles, (unsigned)batch, (unsigned)nsplit);
-    // whole k-tiles everywhere (the split size is a multiple of GK, so only K itself can leave a partial one) and 16-byte loads
-    const bool fast = p.vecA && p.vecB && (d.K % GK) == 0;
-#define LAMP_GEN_LAUNCH(GM_, WM_, WN_, FAST_)                                                                               \
+    // only K itself can leave a partial k-tile (the split size is a multiple of GK), and only a row operand needs help with it
+    const bool tail = (d.K % GK) != 0 && (!ta || !tb);
+#define LAMP_GEN_LAUNCH(GM_, WM_, WN_, TAIL_)                                                                               \
     do {                                                                                                                     \
         if (ta && tb)                                                                                                        \
-            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, true, true, FAST_>), grid, dim3(256), 0, s, p, tiles_n);   \
+            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, true, true, false>), grid, dim3(256), 0, s, p, tiles_n);   \
         else if (ta)                                                                                                         \
-            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, true, false, FAST_>), grid, dim3(256), 0, s, p, tiles_n);  \
+            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, true, false, TAIL_>), grid, dim3(256), 0, s, p, tiles_n);  \
         else if (tb)                                                                                                         \
-            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, false, true, FAST_>), grid, dim3(256), 0, s, p, tiles_n);  \
+            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, false, true, TAIL_>), grid, dim3(256), 0, s, p, tiles_n);  \
         else                                                                                                                 \
-            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, false, false, FAST_>), grid, dim3(256), 0, s, p, tiles_n); \
+            hipLaunchKernelGGL((gemm_gen_kernel<GM_, 64, WM_, WN_, false, false, TAIL_>), grid, dim3(256), 0, s, p, tiles_n); \
     } while (0)
-    if (gm == 32 && fast)
+    if (gm == 32 && tail)
         LAMP_GEN_LAUNCH(32, 1, 4, true);
     else if (gm == 32)
         LAMP_GEN_LAUNCH(32, 1, 4, false);
-    else if (fast)
+    else if (tail)
         LAMP_GEN_LAUNCH(64, 2, 2, true);
     else
         LAMP_GEN_LAUNCH(64, 2, 2, false);
@@ -444,7 +439,7 @@ int launch_gemm_group(const lamp_gemm_desc* descs, int n, hipStream_t s) {
         GroupParams g;
         g.n = cnt;
         g.share_begin[0] = 0;
-        bool ta0 = false, tb0 = false, fast = true;
+        bool ta0 = false, tb0 = false, tail = false;
         double flops = 0, bytes = 0;
         for (int i = 0; i < cnt; ++i) {
             const lamp_gemm_desc& d = descs[first + i];
@@ -461,9 +456,7 @@ int launch_gemm_group(const lamp_gemm_desc* descs, int n, hipStream_t s) {
             const int64_t span_b = tb ? int64_t(d.K) * ldb : int64_t(64) * ldb + d.K;
             if (span_a * 4 >= 0x7fffffffLL || span_b * 4 >= 0x7fffffffLL || int64_t(64) * d.ldc * 4 >= 0x7fffffffLL)
                 return LAMP_E_UNSUPPORTED;
-            const bool va = aligned16(d.A) && (lda & 3) == 0 && ((ta ? d.M : d.K) & 3) == 0;
-            const bool vb = aligned16(d.B) && (ldb & 3) == 0 && ((tb ? d.N : d.K) & 3) == 0;
-            fast = fast && va && vb && (d.K % GK) == 0;
+            tail = tail || ((d.K % GK) != 0 && (!ta || !tb));
             GroupProblem& q = g.prob[i];
             q.A = d.A;
             q.B = d.B;
@@ -478,7 +471,6 @@ int launch_gemm_group(const lamp_gemm_desc* descs, int n, hipStream_t s) {
             const int64_t tiles = int64_t((d.M + 63) / 64) * q.tiles_n;
             if (tiles > (1 << 24)) return LAMP_E_DIMS;
             q.tiles = int(tiles);
-            q.vec = (va ? 1 : 0) | (vb ? 2 : 0);
             q.alpha = d.alpha;
             q.accumulate = d.accumulate;
             g.share_begin[i + 1] = g.share_begin[i] + (q.tiles + 7) / 8;
@@ -488,18 +480,18 @@ int launch_gemm_group(const lamp_gemm_desc* descs, int n, hipStream_t s) {
         for (int i = cnt; i < GROUP_MAX; ++i) g.share_begin[i + 1] = g.share_begin[cnt];
         ProfScope prof(LAMP_K_GEMM, flops, bytes, s);
         const dim3 grid(unsigned(g.share_begin[cnt]) * 8u);
-#define LAMP_GROUP_LAUNCH(FAST_)                                                                                   \
+#define LAMP_GROUP_LAUNCH(TAIL_)                                                                                   \
     do {                                                                                                            \
         if (ta0 && tb0)                                                                                             \
-            hipLaunchKernelGGL((gemm_group_kernel<true, true, FAST_>), grid, dim3(256), 0, s, g);                   \
+            hipLaunchKernelGGL((gemm_group_kernel<true, true, false>), grid, dim3(256), 0, s, g);                   \
         else if (ta0)                                                                                               \
-            hipLaunchKernelGGL((gemm_group_kernel<true, false, FAST_>), grid, dim3(256), 0, s, g);                  \
+            hipLaunchKernelGGL((gemm_group_kernel<true, false, TAIL_>), grid, dim3(256), 0, s, g);                  \
         else if (tb0)                                                                                               \
-            hipLaunchKernelGGL((gemm_group_kernel<false, true, FAST_>), grid, dim3(256), 0, s, g);                  \
+            hipLaunchKernelGGL((gemm_group_kernel<false, true, TAIL_>), grid, dim3(256), 0, s, g);                  \
         else                                                                                                        \
-            hipLaunchKernelGGL((gemm_group_kernel<false, false, FAST_>), grid, dim3(256), 0, s, g);                 \
+            hipLaunchKernelGGL((gemm_group_kernel<false, false, TAIL_>), grid, dim3(256), 0, s, g);                 \
     } while (0)
-        if (fast)
+        if (tail)
             LAMP_GROUP_LAUNCH(true);
         else
             LAMP_GROUP_LAUNCH(false);
