@@ -306,6 +306,24 @@ def cpu_baseline(w, sd, adj, seq, pos, budget_s=20.0):
     }
 
 
+def training_step_line(timeout=120):
+    """SURVEY.md 8f n4 beside the forward metric: the reference's train-loop body (train.py:34-48: forward with dropout, BCE,
+    loss.backward(), torch.optim.Adam step) on the headline model, batch 32 -- tools/bench_train.py in a child process (its own
+    import and build of the model; ~10 s), bounded, never part of `value`.  -> the child's line, trimmed, or a 'skipped' note."""
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'bench_train.py'), '--steps', '30', '--warmup', '5']
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout, check=True,
+                             cwd=ROOT).stdout.decode()
+        d = json.loads(out.strip().splitlines()[-1])
+        keep = ('metric', 'value', 'unit', 'ms_per_step', 'host_issue_ms_per_step', 'batch', 'dropout', 'steps', 'dtype', 'data',
+                'optimizer', 'deferred_weight_gradients', 'composite_calls', 'synchronised_split_ms')
+        line = {k: d[k] for k in keep if k in d}
+        line['command'] = 'python tools/bench_train.py --steps 30 --warmup 5 (child process of this invocation)'
+        return line
+    except Exception as e:   # the forward line must not depend on this leg
+        return {'skipped': '%s: %s' % (type(e).__name__, str(e)[:200])}
+
+
 def warm_device(step, seconds=DEVICE_WARMUP_S):
     """Keep the device busy for a fixed wall time so the timed region does not measure the clock ramp.  Steps longer than
     an eighth of that time (the 1024-sample share of configs[4]: seconds each) are issued one at a time."""
@@ -850,6 +868,7 @@ def main():
         mr.clear()
         torch.cuda.empty_cache()
         result['workloads'] = extra
+        result['training_step'] = training_step_line()
         m.update(sd=sd_h, adj=adj_h, seq=seq_h, pos=pos_h)
 
     if n_gpus == 1 and not args.no_cpu_baseline:

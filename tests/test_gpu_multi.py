@@ -104,6 +104,18 @@ def test_bench_kernel_only_fraction_is_measured_in_the_run(dev):
     assert any('attn16_kernel' in k for k in att['by_kernel'])
 
 
+def test_bench_line_carries_the_training_step(dev):
+    """bench.py's default line reports the train-loop body beside the forward metric, measured in a child
+    process of the same invocation: the leg itself."""
+    import bench
+    line = bench.training_step_line()
+    assert 'skipped' not in line, line
+    assert line['batch'] == 32 and line['dropout'] == 0.1 and line['optimizer'] == 'torch.optim.Adam'
+    assert line['deferred_weight_gradients'] is True and line['composite_calls'] is True
+    assert 1.0 < line['ms_per_step'] < 20.0 and abs(line['value'] - 32 / (line['ms_per_step'] * 1e-3)) < 1e-6 * line['value']
+    assert 0.0 < line['host_issue_ms_per_step'] <= line['ms_per_step'] * 1.02
+
+
 def test_bench_and_eval_with_eight_ranks_on_one_device(dev, tmp_path):
     """The rank count the driver's scaling run uses (batch shards over 8 GPUs), as far as one GPU allows:
     eight self-spawned ranks over gloo sharing this box's device -- every rank reports, rank 0 recomputes the first samples
