@@ -83,14 +83,15 @@ def test_every_parameter_gradient_matches_oracle_autograd(dev, name):
     assert max_abs_diff(ev, logits.detach()) < 2e-5
 
 
+@pytest.mark.parametrize('case', ['reuters_like', 'tiny_none_h1', 'inveye_h8'])
 @pytest.mark.parametrize('dropout', [0.0, 0.1])
-def test_deferred_weight_gradients_equal_the_autograd_route(dev, dropout):
+def test_deferred_weight_gradients_equal_the_autograd_route(dev, dropout, case):
     """lamp_amd/training.py queues dW = dY^T.X of every projection and computes them in one grouped launch when the
     backward pass has run (train.py:40): same gradients as the per-layer route (up to the K-split's summation order),
     identical data gradients, `.grad` accumulation across two backward passes, and nothing deferred for non-leaf
     weights."""
     from lamp_amd import training
-    m, sd, blocked, seq, spos, h, tgt = build(CASES['reuters_like'], dev, dropout=dropout)
+    m, sd, blocked, seq, spos, h, tgt = build(CASES[case], dev, dropout=dropout)
     m.train()
 
     def grads(defer, passes=1, composite=True, stale=0):
