@@ -647,21 +647,18 @@ int lamp_mha_train_fwd(const lamp_mha_train_desc* c, const lamp_mha_weights* w, 
     hipStream_t s = hipStream_t(stream);
     const int hdk = H * dk, hdv = H * dv;
     const int64_t Mq = int64_t(B) * lq, Mk = int64_t(B) * lk;
-    if (xq == xk && xk == xv && hdk == hdv) {   // self-attention: the three projections as segments of one launch (same bits)
+    // the projections that share their input go out as segments of one launch (same bits as one launch each)
+    const bool one_kv = xk == xv && hdk == hdv, one_qkv = one_kv && xq == xk && lq == lk;
+    {
         const float* W[3] = {w->w_qs, w->w_ks, w->w_vs};
         float* C[3] = {q, k, v};
-        LAMP_CK(linear(xq, Mq, d, d, W, 3, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
-    } else {
-        const float* W[1] = {w->w_qs};
-        float* C[1] = {q};
-        LAMP_CK(linear(xq, Mq, d, d, W, 1, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
+        LAMP_CK(linear(xq, Mq, d, d, W, one_qkv ? 3 : 1, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
     }
-    if (xq == xk && xk == xv && hdk == hdv) {
-    } else if (xk == xv && hdk == hdv) {
+    if (!one_qkv && one_kv) {
         const float* W[2] = {w->w_ks, w->w_vs};
         float* C[2] = {k, v};
         LAMP_CK(linear(xk, Mk, d, d, W, 2, hdk, d, nullptr, nullptr, 0, 0, C, hdk, s));
-    } else {
+    } else if (!one_qkv) {
         const float* Wk[1] = {w->w_ks};
         float* Ck[1] = {k};
         LAMP_CK(linear(xk, Mk, d, d, Wk, 1, hdk, d, nullptr, nullptr, 0, 0, Ck, hdk, s));
