@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--host-profile', default=None, help='write a cProfile listing of 20 steps to this file')
     ap.add_argument('--per-launch', action='store_true', help='one Python round trip per launch instead of one library call per sub-layer')
+    ap.add_argument('--single-thread-autograd', action='store_true', help='torch.autograd.set_multithreading_enabled(False): backward on the calling thread')
     ap.add_argument('--no-defer', action='store_true', help='weight gradients through autograd, one launch (+ split-K reduce) each')
     ap.add_argument('--fused-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of the reference's call (main.py:99)")
     a = ap.parse_args()
@@ -48,6 +49,8 @@ def main():
     opt = torch.optim.Adam(model.get_trainable_parameters(), lr=2e-4, betas=(0.9, 0.98), eps=1e-9,
                            **({'fused': True} if a.fused_adam else {}))
     model.train()
+    if a.single_thread_autograd:
+        torch.autograd.set_multithreading_enabled(False)
 
     def step(timers=None):
         t0 = time.perf_counter()
@@ -98,7 +101,7 @@ def main():
     out = {'metric': 'training samples/sec (forward + backward + Adam), %s' % a.workload, 'value': a.batch / dt,
            'unit': 'samples/s', 'ms_per_step': dt * 1e3, 'host_issue_ms_per_step': host * 1e3, 'batch': a.batch, 'dropout': a.dropout, 'steps': a.steps,
            'final_loss': float(loss.detach()), 'dtype': 'f32', 'data': 'synthetic',
-           'deferred_weight_gradients': not a.no_defer, 'composite_calls': not a.per_launch, 'optimizer': 'torch.optim.Adam' + ('(fused=True)' if a.fused_adam else ''),
+           'deferred_weight_gradients': not a.no_defer, 'composite_calls': not a.per_launch, 'autograd_multithreading': not a.single_thread_autograd, 'optimizer': 'torch.optim.Adam' + ('(fused=True)' if a.fused_adam else ''),
            'synchronised_split_ms': {'forward': fwd * 1e3, 'backward': bwd * 1e3, 'optimizer': optim * 1e3},
            'hip_kernels_one_step': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
                                         'tflops': round(v['flops'] / v['ms'] / 1e9, 1) if v['ms'] > 0 and v['flops'] else 0.0}
