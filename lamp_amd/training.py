@@ -94,10 +94,12 @@ class _WeightGrads(object):
                 N.reduce_partials_grouped([j for pending, _ in todo for j in pending[0]])
                 for _, grads in todo:
                     for param, t in grads:
+                        if t.shape != param.shape:
+                            t = t.view(param.shape)
                         if param.grad is None:
-                            param.grad = t.view(param.shape)
+                            param.grad = t
                         else:
-                            param.grad.add_(t.view(param.shape))
+                            param.grad.add_(t)
         by_dev = {}
         for it in items:
             by_dev.setdefault(it[1].device, []).append(it)
@@ -115,14 +117,14 @@ class _WeightGrads(object):
                         if g is None:
                             out = torch.empty(shape2, dtype=torch.float32, device=dev)
                             fresh.append((param, out))
-                            problems.append((dy2.t(), x2.t(), out, False))
+                            problems.append((dy2, x2, out, False))
                         elif g.is_contiguous() and g.dtype == torch.float32:
-                            problems.append((dy2.t(), x2.t(), g.view(shape2), True))
+                            problems.append((dy2, x2, g.view(shape2), True))
                         else:
                             out = torch.empty(shape2, dtype=torch.float32, device=dev)
                             detour.append((g, out))
-                            problems.append((dy2.t(), x2.t(), out, False))
-                    N.matmul_nt_grouped(problems)
+                            problems.append((dy2, x2, out, False))
+                    N.wgrad_grouped(problems)
                     for param, out in fresh:
                         param.grad = out.view(param.shape)
                     for g, out in detour:

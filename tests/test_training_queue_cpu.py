@@ -30,13 +30,13 @@ def grouped(monkeypatch):
     def fake(problems):
         launches.append(len(problems))
         outs = set()
-        for a, b, out, accumulate in problems:
+        for dy2, x2, out, accumulate in problems:
             assert id(out) not in outs and out.data_ptr() not in outs, 'two products of one launch write one output'
             outs.add(out.data_ptr())
-            r = a @ b.t()
+            r = dy2.t() @ x2
             out.copy_(out + r if accumulate else r)
 
-    monkeypatch.setattr(training.N, 'matmul_nt_grouped', fake)
+    monkeypatch.setattr(training.N, 'wgrad_grouped', fake)
     training._weight_grads.tasks.clear()
     yield launches
     training._weight_grads.tasks.clear()
