@@ -153,17 +153,24 @@ def _loops(unit, want, flags=()):
 
 
 def test_gemm_main_loops_carry_no_vector_instructions():
-    """Forward tile GEMMs (LDS staging through registers / LDS-DMA: offsets advance in scalar registers) and the general GEMM's
-    FAST instantiations (loop-invariant per-lane offsets, the k-tile's base in the scalar offset): the innermost loop of every
-    product-path instantiation holds MFMAs, LDS / memory instructions and scalar bookkeeping only.  (Before round 5 gemm_gen
-    carried 36-66 vector instructions per two k-tiles: +17...+63 % on the MFMAs' time.)"""
-    _, gen = _loops('gemm_gen.hip', 'gemm_gen_kernel<')
-    fast = {n: l for n, l in gen.items() if n.split('>')[0].endswith('true')}
-    assert len(fast) == 8
-    for name, loops in fast.items():
-        inner = loops[0][2]
-        assert inner['valu'] + inner['trans'] <= 6, (name, dict(inner))     # one instantiation keeps a 6-instruction waterfall
-    assert sum(l[0][2]['valu'] == 0 for l in fast.values()) >= 7
+    """Forward tile GEMMs (LDS staging through registers / LDS-DMA: offsets advance in scalar registers) and the general GEMM
+    (loop-invariant per-lane offsets, the k-tile's base in the scalar offset): the innermost loop of every product-path
+    instantiation holds MFMAs, LDS / memory instructions and scalar bookkeeping only.  (Before round 5 gemm_gen carried 36-66
+    vector instructions per two k-tiles: +17...+63 % on the MFMAs' time.)  The TAIL instantiations (last template argument true:
+    a row operand whose K leaves a partial k-tile) also hold that one tile's per-element bounds -- statically inside the loop,
+    behind a scalar branch that only the last k-tile takes."""
+    for want, n_plain, n_tail in (('gemm_gen_kernel<', 8, 6), ('gemm_group_kernel<', 4, 3)):
+        _, gen = _loops('gemm_gen.hip', want)
+        plain = {n: l for n, l in gen.items() if n.split('>')[0].endswith('false')}
+        tail = {n: l for n, l in gen.items() if n.split('>')[0].endswith('true')}
+        assert len(plain) == n_plain and len(tail) == n_tail, (want, sorted(gen))
+        for name, loops in plain.items():
+            inner = loops[0][2]
+            assert inner['valu'] + inner['trans'] <= 6, (name, dict(inner))     # one instantiation keeps a short waterfall
+        assert sum(l[0][2]['valu'] == 0 for l in plain.values()) >= n_plain - 1
+        for name, loops in tail.items():
+            inner = loops[0][2]
+            assert 0 < inner['valu'] <= 44 and inner['trans'] == 0, (name, dict(inner))
     _, nt = _loops('gemm.hip', 'gemm_nt_kernel<')
     for name, loops in nt.items():
         if ', 16, 2, 2, false, ' in name:   # the 16-deep tiles of the forward (64x64x16, 128x64x16), K a multiple of the tile depth
