@@ -86,6 +86,10 @@ struct ChainParams {
     ChainGemm w2;      // src = H, dst = X + X
     ChainLN ln2;
     int has_ffn;       // 0: stop after ln1
+    // chain_rows4_kernel, when the LayerNorm operand rows do not fit LDS beside the panel (d_ff = 1024: bibtex).  res_alias: the
+    // modulo-residual rows live in the unused upper half of the H rows while the fc step runs (row stride hw, first column k_h:
+    // needs hw >= k_h + d).  wout_late: the read-out rows are loaded into H after the W2 step has consumed it, not in the prologue.
+    int res_alias, wout_late;
     unsigned long long* trace;   // tuning build: per-workgroup stamps
 };
 
@@ -932,7 +936,8 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
     const int x_floats = R * d, h_floats = R * p.hw;
     const int c_floats = x_floats + h_floats;
     const int c_g1 = c_floats, c_be1 = c_g1 + d, c_g2 = c_be1 + d, c_be2 = c_g2 + d, c_b2 = c_be2 + d, c_b1 = c_b2 + d;
-    const int c_res = c_b1 + dff, c_wout = c_res + (p.ln1.res ? R * d : 0);
+    const int c_res = p.res_alias ? x_floats + p.k_h : c_b1 + dff, res_ld = p.res_alias ? p.hw : d;
+    const int c_wout = p.wout_late ? x_floats : (p.res_alias ? c_b1 + dff : c_res + (p.ln1.res ? R * d : 0));
     auto buf_b = [&](int which) { return lds0 + (which ? unsigned(x_floats) * 4u : 0u); };
     auto buf_f = [&](int which) { return smem + (which ? x_floats : 0); };
     auto buf_w = [&](int which) { return which ? p.hw : d; };
@@ -957,13 +962,13 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
         for (int k = first(); k < n; k += WAVES) lds_dma16(rs, smem + at + k * 256, unsigned(k * 64 + lane) * 16u, 0);
         pc += n;
     };
-    auto load_mod_rows = [&](const float* table, int mod, int at) {
+    auto load_mod_rows = [&](const float* table, int mod, int at, int ld) {
         const __amdgpu_buffer_rsrc_t rs = rsrc_u(table, uint64_t(mod) * uint64_t(d) * 4u);
         const int ppr = d / 256, n = R * ppr;
         for (int k = first(); k < n; k += WAVES) {
             const int r = k / ppr, part = k - r * ppr;
             const unsigned src_row = unsigned(row0 + r) % unsigned(mod);
-            lds_dma16(rs, smem + at + r * d + part * 256, r < rows_m ? (src_row * unsigned(d) + unsigned(part * 64 + lane) * 4u) * 4u : OOB, 0);
+            lds_dma16(rs, smem + at + r * ld + part * 256, r < rows_m ? (src_row * unsigned(d) + unsigned(part * 64 + lane) * 4u) * 4u : OOB, 0);
         }
         pc += n;
     };
@@ -971,7 +976,7 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
     load_rows(p.in_h, p.ld_h, p.k_h, 1);
     load_vec(p.ln1.g, d, c_g1);
     load_vec(p.ln1.b, d, c_be1);
-    if (p.ln1.res) load_mod_rows(p.ln1.res, p.ln1.r_mod, c_res);
+    if (p.ln1.res) load_mod_rows(p.ln1.res, p.ln1.r_mod, c_res, res_ld);
     const ChainLN& lnl = p.has_ffn ? p.ln2 : p.ln1;
     if (p.has_ffn) {
         load_vec(p.ln2.g, d, c_g2);
@@ -979,7 +984,7 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
         load_vec(p.w2.bias[0], d, c_b2);
         load_vec(p.w1.bias[0], dff, c_b1);
     }
-    if (lnl.w_out) load_mod_rows(lnl.w_out, lnl.n_labels, c_wout);
+    if (lnl.w_out && !p.wout_late) load_mod_rows(lnl.w_out, lnl.n_labels, c_wout, d);
     wait_vmcnt<0>();
     wg_barrier();
 
@@ -1138,7 +1143,7 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
                     raw[i] = lds_read16(self);
                     gg[i] = lds_read16(lds0 + unsigned(g_at) * 4u + unsigned(cq[i]) * 16u);
                     bb[i] = lds_read16(lds0 + unsigned(be_at) * 4u + unsigned(cq[i]) * 16u);
-                    rr[i] = lds_read16(n.res ? lds0 + unsigned(c_res + r * d) * 4u + unsigned(cq[i]) * 16u : self);
+                    rr[i] = lds_read16(n.res ? lds0 + unsigned(c_res + r * res_ld) * 4u + unsigned(cq[i]) * 16u : self);
                     ww[i] = lds_read16(n.w_out ? lds0 + unsigned(c_wout + r * d) * 4u + unsigned(cq[i]) * 16u : self);
                 }
                 wait_lgkmcnt<0>();
@@ -1200,6 +1205,11 @@ __global__ __launch_bounds__(512, 2) void chain_rows4_kernel(ChainParams p) {
 #ifdef LAMP_TUNING
         if (p.trace) t[4] = wall_clock64();
 #endif
+        if (p.wout_late) {   // H is dead from here on (the W2 step ended with a barrier): the read-out rows move in
+            load_mod_rows(p.ln2.w_out, p.ln2.n_labels, c_wout, d);
+            wait_vmcnt<0>();
+            wg_barrier();
+        }
         layernorm(p.ln2, c_g2, c_be2);
     }
 #ifdef LAMP_TUNING
@@ -1272,7 +1282,10 @@ static int chain_geom_index(bool have_pack = false) {
 // separate launches are no longer at their latency floor.
 // Which panel height serves M rows from format-1 packs: G row groups of four (chain_rows4_kernel), the fewest that still give
 // every panel its own CU; 0 = not this kernel (no packs, widths that do not tile 512-column passes, more than 3072 rows, LDS).
-static int rows4_groups(int64_t M, int d, int k_h, int dff, bool has_ffn, const lamp_chain_pack* pk, bool res_mod, bool w_out) {
+static int rows4_groups(int64_t M, int d, int k_h, int dff, bool has_ffn, const lamp_chain_pack* pk, bool res_mod, bool w_out,
+                        int* res_alias = nullptr, int* wout_late = nullptr) {
+    if (res_alias) *res_alias = 0;
+    if (wout_late) *wout_late = 0;
     if (!pk || !pk->fc4 || (has_ffn && (!pk->w14 || !pk->w24))) return 0;
     int G = int((M + 4 * 256 - 1) / (4 * 256));
     bool forced = false;
@@ -1288,9 +1301,16 @@ static int rows4_groups(int64_t M, int d, int k_h, int dff, bool has_ffn, const 
     // MFMA count, the 16x16x4 instruction at a higher clock); five and six row groups carry the chain to 6144 rows
     if (G < 1 || G > 6 || (G == 4 && !forced) || M > int64_t(4 * G) * 65535 || d % 512 || k_h % 64 || (has_ffn && dff % 512)) return 0;
     const int hw = has_ffn ? (k_h > dff ? k_h : dff) : k_h;
-    const size_t lds4 = (size_t(4 * G) * size_t(d + hw) + size_t(5) * d + size_t(has_ffn ? dff : 0) + (res_mod ? size_t(4 * G) * d : 0) +
-                         (w_out ? size_t(4 * G) * d : 0)) * 4;
-    return lds4 <= size_t(160) * 1024 ? G : 0;
+    const size_t base = size_t(4 * G) * size_t(d + hw) + size_t(5) * d + size_t(has_ffn ? dff : 0), rows = size_t(4 * G) * d;
+    const size_t limit = size_t(160) * 1024 / 4;
+    if (base + (res_mod ? rows : 0) + (w_out ? rows : 0) <= limit) return G;
+    // The operand rows do not fit beside the panel (20-row panels with d_ff = 1024): both have a dead region of H to live in --
+    // the modulo-residual rows the columns past k_h while the fc step runs, the read-out rows all of H after the W2 step.
+    const bool ra = res_mod && has_ffn && hw >= k_h + d, wl = w_out && has_ffn && size_t(4 * G) * hw >= rows;
+    if (base + (res_mod && !ra ? rows : 0) + (w_out && !wl ? rows : 0) > limit) return 0;
+    if (res_alias) *res_alias = ra;
+    if (wout_late) *wout_late = wl;
+    return G;
 }
 
 bool chain_applies(int64_t M, int d, int k_h, int dff, bool has_ffn, const lamp_chain_pack* pk, bool res_mod, bool w_out) {
@@ -1386,9 +1406,10 @@ int launch_chain(const float* A, int64_t lda, int k_h, const float* res, int64_t
     // Panels of 4 G rows (chain_rows4_kernel) when they spread the rows over more CUs than sixteen-row panels would
     {
         const ChainLN& lnl = ffn ? p.ln2 : p.ln1;
-        const int G = rows4_groups(M, d, k_h, dff, ffn != nullptr, have_pack4 ? pk : nullptr, p.ln1.res != nullptr, lnl.w_out != nullptr);
+        const int G = rows4_groups(M, d, k_h, dff, ffn != nullptr, have_pack4 ? pk : nullptr, p.ln1.res != nullptr, lnl.w_out != nullptr,
+                                   &p.res_alias, &p.wout_late);
         const size_t lds4 = (size_t(4 * G) * size_t(p.d + p.hw) + size_t(5) * d + size_t(ffn ? dff : 0) +
-                             (p.ln1.res ? size_t(4 * G) * d : 0) + (lnl.w_out ? size_t(4 * G) * d : 0)) * 4;
+                             (p.ln1.res && !p.res_alias ? size_t(4 * G) * d : 0) + (lnl.w_out && !p.wout_late ? size_t(4 * G) * d : 0)) * 4;
         if (G > 0) {
             ProfScope prof(LAMP_K_GEMM, fl, by, s);
             const unsigned grid4 = unsigned((M + 4 * G - 1) / (4 * G));

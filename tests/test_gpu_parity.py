@@ -700,6 +700,42 @@ def test_chain_routes_of_the_product_library_give_every_sample_the_same_bits(dev
     assert torch.equal(upd[:4], small) and not torch.equal(upd, ref[:32])
 
 
+def test_chain_with_operand_rows_in_dead_panel_regions_bibtex_shape(dev):
+    """d_ff = 1024 at bibtex's 159 labels: batch 32 = 5088 rows = 255 panels of twenty rows, whose LayerNorm operand rows no longer
+    fit LDS beside the panel -- the modulo-residual rows of layer 0's first block then live in the unused upper half of the
+    hidden rows while the fc step runs, the read-out rows of the last block are loaded into the hidden region after the W2 step
+    (chain.hip: res_alias / wout_late).  Same samples through batch 32 (all four sub-chains as chain launches), batch 40
+    (6360 rows: five separate launches each) and batch 3 (477 rows: separate launches): bit-identical logits, encoder rows and
+    intermediate read-outs; a partial last panel (batch 31: 4929 rows) included."""
+    from lamp_amd.Models import LAMP
+    V, L, T, d, dff, h = 300, 159, 20, 512, 1024, 4
+    sd = R.make_state_dict(V, L, T, d, dff, h, 1, 2, pos_emb=False, seed=5)
+    adj = R.make_adjacency(L, 0.05, 5)
+    m = LAMP(V, L, T, L, n_layers_enc=1, n_layers_dec=2, n_head=h, n_head2=h, d_word_vec=d, d_model=d, d_inner_hid=dff,
+             d_k=d // h, d_v=d // h, encoder='graph', decoder='graph', label_adj_matrix=adj.clone(), label_mask='prior',
+             dec_dropout2=False, no_enc_pos_embedding=True)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    B = 40
+    seq, spos = R.make_batch(B, V, T, lengths=[T, 3, 17, 9, 20] * 8, seed=5)
+    seq, spos = seq.to(dev), spos.to(dev)
+    assert m.use_chain_packs
+    ref, enc_ref, ip_ref = m((seq, spos), None, None, None, int_preds=True)       # 6360 rows: separate launches
+    for b in (32, 31, 3, 26):                                                     # 5088, 4929 (20-row panels), 477, 4134 rows
+        for lo in (0, B - b):
+            got, enc, ip = m((seq[lo:lo + b], spos[lo:lo + b]), None, None, None, int_preds=True)
+            assert torch.equal(got, ref[lo:lo + b]) and torch.equal(enc, enc_ref[lo:lo + b]), (b, lo)
+            assert all(torch.equal(a, w[lo:lo + b]) for a, w in zip(ip, ip_ref)), (b, lo)
+            plain, _, _ = m((seq[lo:lo + b], spos[lo:lo + b]), None, None, None)   # without int_preds: the fused read-out
+            assert torch.equal(plain, got), (b, lo)
+    for _ in range(20):   # a load consumed before it landed would not repeat
+        again, _, _ = m((seq[:32], spos[:32]), None, None, None)
+        assert torch.equal(again, ref[:32])
+    oracle, _, _ = R.forward(R.to_dtype({k: v.detach().cpu() for k, v in m.state_dict().items()}, torch.float64),
+                             seq[:32].cpu(), spos[:32].cpu(), h, R.label_block_mask(adj, 'prior', L))
+    assert max_abs_diff(ref[:32], oracle) < 1e-4
+
+
 def test_chain_launches_survive_a_busy_neighbour_stream(dev):
     """The hand-scheduled chain kernels under contention: 300 back-to-back forwards at the headline decoder shape (2880 rows:
     twelve-row panels) and 100 at 3600 rows (sixteen-row panels) while a second stream keeps the K/V-projection GEMM running on
