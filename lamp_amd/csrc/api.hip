@@ -228,6 +228,26 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
         return launch_chain(sc.A, hdv, hdv, xq, r_mod, M, d, w.fc, w.ln_g, w.ln_b, tail->ffn, tail->dff,
                             tail->w_out ? nullptr : out, tail->w_out, tail->n_labels, tail->logits, s, tail->pk);
     }
+    if (h > 1 && tail && tail->ffn && tail->pk && M > 6144 && (!tail->w_out || tail->n_labels == lq)) {
+        // Just past one chain launch's reach (6145-12288 rows: batch 69-136 at 90 labels) the tail is still faster as TWO chain
+        // launches over halves of the batch -- whole samples, so that row % lq of the shared residual / read-out rows stays the
+        // group-local row -- when each half fills the CUs with 24-row panels: batch 128 = 2 x 5760 rows, +6 % whole-forward
+        // (48.9 k against 46.1 k samples/s).  With smaller halves (batch 96: 2 x 4320 rows) it ties, and from ~190 samples on the
+        // five launches have enough tiles per GEMM to win (profiles/r05_batch_sweep.txt): both keep the separate launches.
+        const int per = (B + 1) / 2, last = B - per;
+        if (int64_t(per) * lq <= 6144 && int64_t(last) * lq > 4608 &&
+            chain_applies(int64_t(per) * lq, d, hdv, tail->dff, true, tail->pk, xq_shared, tail->w_out != nullptr) &&
+            chain_applies(int64_t(last) * lq, d, hdv, tail->dff, true, tail->pk, xq_shared, tail->w_out != nullptr)) {
+            for (int g = 0; g < 2; ++g) {
+                const int64_t r0 = int64_t(g) * per * lq, rows = int64_t(g == 0 ? per : last) * lq;
+                LAMP_CK(launch_chain(sc.A + r0 * hdv, hdv, hdv, xq_shared ? xq : xq + r0 * d, r_mod, rows, d, w.fc, w.ln_g, w.ln_b,
+                                     tail->ffn, tail->dff, tail->w_out ? nullptr : out + r0 * d, tail->w_out, tail->n_labels,
+                                     tail->logits ? tail->logits + r0 : nullptr, s, tail->pk));
+            }
+            tail->done = true;
+            return 0;
+        }
+    }
     if (h > 1) {
         const float* W[1] = {w.fc};
         float* C[1] = {out};

@@ -700,6 +700,37 @@ def test_chain_routes_of_the_product_library_give_every_sample_the_same_bits(dev
     assert torch.equal(upd[:4], small) and not torch.equal(upd, ref[:32])
 
 
+def test_chain_over_two_halves_of_a_large_batch(dev):
+    """Just past one chain launch's reach (6145-12288 decoder rows) the row-local tail runs as two chain launches over halves of
+    the batch, whole samples each (api.hip: mha_core), when both halves take 24-row panels.  Batch 136 (68 + 68 samples = 6120
+    rows each), 128 (2 x 5760) and 105 (53 + 52: 4770 / 4680 rows) take that route; 100 (50 + 50: 4500 rows) and 140 keep the five
+    separate launches.  All against the same samples in batches of four (360 rows: separate launches): logits, encoder rows and
+    intermediate read-outs bit for bit."""
+    from lamp_amd.Models import LAMP
+    V, L, T, d, dff, h = 400, 90, 16, 512, 512, 4
+    sd = R.make_state_dict(V, L, T, d, dff, h, 1, 2, pos_emb=True, seed=21)
+    adj = R.make_adjacency(L, 0.1, 21)
+    m = LAMP(V, L, T, L, n_layers_enc=1, n_layers_dec=2, n_head=h, n_head2=h, d_word_vec=d, d_model=d, d_inner_hid=dff,
+             d_k=d // h, d_v=d // h, encoder='graph', decoder='graph', label_adj_matrix=adj.clone(), label_mask='prior',
+             dec_dropout2=False)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    B = 140
+    seq, spos = R.make_batch(B, V, T, lengths=[T, 3, 11, 9, 16] * 28, seed=21)
+    seq, spos = seq.to(dev), spos.to(dev)
+    small = {}
+    for lo in (0, 48, 51, 52, 64, 66, 68, 100, 132, 136):
+        small[lo] = m((seq[lo:lo + 4], spos[lo:lo + 4]), None, None, None, int_preds=True)
+    for b in (140, 136, 128, 105, 100):
+        got, enc, ip = m((seq[:b], spos[:b]), None, None, None, int_preds=True)
+        plain, _, _ = m((seq[:b], spos[:b]), None, None, None)
+        assert torch.equal(plain, got), b
+        for lo, (w, w_enc, w_ip) in small.items():
+            if lo + 4 <= b:
+                assert torch.equal(got[lo:lo + 4], w) and torch.equal(enc[lo:lo + 4], w_enc), (b, lo)
+                assert all(torch.equal(a[lo:lo + 4], x) for a, x in zip(ip, w_ip)), (b, lo)
+
+
 def test_chain_with_operand_rows_in_dead_panel_regions_bibtex_shape(dev):
     """d_ff = 1024 at bibtex's 159 labels: batch 32 = 5088 rows = 255 panels of twenty rows, whose LayerNorm operand rows no longer
     fit LDS beside the panel -- the modulo-residual rows of layer 0's first block then live in the unused upper half of the
