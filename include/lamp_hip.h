@@ -318,7 +318,8 @@ int lamp_gemm_grouped(const lamp_gemm_desc* descs, int32_t n, lamp_stream_t stre
  * "saved" ones must live until the matching backward call, gradients of weights may be NULL = the caller computes them
  * later from the buffers this call leaves behind (lamp_gemm_grouped). */
 
-/* Second stage of a column reduction (LayerNorm-parameter and bias gradients): out[c] = sum over n_partials rows of
+/* Second stage of a column reduction (LayerNorm-parameter and bias gradients of `loss.backward()`, train.py:40 -- what autograd
+ * computes for nn.LayerNorm / Conv1d biases in lamp/SubLayers.py:64,129-131): out[c] = sum over n_partials rows of
  * partial[p * n_total + c], c < n_total, in a fixed order; columns [i * n_seg, (i + 1) * n_seg) go to out[i] (n_total <= 3 n_seg).
  * lamp_ffn_bwd / lamp_mha_bwd describe theirs in such jobs instead of launching them when given a `partials` buffer, so that
  * ONE lamp_reduce_partials_grouped launch can run the jobs of a whole backward pass: 17 tiny dependent launches per reuters
