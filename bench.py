@@ -353,6 +353,12 @@ def csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
+def _built_toolchain():
+    """The compiler that built liblamp_hip.so and passed the ISA guard of the hand-scheduled kernels (lamp_amd/build.py)."""
+    from lamp_amd import build as B
+    return B.built_toolchain()
+
+
 def load_traffic(workload):
     """HBM-side bytes per GEMM launch measured by the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
     separate runs, FETCH_SIZE doubled per the MI355X guide's gfx950 calibration) -- or None when no profile of this
@@ -613,6 +619,9 @@ def main():
                     help='skip the three rocprofv3 --pmc sub-runs behind roofline.traffic / roofline.attention (N = 1)')
     ap.add_argument('--no-chain-packs', action='store_true',
                     help='A/B switch: run the decoder chain launch from the native weight layouts (no weights-only repack)')
+    ap.add_argument('--no-embed-fold', action='store_true',
+                    help="A/B switch: launch encoder layer 0's first FFN GEMM instead of gathering its hidden rows from the "
+                         'weights-only folded tables (LAMP.fold_embedding)')
     ap.add_argument('--mask', default=None, choices=['prior', 'none', 'inveye'], help='override the workload label mask')
     args = ap.parse_args()
 
@@ -647,6 +656,9 @@ def main():
     if args.no_chain_packs:
         from lamp_amd.Models import LAMP
         LAMP.use_chain_packs = False
+    if args.no_embed_fold:
+        from lamp_amd.Models import LAMP
+        LAMP.fold_embedding = False
     w_base = dict(WORKLOADS[args.workload])
     if args.mask:
         w_base['mask'] = args.mask
@@ -778,6 +790,17 @@ def main():
         roof.update(achieved=tf, frac=tf / PEAK_FP32_MFMA_TFLOPS, algorithmic_gflop_per_step=gf / 1e9,
                     flops_source='analytic, real token count %d of %d padded positions' % (n_tok, args.batch * w['T']))
         kernels['gemm']['tflops'] = tf
+    # what the model object computed ONCE per weight version, outside every forward (all of it a function of the weights alone)
+    from lamp_amd.Models import LAMP as _LAMP
+    hoisted = 2.0 * w['L'] * w['d'] * w['d'] if _LAMP.cache_layer0_query else 0.0            # SURVEY.md G11, per sample
+    folded = 2.0 * w['T'] * w['d'] * w['dff'] if _LAMP.fold_embedding else 0.0               # encoder layer 0's W1, per sample
+    weights_only = {
+        'dec0_query': bool(_LAMP.cache_layer0_query), 'chain_packs': bool(_LAMP.use_chain_packs),
+        'embed_fold': bool(_LAMP.fold_embedding),
+        'note': 'decoder layer 0 query = label table x W_q (SURVEY.md G11); encoder layer 0 hidden = relu((Emb W1^T)[tok] + '
+                '(Pos W1^T + b1)[pos]) -- the gather is a one-hot product, so W1 folds into the tables; both re-associations '
+                'of the same linear maps, built once per weight version with lamp_linear_fwd.  F_live (SURVEY.md 8d) is NOT '
+                'reduced for either; forward.executed_gflop_per_sample is.  --no-embed-fold runs the unfolded route.'}
     result = {
         'metric': 'forward samples/sec, reuters d512 2+2L 4h' if args.workload == 'reuters' else
                   'forward samples/sec, %s d%d 2+2L %dh' % (args.workload, w['d'], w['h']),
@@ -807,12 +830,16 @@ def main():
                                ('torch.distributed.run' if world > 1 else 'single process'),
                    'backend': cp.backend, 'backend_note': cp.note,
                    'device_warmup_s': DEVICE_WARMUP_S, 'device_warmup_steps': m['device_warmup_steps'],
+                   'weights_only_precomputation': weights_only,
+                   'csrc_fingerprint': csrc_fingerprint(), 'hipcc': _built_toolchain(),
                    },
         'roofline': roof,
         'forward': {
             'f_live_gflop_per_sample': fl / 1e9,
             'achieved_tflops_per_gpu': value / n_gpus * fl / 1e12,
             'frac_of_fp32_mfma_peak': value / n_gpus * fl / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            'executed_gflop_per_sample': (fl - hoisted - folded) / 1e9,
+            'executed_frac_of_fp32_mfma_peak': value / n_gpus * (fl - hoisted - folded) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             'kernel_time_us_per_step': sum(k['us_per_step'] for k in kernels.values()),
             'kernel_time_note': 'HIP-event durations of an INSTRUMENTED replay (an event pair around every launch adds '
                                 '~2-3 us per kernel): the sum may exceed ms_per_step; rocprofv3 kernel-only figures are '

@@ -39,7 +39,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define LAMP_HIP_ABI_VERSION 4   /* 4: + lamp_gemm_grouped, lamp_{ffn,mha}_train_fwd / _bwd (additive) */
+#define LAMP_HIP_ABI_VERSION 5   /* 5: lamp_model grows (enc0_emb_w1 / enc0_pos_w1, label_csr); 4: + lamp_gemm_grouped, lamp_{ffn,mha}_train_fwd / _bwd */
 
 typedef void* lamp_stream_t; /* hipStream_t */
 
@@ -166,6 +166,16 @@ typedef struct lamp_model {
     /* Optional: host array of 2 * n_layers_dec packs -- entry 2 i: layer i's (enc_attn.fc, pos_ffn1), entry 2 i + 1: its
      * (slf_attn.fc, pos_ffn2); entries with NULL members, or a NULL array, leave that sub-chain on the native layouts. */
     const lamp_chain_pack* chain_packs;
+    /* Optional (both or neither; ABI 5): encoder layer 0's first FFN matrix folded into the embedding tables.  The token /
+     * position gather of lamp/Encoders.py:66,75 is a one-hot product, so relu((Emb[tok] + Pos[p]) W1^T + b1) of
+     * lamp/SubLayers.py:135 equals relu(enc0_emb_w1[tok] + enc0_pos_w1[p]) with the weights-only tables
+     *   enc0_emb_w1 [n_src_vocab, d_inner] = src_word_emb . W1^T            (+ b1 when position_enc is NULL)
+     *   enc0_pos_w1 [n_position, d_inner]  = position_enc . W1^T + b1       (NULL when position_enc is NULL)
+     * of enc_layers[0].pos_ffn (a caller builds them once per weight version with lamp_linear_fwd).  lamp_forward then
+     * gathers that layer's hidden rows beside the embedded rows and does not launch its first GEMM: a re-association, so
+     * results differ from the unfolded route in the last bits (not bit-identical, well inside 1e-4).  NULL = unfolded. */
+    const float* enc0_emb_w1;
+    const float* enc0_pos_w1;
 } lamp_model;
 
 /* Optional extra outputs of lamp_forward (return_attns / int_preds, lamp/Models.py:127-135).

@@ -1,7 +1,7 @@
 """LAMP model facade (reference: lamp/Models.py:18-137) for encoder='graph', decoder='graph'.
 
-``forward`` in eval mode on a HIP device is ONE call into liblamp_hip.so (``lamp_forward``): about
-thirty kernel launches for a 2+2-layer model instead of the reference's ~140 ATen ops, no
+``forward`` in eval mode on a HIP device is ONE call into liblamp_hip.so (``lamp_forward``): 18
+kernel launches for a 2+2-layer model instead of the reference's ~140 ATen ops, no
 per-forward mask materialisation, no head split/merge copies, and the discarded encoder
 self-attention (lamp/Layers.py:16-18) is simply not computed unless its maps are requested.
 """
@@ -155,6 +155,13 @@ class LAMP(nn.Module):
             ffn(l.pos_ffn2)
         return out
 
+    def _fold_weights(self):
+        """(token table, position table or None, W1, b1) of the encoder's first layer."""
+        enc = self.encoder
+        ff = enc.layer_stack[0].pos_ffn
+        return (enc.src_word_emb.weight, enc.position_enc.weight if hasattr(enc, 'position_enc') else None,
+                ff.w_1.weight, ff.w_1.bias)
+
     def _chain_weights(self):
         out = []
         for l in self.decoder.layer_stack:
@@ -178,13 +185,16 @@ class LAMP(nn.Module):
         bits = self.decoder.label_mask_bits
         hoist = self.cache_layer0_query and not replica   # the hoisted projection needs a one-off stream sync
         packs = self.use_chain_packs and not replica      # weights-only repacks: same one-off cost, same staleness rule
+        fold = self.fold_embedding and not replica and len(self.encoder.layer_stack) > 0   # weights-only tables, likewise
         key = tuple(p.data_ptr() for p in params) + (N.ptr(mask), N.ptr(bits), N.ptr(tiles), self.use_label_tiles,
-                                                      hoist, self.use_mask_bits, packs)
+                                                      hoist, self.use_mask_bits, packs, fold)
         if hoist:  # the hoisted projection below is stale once either operand changes
             l0 = self.decoder.layer_stack[0].enc_attn
             key += (self.decoder.tgt_word_emb.weight._version, l0.w_qs.weight._version)
         if packs:
             key += tuple(w._version for w in self._chain_weights())
+        if fold:
+            key += tuple(w._version for w in self._fold_weights() if w is not None)
         cache = None if replica else self._native_cache
         if cache is not None and cache[0] == key:
             return cache[1]
@@ -239,7 +249,19 @@ class LAMP(nn.Module):
                     pack_arr[2 * i + j] = N.ChainPack(*ptrs)
             m.chain_packs = pack_arr
             torch.cuda.current_stream().synchronize()
-        built = (m, enc_arr, dec_arr, q0, pack_arr, pack_keep)
+        fold_keep = None
+        if fold:
+            # encoder layer 0's W1 folded into the embedding tables (lamp_model.enc0_emb_w1 / enc0_pos_w1, include/lamp_hip.h):
+            # the gather is a one-hot product, so relu((Emb[tok] + Pos[p]) W1^T + b1) = relu((Emb W1^T)[tok] + (Pos W1^T + b1)[p]).
+            # Weights only -- built with lamp_linear_fwd once per weight version, like the hoisted query above.
+            emb_w, pos_w, w1, b1 = self._fold_weights()
+            w1 = w1.detach().reshape(w1.size(0), -1)
+            e1 = N.linear(emb_w.detach(), w1, None if pos_w is not None else b1.detach())
+            p1 = N.linear(pos_w.detach(), w1, b1.detach()) if pos_w is not None else None
+            m.enc0_emb_w1, m.enc0_pos_w1 = e1.data_ptr(), N.ptr(p1)
+            fold_keep = (e1, p1)
+            torch.cuda.current_stream().synchronize()
+        built = (m, enc_arr, dec_arr, q0, pack_arr, pack_keep, fold_keep)
         if not replica:
             self._native_cache = (key, built)
         return built
@@ -355,6 +377,9 @@ class LAMP(nn.Module):
     cache_layer0_query = True
     # Keep fragment-major copies of the decoder sub-chains' weight matrices (lamp_pack_weight) for the fused chain launch.
     use_chain_packs = True
+    # Fold encoder layer 0's first FFN matrix into the embedding tables (weights-only: Emb . W1^T and Pos . W1^T + b1, one
+    # GEMM fewer per forward; results move in the last bits, a re-association).  False = the unfolded route.
+    fold_embedding = True
     # Skip fully blocked 32x32 tiles of the label graph in the label->label attention.
     use_label_tiles = True
     # Read the label mask bit-packed (one 32-bit word per 32-key tile and row) instead of as bytes.

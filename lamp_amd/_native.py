@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LAMP_HIP_LIBRARY') or os.path.join(_HERE, 'liblamp_hip.so')
 TUNING_LIB_PATH = os.path.join(_HERE, 'liblamp_hip_tuning.so')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 LAMP_MASK_NONE, LAMP_MASK_U8, LAMP_MASK_KEY_TOKENS_I64, LAMP_MASK_BITS_U32 = 0, 1, 2, 3
 K_EMBED, K_GEMM, K_ATTN, K_LAYERNORM, K_DIAG, K_COUNT = 0, 1, 2, 3, 4, 5
 KERNEL_CLASS_NAMES = ('embed', 'gemm', 'attention', 'layernorm', 'diag_readout')
@@ -71,7 +71,8 @@ class Model(C.Structure):
                 ('n_layers_enc', C.c_int32), ('n_layers_dec', C.c_int32), ('reserved', C.c_int32),
                 ('src_word_emb', _vp), ('position_enc', _vp), ('tgt_word_emb', _vp), ('w_out', _vp),
                 ('label_mask', _vp), ('label_mask_bits', _vp), ('label_tiles', _vp), ('enc_layers', C.POINTER(EncLayer)), ('dec_layers', C.POINTER(DecLayer)),
-                ('dec0_query', _vp), ('chain_packs', C.POINTER(ChainPack))]
+                ('dec0_query', _vp), ('chain_packs', C.POINTER(ChainPack)),
+                ('enc0_emb_w1', _vp), ('enc0_pos_w1', _vp)]
 
 
 class GemmDesc(C.Structure):  # include/lamp_hip.h: lamp_gemm_desc

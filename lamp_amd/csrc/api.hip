@@ -307,12 +307,14 @@ static int project_kv_layers(const float* x, int64_t Me, int d, int dk, int dv, 
 // Packed encoder rows (ragged batches): `rows_dev` = the live row count in device memory (M is the upper bound the
 // launches are sized for); with `scatter` this is the LAST encoder layer, whose LayerNorm also writes the padded
 // [nb, T, d] encoder output `y_flat` (see layernorm_kernel<.., RG = 2>).
+// `hidden_ready`: relu(x W1^T + b1) is already in `hidden` (the encoder's first layer with W1 folded into the embedding
+// tables, pointwise.hip: gather_row) -- the first GEMM is not launched.
 static int ffn_core(const float* x, int64_t M, int d, int dff, const lamp_ffn_weights& w, float* out,
                     float* hidden, hipStream_t s, const float* w_out = nullptr, int n_labels = 0,
                     float* logits = nullptr, const int* rows_dev = nullptr, const SeqPlan* scatter = nullptr,
-                    int nb = 0, int T = 0, float* y_flat = nullptr) {
+                    int nb = 0, int T = 0, float* y_flat = nullptr, bool hidden_ready = false) {
     if (!w.w1 || !w.b1 || !w.w2 || !w.b2 || !w.ln_g || !w.ln_b) return LAMP_E_NULL;
-    {
+    if (!hidden_ready) {
         const float* W[1] = {w.w1};
         const float* b[1] = {w.b1};
         float* C[1] = {hidden};
@@ -478,6 +480,7 @@ int lamp_diag_logits_fwd(const float* y, const float* w_out, int32_t B, int32_t 
 }
 
 static_assert(sizeof(lamp_gemm_desc) == 160, "lamp_gemm_desc layout is part of the ABI");
+static_assert(sizeof(lamp_model) == 144, "lamp_model layout is part of the ABI (lamp_amd/_native.py: Model)");
 
 size_t lamp_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t batch) {
     return gemm_gen_workspace_bytes(M, N, K, batch);
@@ -932,17 +935,21 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         // ---- GraphEncoder.forward (lamp/Encoders.py:64-110) ----
         lamp_mask pad_mask{LAMP_MASK_KEY_TOKENS_I64, 0, seq, T, 0, nullptr, 0};
         const float* xk = x;  // what the decoder's K / V projections read
+        // Encoder layer 0's W1 folded into the embedding tables (lamp_model::enc0_emb_w1): the gather writes that layer's
+        // hidden rows into H beside the embedded rows, and its first GEMM is not launched.
+        const bool folded = m->enc0_emb_w1 && m->n_layers_enc > 0;
+        const EmbedFold fold{m->enc0_emb_w1, m->enc0_pos_w1, dff, folded ? H : nullptr};
         if (packed) {
             LAMP_CK(launch_embed_plan(seq, pos, m->position_enc != nullptr, nb, T, m->src_word_emb, m->n_src_vocab,
-                                      m->position_enc, m->n_position, d, sp, granules, Xp, s));
+                                      m->position_enc, m->n_position, d, sp, granules, Xp, s, &fold));
             for (int i = 0; i < m->n_layers_enc; ++i) {
                 const bool last = i + 1 == m->n_layers_enc;
                 LAMP_CK(ffn_core(Xp, Me + 1, d, dff, m->enc_layers[i].pos_ffn, Xp, H, s, nullptr, 0, nullptr, sp.rows + 1,
-                                 last ? &sp : nullptr, nb, T, x));  // lamp/Layers.py:18
+                                 last ? &sp : nullptr, nb, T, x, folded && i == 0));  // lamp/Layers.py:18
             }
             xk = Xp;
         } else {
-            LAMP_CK(launch_embed(seq, pos, Me, m->src_word_emb, m->n_src_vocab, m->position_enc, m->n_position, d, x, s));
+            LAMP_CK(launch_embed(seq, pos, Me, m->src_word_emb, m->n_src_vocab, m->position_enc, m->n_position, d, x, s, &fold));
             for (int i = 0; i < m->n_layers_enc; ++i) {
                 const lamp_enc_layer& l = m->enc_layers[i];
                 if (want_enc_attn && aux->enc_self_attn[i]) {
@@ -951,7 +958,8 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
                     LAMP_CK(mha_core(x, false, x, nb, T, T, d, dk, dv, l.slf_attn, &pad_mask, nullptr,
                                      aux->enc_self_attn[i], sc, s, false, nullptr, B, int(b0), &sp));
                 }
-                LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s));  // lamp/Layers.py:18
+                LAMP_CK(ffn_core(x, Me, d, dff, l.pos_ffn, x, H, s, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, nullptr,
+                                 folded && i == 0));  // lamp/Layers.py:18
             }
         }
         const int* kv_rows = packed ? sp.rows : nullptr;
@@ -1028,6 +1036,7 @@ int lamp_forward(const lamp_model* m, const int64_t* src_seq, const int64_t* src
     if (B <= 0 || T <= 0) return LAMP_E_DIMS;
     if (!m->src_word_emb || !m->tgt_word_emb || !m->w_out) return LAMP_E_NULL;
     if (m->position_enc && !src_pos) return LAMP_E_NULL;
+    if (m->enc0_emb_w1 && m->position_enc && !m->enc0_pos_w1) return LAMP_E_NULL;
     if (m->n_layers_dec <= 0) return LAMP_E_DIMS;
     FwdPlan pl;
     LAMP_CK(make_plan(m, T, aux && aux->enc_self_attn, &pl));

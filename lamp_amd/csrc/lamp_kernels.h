@@ -126,8 +126,17 @@ struct SeqPlan {
 };
 int launch_seq_plan(const int64_t* seq, const int64_t* pos, int nb, int T, int64_t seq_stride, bool packed,
                     const SeqPlan& sp, hipStream_t s);
+// The first encoder layer's W1 folded into the embedding tables (lamp_model::enc0_emb_w1 / enc0_pos_w1): the gather kernels then
+// also write that layer's hidden rows, hid[row] = relu(e1[tok] (+ p1[pos])), beside the embedded rows.  hid == nullptr: off.
+struct EmbedFold {
+    const float* e1;   // [n_vocab, dff]     emb . W1^T  (+ b1 when the model has no position table)
+    const float* p1;   // [n_position, dff]  pos_table . W1^T + b1, or nullptr without a position table
+    int dff;
+    float* hid;        // [rows, dff]: same row index as the embedded rows
+};
 int launch_embed_packed(const int64_t* seq, const int64_t* pos, int nb, int T, const float* emb, int n_vocab,
-                        const float* pos_table, int n_position, int d, const SeqPlan& sp, float* out, hipStream_t s);
+                        const float* pos_table, int n_position, int d, const SeqPlan& sp, float* out, hipStream_t s,
+                        const EmbedFold* fold = nullptr);
 // the two above (packed layout) as ONE launch; granules: 2 * nb + 2 unsigned 64-bit words of workspace.  Their content on entry
 // must not carry THIS launch's epoch tag: the tag is a host counter (unique per launch), and the last encoder LayerNorm of the
 // forward zeroes the granules again -- which is what makes a REPLAYED HIP graph (same tag every replay) safe.  Precondition of a
@@ -135,7 +144,7 @@ int launch_embed_packed(const int64_t* seq, const int64_t* pos, int nb, int T, c
 // between the gather and that LayerNorm, would leave granules of the same epoch behind; zero the 2 nb + 2 words first).
 int launch_embed_plan(const int64_t* seq, const int64_t* pos, bool plan_uses_pos, int nb, int T, const float* emb, int n_vocab,
                       const float* pos_table, int n_position, int d, const SeqPlan& sp, unsigned long long* granules, float* out,
-                      hipStream_t s);
+                      hipStream_t s, const EmbedFold* fold = nullptr);
 
 // y = LayerNorm(dropout(x) + residual[row % r_mod or row])   (residual nullable; r_mod 0 = per-row residual; drop nullable)
 // m_dev: live row count in device memory (M sizes the launch).  scatter (+ T, y_flat): the last LayerNorm of the packed
@@ -172,7 +181,7 @@ int launch_diag_bwd(const float* y, const float* w, const float* dl, int B, int 
 int launch_embed_bwd(const int64_t* seq, int64_t n_tok, const float* dout, int d, int n_vocab, int64_t pad_idx,
                      float* d_emb, hipStream_t s);
 int launch_embed(const int64_t* seq, const int64_t* pos, int64_t n_tok, const float* emb, int n_vocab,
-                 const float* pos_table, int n_position, int d, float* out, hipStream_t s);
+                 const float* pos_table, int n_position, int d, float* out, hipStream_t s, const EmbedFold* fold = nullptr);
 int launch_diag(const float* y, const float* w, int B, int L, int d, float* logits, hipStream_t s);
 int launch_prior_graph(const int64_t* ids, const int64_t* offsets, int64_t n_samples, int L, float* adj,
                        uint8_t* blocked, hipStream_t s);

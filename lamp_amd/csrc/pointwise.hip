@@ -8,21 +8,18 @@ namespace lamp {
 
 __device__ __forceinline__ float wave_sum(float v) { return wave64_sum(v); }
 
-// out[t, :] = emb[seq[t], :] (+ pos_table[pos[t], :])          lamp/Encoders.py:66,75
-__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ seq,
-                                                    const int64_t* __restrict__ pos, int64_t n_tok,
-                                                    const float* __restrict__ emb, int n_vocab,
-                                                    const float* __restrict__ pos_table, int n_position,
-                                                    int d, float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t t = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);  // XCD order of the next GEMM
-    if (t >= n_tok) return;
-    const int64_t tok = seq[t];
-    const int64_t ps = pos_table ? pos[t] : 0;
+// One gathered row by one wave: out[dst] = emb[tok] (+ pos_table[ps]); NaN rows for out-of-range indices.  With `fold`
+// (EmbedFold, lamp_kernels.h) the same wave also writes the first encoder layer's HIDDEN row
+//     hid[dst] = relu(e1[tok] (+ p1[ps]))      e1 = emb . W1^T, p1 = pos_table . W1^T + b1  (weights-only tables),
+// i.e. relu((emb[tok] + pos_table[ps]) . W1^T + b1) of lamp/SubLayers.py:135 re-associated: the gather is a one-hot product,
+// so the first FFN GEMM of the encoder folds into the tables and is not launched (api.hip: ffn_core(hidden_ready)).
+__device__ __forceinline__ void gather_row(int64_t tok, int64_t ps, const float* __restrict__ emb, int n_vocab,
+                                           const float* __restrict__ pos_table, int n_position, int d, float* __restrict__ out,
+                                           int64_t dst, const EmbedFold& fold, int lane) {
     const bool ok = tok >= 0 && tok < n_vocab && ps >= 0 && (!pos_table || ps < n_position);
     const float4* e = reinterpret_cast<const float4*>(emb + (ok ? tok : 0) * d);
     const float4* q = pos_table ? reinterpret_cast<const float4*>(pos_table + (ok ? ps : 0) * d) : nullptr;
-    float4* o = reinterpret_cast<float4*>(out + t * d);
+    float4* o = reinterpret_cast<float4*>(out + dst * d);
     const float nan = __builtin_nanf("");
     for (int c = lane; c < d / 4; c += 64) {
         float4 v = e[c];
@@ -33,6 +30,32 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
         if (!ok) v = make_float4(nan, nan, nan, nan);
         o[c] = v;
     }
+    if (!fold.hid) return;
+    const float4* e1 = reinterpret_cast<const float4*>(fold.e1 + (ok ? tok : 0) * fold.dff);
+    const float4* q1 = fold.p1 ? reinterpret_cast<const float4*>(fold.p1 + (ok ? ps : 0) * fold.dff) : nullptr;
+    float4* h = reinterpret_cast<float4*>(fold.hid + dst * fold.dff);
+    for (int c = lane; c < fold.dff / 4; c += 64) {
+        float4 v = e1[c];
+        if (q1) {
+            const float4 w = q1[c];
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (!ok) v = make_float4(nan, nan, nan, nan);
+        h[c] = v;
+    }
+}
+
+// out[t, :] = emb[seq[t], :] (+ pos_table[pos[t], :])          lamp/Encoders.py:66,75
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ seq,
+                                                    const int64_t* __restrict__ pos, int64_t n_tok,
+                                                    const float* __restrict__ emb, int n_vocab,
+                                                    const float* __restrict__ pos_table, int n_position,
+                                                    int d, float* __restrict__ out, EmbedFold fold) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);  // XCD order of the next GEMM
+    if (t >= n_tok) return;
+    gather_row(seq[t], pos_table ? pos[t] : 0, emb, n_vocab, pos_table, n_position, d, out, t, fold, lane);
 }
 
 // One sample's extents, by one wave (see seq_plan_kernel): kl = 1 + its last non-PAD token, pl >= kl additionally covers the
@@ -123,7 +146,7 @@ __global__ __launch_bounds__(1024) void seq_plan_kernel(const int64_t* __restric
 __global__ __launch_bounds__(256) void embed_packed_kernel(const int64_t* __restrict__ seq, const int64_t* __restrict__ pos,
                                                            int nb, int T, const float* __restrict__ emb, int n_vocab,
                                                            const float* __restrict__ pos_table, int n_position, int d,
-                                                           SeqPlan sp, float* __restrict__ out) {
+                                                           SeqPlan sp, float* __restrict__ out, EmbedFold fold) {
     const int lane = threadIdx.x & 63;
     const int64_t flat = int64_t(xcd_remap(blockIdx.x, gridDim.x)) * 4 + (threadIdx.x >> 6);
     const int64_t n_flat = int64_t(nb) * T;
@@ -139,20 +162,7 @@ __global__ __launch_bounds__(256) void embed_packed_kernel(const int64_t* __rest
         ps = pos_table ? pos[flat] : 0;
         dst = int64_t(sp.off[b]) + j;
     }
-    const bool ok = tok >= 0 && tok < n_vocab && ps >= 0 && (!pos_table || ps < n_position);
-    const float4* e = reinterpret_cast<const float4*>(emb + (ok ? tok : 0) * d);
-    const float4* q = pos_table ? reinterpret_cast<const float4*>(pos_table + (ok ? ps : 0) * d) : nullptr;
-    float4* o = reinterpret_cast<float4*>(out + dst * d);
-    const float nan = __builtin_nanf("");
-    for (int c = lane; c < d / 4; c += 64) {
-        float4 v = e[c];
-        if (q) {
-            const float4 w = q[c];
-            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-        }
-        if (!ok) v = make_float4(nan, nan, nan, nan);
-        o[c] = v;
-    }
+    gather_row(tok, ps, emb, n_vocab, pos_table, n_position, d, out, dst, fold, lane);
 }
 
 // The sequence plan AND the packed embedding gather in ONE launch (round 4: a dependent launch costs 5-8 us on this chain
@@ -244,7 +254,8 @@ __global__ __launch_bounds__(256) void embed_plan_kernel(const int64_t* __restri
                                                          const int64_t* __restrict__ plan_pos, int nb, int T,
                                                          const float* __restrict__ emb, int n_vocab,
                                                          const float* __restrict__ pos_table, int n_position, int d,
-                                                         SeqPlan sp, PlanGranules gr, int n_plan, float* __restrict__ out) {
+                                                         SeqPlan sp, PlanGranules gr, int n_plan, float* __restrict__ out,
+                                                         EmbedFold fold) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (int(blockIdx.x) < n_plan) {
         for (int b = int(blockIdx.x) * 4 + wave; b < nb; b += n_plan * 4) {
@@ -334,20 +345,7 @@ __global__ __launch_bounds__(256) void embed_plan_kernel(const int64_t* __restri
         if (j >= int(va)) return;
         dst = int64_t(vb) + j;
     }
-    const bool okt = tok >= 0 && tok < n_vocab && ps >= 0 && (!pos_table || ps < n_position);
-    const float4* e = reinterpret_cast<const float4*>(emb + (okt ? tok : 0) * d);
-    const float4* q = pos_table ? reinterpret_cast<const float4*>(pos_table + (okt ? ps : 0) * d) : nullptr;
-    float4* o = reinterpret_cast<float4*>(out + dst * d);
-    const float nan = __builtin_nanf("");
-    for (int c = lane; c < d / 4; c += 64) {
-        float4 v = e[c];
-        if (q) {
-            const float4 w = q[c];
-            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-        }
-        if (!okt) v = make_float4(nan, nan, nan, nan);
-        o[c] = v;
-    }
+    gather_row(tok, ps, emb, n_vocab, pos_table, n_position, d, out, dst, fold, lane);
 }
 
 // y = (x - mean) / sqrt(var_biased + eps) * g + b over the last dim.  Two-pass (mean, then centred
@@ -516,17 +514,34 @@ static inline int grid4(int64_t rows, unsigned* g) {
     return 0;
 }
 
+// fold (nullable): also write the first encoder layer's hidden rows from the folded tables (gather_row)
+static int check_fold(const EmbedFold* fold, const float* pos_table, EmbedFold* out) {
+    *out = EmbedFold{nullptr, nullptr, 0, nullptr};
+    if (!fold || !fold->hid) return 0;
+    if (!fold->e1 || (pos_table && !fold->p1)) return LAMP_E_NULL;
+    if (fold->dff <= 0 || (fold->dff & 3)) return LAMP_E_UNSUPPORTED;
+    if (!aligned16(fold->e1) || !aligned16(fold->hid) || (fold->p1 && !aligned16(fold->p1))) return LAMP_E_ALIGN;
+    *out = *fold;
+    if (!pos_table) out->p1 = nullptr;
+    return 0;
+}
+static inline double embed_bytes(int64_t n_tok, int d, bool pos, const EmbedFold& f) {
+    return double(n_tok) * (16.0 + 4.0 * d * (pos ? 3 : 2) + (f.hid ? 4.0 * f.dff * (pos ? 3 : 2) : 0.0));
+}
+
 int launch_embed(const int64_t* seq, const int64_t* pos, int64_t n_tok, const float* emb, int n_vocab,
-                 const float* pos_table, int n_position, int d, float* out, hipStream_t s) {
+                 const float* pos_table, int n_position, int d, float* out, hipStream_t s, const EmbedFold* fold) {
     if (n_tok <= 0 || d <= 0 || n_vocab <= 0) return LAMP_E_DIMS;
     if (d & 3) return LAMP_E_UNSUPPORTED;
     if (!seq || !emb || !out || (pos_table && !pos)) return LAMP_E_NULL;
     if (!aligned16(emb) || !aligned16(out) || (pos_table && !aligned16(pos_table))) return LAMP_E_ALIGN;
+    EmbedFold f;
+    if (int e = check_fold(fold, pos_table, &f)) return e;
     unsigned g;
     if (int e = grid4(n_tok, &g)) return e;
-    ProfScope prof(LAMP_K_EMBED, 0.0, double(n_tok) * (16.0 + 4.0 * d * (pos_table ? 3 : 2)), s);
+    ProfScope prof(LAMP_K_EMBED, 0.0, embed_bytes(n_tok, d, pos_table != nullptr, f), s);
     hipLaunchKernelGGL(embed_kernel, dim3(g), dim3(256), 0, s, seq, pos, n_tok, emb, n_vocab, pos_table,
-                       n_position, d, out);
+                       n_position, d, out, f);
     return int(hipGetLastError());
 }
 
@@ -591,30 +606,35 @@ int launch_seq_plan(const int64_t* seq, const int64_t* pos, int nb, int T, int64
 }
 
 int launch_embed_packed(const int64_t* seq, const int64_t* pos, int nb, int T, const float* emb, int n_vocab,
-                        const float* pos_table, int n_position, int d, const SeqPlan& sp, float* out, hipStream_t s) {
+                        const float* pos_table, int n_position, int d, const SeqPlan& sp, float* out, hipStream_t s,
+                        const EmbedFold* fold) {
     if (nb <= 0 || T <= 0 || d <= 0 || n_vocab <= 0) return LAMP_E_DIMS;
     if (d & 3) return LAMP_E_UNSUPPORTED;
     if (!seq || !emb || !out || (pos_table && !pos)) return LAMP_E_NULL;
     if (!aligned16(emb) || !aligned16(out) || (pos_table && !aligned16(pos_table))) return LAMP_E_ALIGN;
+    EmbedFold f;
+    if (int e = check_fold(fold, pos_table, &f)) return e;
     unsigned g;
     const int64_t n_tok = int64_t(nb) * T;
     if (int e = grid4(n_tok + 1, &g)) return e;
-    ProfScope prof(LAMP_K_EMBED, 0.0, double(n_tok) * (16.0 + 4.0 * d * (pos_table ? 3 : 2)), s);
+    ProfScope prof(LAMP_K_EMBED, 0.0, embed_bytes(n_tok, d, pos_table != nullptr, f), s);
     hipLaunchKernelGGL(embed_packed_kernel, dim3(g), dim3(256), 0, s, seq, pos, nb, T, emb, n_vocab, pos_table,
-                       n_position, d, sp, out);
+                       n_position, d, sp, out, f);
     return int(hipGetLastError());
 }
 
 // Plan + packed gather in one launch (embed_plan_kernel).  `granules`: 2 * nb + 2 unsigned 64-bit words of workspace, any content.
 int launch_embed_plan(const int64_t* seq, const int64_t* pos, bool plan_uses_pos, int nb, int T, const float* emb, int n_vocab,
                       const float* pos_table, int n_position, int d, const SeqPlan& sp, unsigned long long* granules, float* out,
-                      hipStream_t s) {
+                      hipStream_t s, const EmbedFold* fold) {
     if (nb <= 0 || T <= 0 || d <= 0 || n_vocab <= 0) return LAMP_E_DIMS;
     if (d & 3) return LAMP_E_UNSUPPORTED;
     if (!seq || !emb || !out || !granules || (pos_table && !pos) || (plan_uses_pos && !pos)) return LAMP_E_NULL;
     if (!aligned16(emb) || !aligned16(out) || (pos_table && !aligned16(pos_table)) || (reinterpret_cast<uintptr_t>(granules) & 7u))
         return LAMP_E_ALIGN;
     if (!sp.klen || !sp.plen || !sp.off || !sp.rows || !sp.padbits) return LAMP_E_NULL;
+    EmbedFold f;
+    if (int e = check_fold(fold, pos_table, &f)) return e;
     unsigned g;
     const int64_t n_tok = int64_t(nb) * T;
     if (int e = grid4(n_tok + 1, &g)) return e;
@@ -623,9 +643,9 @@ int launch_embed_plan(const int64_t* seq, const int64_t* pos, bool plan_uses_pos
     unsigned epoch = epoch_counter.fetch_add(1, std::memory_order_relaxed);
     if (epoch == 0) epoch = epoch_counter.fetch_add(1, std::memory_order_relaxed);
     PlanGranules gr{granules, granules + nb, epoch};
-    ProfScope prof(LAMP_K_EMBED, 0.0, double(n_tok) * (32.0 + 4.0 * d * (pos_table ? 3 : 2)), s);
+    ProfScope prof(LAMP_K_EMBED, 0.0, 16.0 * double(n_tok) + embed_bytes(n_tok, d, pos_table != nullptr, f), s);
     hipLaunchKernelGGL(embed_plan_kernel, dim3(g + unsigned(n_plan)), dim3(256), 0, s, seq, pos, plan_uses_pos ? pos : nullptr, nb, T, emb,
-                       n_vocab, pos_table, n_position, d, sp, gr, n_plan, out);
+                       n_vocab, pos_table, n_position, d, sp, gr, n_plan, out, f);
     return int(hipGetLastError());
 }
 

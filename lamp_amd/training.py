@@ -19,11 +19,20 @@ backward pass, and alone it is 64 output tiles at d_model = 512 -- a K split ove
 each.  The sub-layers' backward functions therefore only queue (parameter, dY, X); when the engine has run the whole
 graph, one ``lamp_gemm_grouped`` launch computes every queued product (28 of them for the 2+2-layer model) and the results
 are stored in (or accumulated into) the parameters' ``.grad`` -- what ``optimizer.step()`` reads next (train.py:40-48).
-Only leaf parameters are deferred; anything else (``nn.DataParallel`` replicas, ``torch.autograd.grad`` on a sub-module
-called directly) gets its gradient through autograd as before.
+A deferred gradient BYPASSES autograd (the sub-layer's backward returns None for it), so it is taken only where nothing can
+observe the difference -- decided twice:
+  * in the forward (``_deferrable``): every parameter is a leaf CUDA tensor that requires grad and carries no tensor hook
+    (``register_hook`` / ``register_post_accumulate_grad_hook``), and the forward does not run inside a
+    ``DistributedDataParallel`` wrapper (whose reducer hooks sit on the AccumulateGrad nodes, invisible from Python);
+  * in the backward (``_Deferral.live``): the engine is going to EXECUTE each parameter's AccumulateGrad node in this pass,
+    i.e. this is ``loss.backward()`` accumulating into ``.grad``.  Under ``torch.autograd.grad(loss, [w])`` and
+    ``loss.backward(inputs=[x])`` it is not, and the gradient goes through autograd as a tensor -- as it does for
+    ``nn.DataParallel`` replicas (non-leaf weights) and for everything when ``DEFER_WEIGHT_GRADS`` is False or inside
+    ``with weight_grad_deferral(False):`` (the switch for hook-based reducers / clippers this module cannot see).
 """
 import contextlib
 import threading
+import warnings
 
 import torch
 
@@ -53,7 +62,10 @@ class _WeightGrads(object):
     """The queues of deferred weight gradients, one per running backward pass (autograd graph task: a re-entrant backward
     inside a checkpointed region is its own task); each is flushed by its task's end-of-backward callback."""
 
-    MAX_TASKS = 4   # a pass that raised never runs its callback: its queue is dropped once this many newer passes exist
+    # a pass that raised never runs its callback: its queue (dY / X activations) is dropped once this many newer passes
+    # exist.  Live passes beyond that (deeply nested re-entrant checkpointing, many concurrent backward threads) would lose
+    # gradients: the eviction of a non-empty queue is therefore loud.
+    MAX_TASKS = 16
 
     def __init__(self):
         self.tasks = {}   # graph-task id -> (items, jobs)
@@ -67,7 +79,12 @@ class _WeightGrads(object):
             q = self.tasks[task] = ([], [])
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
             while len(self.tasks) > self.MAX_TASKS:
-                del self.tasks[min(self.tasks)]
+                oldest = min(self.tasks)
+                items, jobs = self.tasks.pop(oldest)
+                if items or jobs:
+                    warnings.warn('lamp_amd.training: dropped %d deferred weight gradients of backward pass %d (more than %d '
+                                  'passes in flight, or passes that raised); set training.DEFER_WEIGHT_GRADS = False if that '
+                                  'pass was alive' % (len(items) + len(jobs), oldest, self.MAX_TASKS), RuntimeWarning)
         return q
 
     def pending(self):
@@ -135,14 +152,56 @@ class _WeightGrads(object):
 _weight_grads = _WeightGrads()
 
 
+@contextlib.contextmanager
+def weight_grad_deferral(enabled):
+    """``with weight_grad_deferral(False): loss = model(...); loss.backward()`` -- every weight gradient of forwards run
+    inside goes through autograd (for gradient hooks this module cannot see: DDP-style reducers on AccumulateGrad nodes)."""
+    global DEFER_WEIGHT_GRADS
+    before = DEFER_WEIGHT_GRADS
+    DEFER_WEIGHT_GRADS = bool(enabled)
+    try:
+        yield
+    finally:
+        DEFER_WEIGHT_GRADS = before
+
+
+def _inside_ddp_forward():
+    ddp = getattr(torch.nn.parallel, 'DistributedDataParallel', None)
+    return getattr(ddp, '_active_ddp_module', None) is not None
+
+
+class _Deferral(tuple):
+    """The leaf Parameters of one sub-layer whose gradients MAY bypass autograd, with their AccumulateGrad nodes."""
+
+    def __new__(cls, params):
+        self = super().__new__(cls, params)
+        with torch.enable_grad():   # the accumulator node of a leaf: what loss.backward() runs to fill .grad
+            self.nodes = [p.view_as(p).grad_fn.next_functions[0][0] for p in params if p is not None]
+        return self
+
+    def live(self):
+        """Called inside the backward pass: self if this pass accumulates into every parameter's .grad, else None."""
+        try:
+            for n in self.nodes:
+                if not torch._C._will_engine_execute_node(n):
+                    return None    # backward(inputs=[...]) that leaves this parameter out
+        except RuntimeError:
+            return None            # torch.autograd.grad(): gradients are captured, not accumulated
+        return self
+
+
 def _deferrable(*params):
-    """The parameters themselves if their gradients may bypass autograd (see the module docstring), else None."""
-    if not DEFER_WEIGHT_GRADS:
+    """A _Deferral of the parameters if their gradients may bypass autograd (see the module docstring), else None."""
+    if not DEFER_WEIGHT_GRADS or _inside_ddp_forward():
         return None
     for p in params:
-        if p is not None and not (p.is_leaf and p.requires_grad and p.is_cuda):
+        if p is None:
+            continue
+        if not (p.is_leaf and p.requires_grad and p.is_cuda):
             return None
-    return params
+        if p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None):
+            return None   # a hook would fire with grad=None before the real gradient exists
+    return _Deferral(params)
 
 
 class _Seeds(object):
@@ -214,8 +273,8 @@ class _FFNFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, h, o, w1, w2, ln_g = ctx.saved_tensors
         W1, W2 = _w2d(w1), _w2d(w2)
+        defer = ctx.defer.live() if ctx.defer is not None else None
         if ctx.composite:
-            defer = ctx.defer
             wait1, wait2 = defer is not None, defer is not None and ctx.p > 0
             dx, d_o, dh, dW1, dW2, db1, db2, dg, db, pending = N.ffn_bwd(
                 x2, h, o, dy.reshape(x2.shape).contiguous(), W1, W2, ln_g, ctx.p, ctx.seed, not wait1, not wait2,
@@ -231,7 +290,6 @@ class _FFNFn(torch.autograd.Function):
                     dg, db, None, None, None)
         dz, do, dg, db, db2 = N.layernorm_bwd(o, x2, ln_g, dy.reshape(x2.shape), dropout_p=ctx.p, seed=ctx.seed,
                                               want_dbias=True)
-        defer = ctx.defer
         # do IS dz when there is no dropout, and dz is accumulated into below: that product cannot wait
         if defer is not None and do is not dz:
             _weight_grads.add(defer[1], do, h)
@@ -274,11 +332,14 @@ class _MHAFn(torch.autograd.Function):
                                   seed_out & 0xffffffff)
             q, k, v, a, P, Pd, o, y = N.mha_train_fwd(desc, xq, xkv, xkv if xv is None else xv, wq, wk, wv, fc, ln_g, ln_b,
                                                      mask)
-            ctx.save_for_backward(xq, xkv, wq, wk, wv, fc if fc is not None else wq.new_empty(0), ln_g, q, k, v, a, P,
-                                  o if o is not None else a, xv if xv is not None else wq.new_empty(0))
-            ctx.cfg = (B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, fc is not None, xv is not None)
             attn = Pd if p_attn > 0 else P.clone()
-            ctx.Pd = Pd   # the dropped map is what the value product used: kept for the backward instead of recomputed
+            # the dropped map is what the value product used: kept for the backward instead of recomputed -- and it is the map
+            # the caller gets, so it is SAVED (version-checked: an in-place edit by the caller raises in backward instead of
+            # corrupting the gradients silently)
+            ctx.save_for_backward(xq, xkv, wq, wk, wv, fc if fc is not None else wq.new_empty(0), ln_g, q, k, v, a, P,
+                                  o if o is not None else a, xv if xv is not None else wq.new_empty(0),
+                                  Pd if p_attn > 0 else wq.new_empty(0))
+            ctx.cfg = (B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, fc is not None, xv is not None)
             ctx.mark_non_differentiable(attn)
             return y, attn
         q = N.linear(xq, wq)
@@ -293,7 +354,7 @@ class _MHAFn(torch.autograd.Function):
         o = N.linear(a, fc) if fc is not None else a
         y = N.layernorm_residual(o, xq, ln_g, ln_b, dropout_p=p_out, seed=seed_out)
         ctx.save_for_backward(xq, xkv, wq, wk, wv, fc if fc is not None else wq.new_empty(0), ln_g, q, k, v, a, P, o,
-                              xv if xv is not None else wq.new_empty(0))
+                              xv if xv is not None else wq.new_empty(0), wq.new_empty(0))
         ctx.cfg = (B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, fc is not None, xv is not None)
         attn = Pd if p_attn > 0 else P.clone()  # what the reference returns (lamp/SubLayers.py:40-43): the dropped map
         ctx.mark_non_differentiable(attn)
@@ -301,15 +362,15 @@ class _MHAFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dP_unused):
-        xq, xkv, wq, wk, wv, fc, ln_g, q, k, v, a, P, o, xv = ctx.saved_tensors
+        xq, xkv, wq, wk, wv, fc, ln_g, q, k, v, a, P, o, xv, Pd_saved = ctx.saved_tensors
         B, lq, lk, H, dk, dv, inv_t, p_attn, p_out, seed_attn, seed_out, has_fc, has_xv = ctx.cfg
         d = xq.size(-1)
+        defer = ctx.defer.live() if ctx.defer is not None else None
         if ctx.composite:
-            defer = ctx.defer
             wait, wait_fc = defer is not None, defer is not None and p_out > 0
             desc = N.MhaTrainDesc(B, lq, lk, d, H, dk, dv, inv_t, p_attn, p_out, seed_attn & 0xffffffff,
                                   seed_out & 0xffffffff)
-            r = N.mha_bwd(desc, xq, xkv, xv if has_xv else xkv, q, k, v, a, P, ctx.Pd, o if has_fc else None,
+            r = N.mha_bwd(desc, xq, xkv, xv if has_xv else xkv, q, k, v, a, P, Pd_saved if p_attn > 0 else None, o if has_fc else None,
                           dy.reshape(B * lq, d).contiguous(), wq, wk, wv, fc if has_fc else None, ln_g, has_xv, not wait,
                           not wait_fc, defer_reduce=wait, shared_qk=ctx.shared_qk)
             if r['pending'] is not None:
@@ -329,7 +390,6 @@ class _MHAFn(torch.autograd.Function):
         dz, do, dg, db, _ = N.layernorm_bwd(o.view(xq2.shape), xq2, ln_g, dy.reshape(xq2.shape), dropout_p=p_out,
                                             seed=seed_out)
         a2 = a.view(-1, H * dv)
-        defer = ctx.defer
         if has_fc:
             if defer is not None and do is not dz:   # do IS dz without dropout, and dz is accumulated into below
                 _weight_grads.add(defer[3], do, a2)

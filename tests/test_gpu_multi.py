@@ -221,6 +221,7 @@ def test_replicas_in_threads_match_the_original(dev):
     """DataParallel-style: replicas (no Parameters, fresh tensors, a stale copied cache) run in one host thread each."""
     m, sd, blocked, seq, spos, h = make_case(CONFIGS['reuters_ragged'], dev)
     seq, spos = seq.to(dev), spos.to(dev)
+    m.fold_embedding = False    # replicas keep no weights-only tables: they run the unfolded route (same bits as this)
     plain, enc_plain, _ = m((seq, spos), None, None, None)      # also fills the original's descriptor cache
     for _ in range(2):                                          # replicas are rebuilt per forward, as DataParallel does
         reps = _replicas(m, 2)

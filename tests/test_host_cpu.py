@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(N.PROTOTYPES) == names  # the ctypes binding covers the whole header
-    assert N.lib().lamp_version() == N.ABI_VERSION == 4
+    assert N.lib().lamp_version() == N.ABI_VERSION == 5
     # the product library exports no tuning / debug hook (those live in the -DLAMP_TUNING build only)
     exported = subprocess.run(['nm', '-D', '--defined-only', N.LIB_PATH], capture_output=True, text=True).stdout
     assert 'lamp_debug' not in exported and 'lamp_set_forward_streams' not in exported
@@ -55,7 +55,7 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(N.FfnWeights) == 48
     assert ctypes.sizeof(N.EncLayer) == 104
     assert ctypes.sizeof(N.DecLayer) == 208
-    assert ctypes.sizeof(N.Model) == 128
+    assert ctypes.sizeof(N.Model) == 144
     assert ctypes.sizeof(N.ChainPack) == 48
     assert ctypes.sizeof(N.Aux) == 40
     assert ctypes.sizeof(N.GemmDesc) == 160

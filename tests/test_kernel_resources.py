@@ -20,7 +20,7 @@ from conftest import ROOT
 from lamp_amd import build as B
 
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
-import check_untracked_loads as CUL  # noqa: E402
+from lamp_amd import isa_guard as CUL  # noqa: E402   (tools/check_untracked_loads.py is its command line)
 import count_loop_valu as CLV  # noqa: E402
 
 # kernels allowed to spill: (translation unit, name) -> max bytes per lane.  Neither uses inline-assembly loads.
@@ -57,6 +57,27 @@ def test_no_kernel_spills_and_the_chain_uses_no_agprs(tuning):
     for want in ('lamp::chain_kernel<2, 16, 32, 2, 1>', 'lamp::chain_packed_kernel<2, 16, 32, 4>', 'lamp::chain_rows4_kernel<2, 3>'):
         assert want in prod, sorted(prod)
         assert prod[want]['occupancy'] >= (2 if 'rows4' in want else 4), prod[want]
+
+
+def test_the_build_runs_the_guards_and_stamps_its_toolchain(tmp_path, monkeypatch):
+    """lamp_amd.build.build() itself refuses to link a library whose hand-scheduled kernels fail the ISA / resource
+    rules (tools/check_untracked_loads.py is only the command line of the same checker), and records the compiler."""
+    B.build()
+    assert B.verify() == []                       # stamped verdicts of the build in the tree
+    assert B.built_toolchain() == B.toolchain() and 'clang version' in B.toolchain()
+    # a finding fails the build before anything is linked (the guard's verdict is forced; nothing is compiled here)
+    monkeypatch.setattr(B, 'verify', lambda verbose=False: ['chain.hip: forced finding'])
+    monkeypatch.setattr(B, 'needs_build', lambda: True)
+    monkeypatch.setattr(B, 'LIB', str(tmp_path / 'liblamp_hip.so'))
+    monkeypatch.setattr(B, 'LIB_TUNING', str(tmp_path / 'liblamp_hip_tuning.so'))
+    (tmp_path / 'liblamp_hip.so').write_bytes(b'stale')
+    with pytest.raises(RuntimeError, match='ISA guard'):
+        B.build()
+    assert not (tmp_path / 'liblamp_hip.so').exists()
+    # the resource rule: AGPRs or scratch in a guarded kernel
+    monkeypatch.setattr(B, 'kernel_resources', lambda s, t: {'lamp::chain_rows4_kernel<2, 3>': {'agpr': 4, 'scratch': 0},
+                                                              'lamp::gemm_nt_kernel<1>': {'agpr': 64, 'scratch': 0}})
+    assert len(B._resource_problems('chain.hip', False)) == 1
 
 
 def test_checker_sees_a_copy_behind_an_untracked_load():
@@ -135,13 +156,10 @@ def test_the_tile_attention_kernel_owns_m0():
     (hipcc rejects m0 in a clobber list as reserved): sound as long as nothing else in the kernel uses m0 -- every mention of
     it in the ISA must be an `s_mov_b32 m0` of ours, followed by s_nop and the buffer_load ... lds it belongs to."""
     asm = CUL.device_asm(os.path.join(ROOT, 'lamp_amd', 'csrc', 'attention_tile.hip'))
-    lines = [l.strip() for l in asm.split('\n')]
-    uses = [i for i, l in enumerate(lines) if re.search(r'\bm0\b', l) and not l.startswith(';')]
-    assert len(uses) > 20
-    for i in uses:
-        assert lines[i].startswith('s_mov_b32 m0, s'), lines[i]
-        assert lines[i + 1].startswith('s_nop') and lines[i + 2].startswith('buffer_load_dwordx4') and lines[i + 2].endswith('lds'), lines[i:i + 3]
-    assert sum(l.endswith(' lds') and l.startswith('buffer_load') for l in lines) == len(uses)
+    n, bad = CUL.m0_findings(asm)
+    assert n > 20 and bad == [], bad[:5]
+    # ... and the rule sees an m0 write that is not followed by its LDS-DMA load
+    assert CUL.m0_findings('s_mov_b32 m0, s5\ns_nop 0\nv_mov_b32_e32 v1, v2\n')[1]
 
 
 # ---- vector instructions in the MFMA loops: matrix-pipe time on gfx950 (profiles/r05_mfma_chain.txt) ----

@@ -100,6 +100,85 @@ def test_reentrant_backward_has_its_own_queue(grouped):
     assert torch.allclose(w1.grad, r1, atol=1e-5) and torch.allclose(w2.grad, r2, atol=1e-5)
 
 
+class _LinSafe(torch.autograd.Function):
+    """y = x W^T deferring only when the pass accumulates into .grad -- the decision _FFNFn / _MHAFn take (_Deferral.live)."""
+
+    @staticmethod
+    def forward(ctx, x, w, defer):
+        ctx.save_for_backward(x, w)
+        ctx.defer = defer
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        defer = ctx.defer.live() if ctx.defer is not None else None
+        if defer is not None:
+            training._weight_grads.add(defer[0], dy, x)
+            return dy @ w, None, None
+        return dy @ w, dy.t() @ x, None
+
+
+def _deferral_on_cpu(*params):
+    """_deferrable without its `is_cuda` requirement (there is no device here): hooks and switches still decide."""
+    real = torch.Tensor.is_cuda
+    try:
+        torch.Tensor.is_cuda = property(lambda self: True)
+        return training._deferrable(*params)
+    finally:
+        torch.Tensor.is_cuda = real
+
+
+def test_deferral_never_hides_a_gradient_from_autograd(grouped):
+    """torch.autograd.grad and backward(inputs=...) get their gradients through autograd (a deferred gradient is
+    returned as None and written into .grad afterwards); tensors with gradient hooks are never deferred."""
+    g = torch.Generator().manual_seed(4)
+    w = torch.nn.Parameter(torch.randn(4, 3, generator=g))
+    x = torch.randn(5, 3, generator=g, requires_grad=True)
+    d = _deferral_on_cpu(w)
+    assert d is not None and d[0] is w
+    ref_w, ref_x = torch.autograd.grad((x @ w.t()).square().sum(), (w, x))
+    # loss.backward(): deferred, .grad filled by the end-of-backward flush
+    _LinSafe.apply(x, w, d).square().sum().backward()
+    assert grouped == [1] and torch.allclose(w.grad, ref_w, atol=1e-5)
+    # torch.autograd.grad: the gradient comes back as a tensor and .grad is not touched
+    w.grad = None
+    gw, = torch.autograd.grad(_LinSafe.apply(x, w, d).square().sum(), [w])
+    assert grouped == [1] and torch.allclose(gw, ref_w, atol=1e-5) and w.grad is None
+    # backward(inputs=[x]): nothing lands in w.grad
+    x.grad = None
+    _LinSafe.apply(x, w, d).square().sum().backward(inputs=[x])
+    assert grouped == [1] and w.grad is None and torch.allclose(x.grad, ref_x, atol=1e-5)
+    # backward(inputs=[w]) accumulates into w.grad: deferred again
+    _LinSafe.apply(x, w, d).square().sum().backward(inputs=[w])
+    assert grouped == [1, 1] and torch.allclose(w.grad, ref_w, atol=1e-5)
+    # hooks see real gradients: such a parameter is not deferred at all
+    seen = []
+    h = w.register_hook(lambda gr: seen.append(gr.clone()))
+    assert _deferral_on_cpu(w) is None
+    w.grad = None
+    _LinSafe.apply(x, w, _deferral_on_cpu(w)).square().sum().backward()
+    assert grouped == [1, 1] and len(seen) == 1 and torch.allclose(seen[0], ref_w, atol=1e-5)
+    h.remove()
+    h2 = w.register_post_accumulate_grad_hook(lambda p: seen.append(p.grad.clone()))
+    assert _deferral_on_cpu(w) is None
+    h2.remove()
+    assert _deferral_on_cpu(w) is not None
+    with training.weight_grad_deferral(False):
+        assert _deferral_on_cpu(w) is None
+    assert _deferral_on_cpu(w) is not None
+
+
+def test_eviction_of_a_live_queue_is_loud(grouped):
+    w = torch.nn.Parameter(torch.randn(2, 2))
+    wg = training._weight_grads
+    for t in range(wg.MAX_TASKS + 1):
+        wg.tasks[1000 + t] = ([(w, torch.zeros(1, 2), torch.zeros(1, 2))], [])
+    x = torch.randn(3, 2, requires_grad=True)
+    with pytest.warns(RuntimeWarning, match='dropped'):
+        _Lin.apply(x, w, w).sum().backward()
+
+
 def test_only_leaf_parameters_are_deferred():
     w = torch.nn.Parameter(torch.randn(3, 3))
     assert training._deferrable(w) is None          # not on the device
