@@ -67,9 +67,15 @@ enum lamp_mask_kind {
                                      past lk are ignored.  One 4-byte load covers a whole 32-key tile of a row. */
 };
 
+/* lamp_mask.flags */
+#define LAMP_MASK_SPARSE_ROWS 1  /* a SHARED bit-packed mask (kind BITS_U32, stride_b == 0) whose rows allow only a small fraction
+                                    of the keys, with no block structure to skip (an unstructured label graph): the library may
+                                    compute the allowed (query, key) pairs only (csrc/attention_sparse.hip) instead of visiting every
+                                    key tile.  Set by the caller from the mask's density (lamp_amd/Decoders.py); exact either way. */
+
 typedef struct lamp_mask {
     int32_t kind;
-    int32_t reserved;
+    int32_t flags;               /* LAMP_MASK_SPARSE_ROWS or 0 */
     const void* ptr;
     int64_t stride_b;
     int64_t stride_q;
@@ -80,6 +86,9 @@ typedef struct lamp_mask {
      * label graph's block structure (lamp/Decoders.py:109-113) handed to the kernel once per model. */
     const int32_t* tile_list;
     int64_t tile_list_stride;
+    int64_t allowed_pairs;       /* with LAMP_MASK_SPARSE_ROWS: number of unblocked (query, key) entries of the shared mask (the
+                                    work the pair kernel executes: lamp_prof_* counts 2 * allowed_pairs * (d_k + d_v) FLOP per
+                                    (sample, head) for it); 0 = unknown */
 } lamp_mask;
 
 /* Element strides of the four attention operands, so that one kernel serves both the
@@ -146,7 +155,7 @@ typedef struct lamp_model {
     int32_t n_src_vocab, n_position, n_labels;
     int32_t d_model, d_inner, d_k, d_v;
     int32_t n_layers_enc, n_layers_dec;
-    int32_t reserved;
+    int32_t label_mask_flags;   /* lamp_mask.flags of the label graph (LAMP_MASK_SPARSE_ROWS), 0 otherwise */
     const float* src_word_emb;  /* [n_src_vocab, d_model]  encoder.src_word_emb.weight */
     const float* position_enc;  /* [n_position, d_model] or NULL (no_enc_pos_embedding) */
     const float* tgt_word_emb;  /* [n_labels, d_model]     decoder.tgt_word_emb.weight */
@@ -176,6 +185,7 @@ typedef struct lamp_model {
      * results differ from the unfolded route in the last bits (not bit-identical, well inside 1e-4).  NULL = unfolded. */
     const float* enc0_emb_w1;
     const float* enc0_pos_w1;
+    int64_t label_mask_allowed; /* lamp_mask.allowed_pairs of the label graph (with LAMP_MASK_SPARSE_ROWS), else 0 */
 } lamp_model;
 
 /* Optional extra outputs of lamp_forward (return_attns / int_preds, lamp/Models.py:127-135).

@@ -31,6 +31,9 @@ def build_label_mask(n_tgt_vocab, label_adj_matrix, label_mask):
 
 
 class GraphDecoder(nn.Module):
+    TILE_HINT_MAX_DENSITY = 0.9   # active 32x32 tiles / all tiles from which the tile-list hint is not handed to the kernels
+    SPARSE_ROWS_MAX_DENSITY = 0.125   # allowed pairs / L^2 up to which an unstructured graph is flagged LAMP_MASK_SPARSE_ROWS
+
     def __init__(self, n_tgt_vocab, n_max_seq, n_layers=6, n_head=8, n_head2=8, d_k=64, d_v=64,
                  d_word_vec=512, d_model=512, d_inner_hid=1024, dropout=0.1, dropout2=0.1,
                  no_dec_self_att=False, label_adj_matrix=None, label_mask=None, enc_vec=True,
@@ -51,9 +54,22 @@ class GraphDecoder(nn.Module):
         self.register_buffer('label_mask_bits', N.pack_mask_bits(blocked) if blocked is not None else None,
                              persistent=False)
         # block structure of the label graph: per 32-label query block, the 32-label key tiles with at least
-        # one edge -- lets the attention kernel skip fully blocked tiles (large sparse / clustered graphs)
-        self.register_buffer('label_tiles', N.active_tile_list(blocked) if blocked is not None else None,
-                             persistent=False)
+        # one edge -- lets the attention kernel skip fully blocked tiles (large sparse / clustered graphs).  The hint is
+        # dropped when it cannot help: on an unstructured graph (BASELINE configs[4]'s Bernoulli(0.05) prior: every tile
+        # holds an edge) walking the list only costs (-0.7 % attention at L = 4096, profiles/r05_sparse_label_attention.txt).
+        tiles = N.active_tile_list(blocked) if blocked is not None else None
+        self.label_tile_density = None
+        if tiles is not None:
+            self.label_tile_density = float(tiles[:, 0].sum()) / float(tiles.size(0) * (tiles.size(1) - 1))
+            if self.label_tile_density >= self.TILE_HINT_MAX_DENSITY:
+                tiles = None
+        self.register_buffer('label_tiles', tiles, persistent=False)
+        # ... and an unstructured graph whose ROWS are sparse (configs[4]: ~5 % of the keys per label) is flagged for the pair
+        # kernel (csrc/attention_sparse.hip computes the allowed (query, key) pairs only; the library takes it for >= 1024 labels
+        # with 128-wide heads).  Measured break-even against the dense tile kernel: profiles/r06_sparse_label_attention.txt.
+        self.label_allowed_pairs = int((blocked == 0).sum()) if blocked is not None else 0
+        self.label_rows_sparse = bool(blocked is not None and tiles is None and
+                                      self.label_allowed_pairs <= self.SPARSE_ROWS_MAX_DENSITY * blocked.numel())
         self.layer_stack = nn.ModuleList(
             DecoderLayer(d_model, d_inner_hid, n_head, n_head2, d_k, d_v, dropout=dropout, dropout2=dropout2,
                          no_dec_self_att=no_dec_self_att, attn_type=attn_type) for _ in range(n_layers))
@@ -67,8 +83,12 @@ class GraphDecoder(nn.Module):
         t, bits = self.label_tiles, self.label_mask_bits
         tl = (t.data_ptr() if t is not None else None, t.size(1) if t is not None else 0)
         if bits is not None:
-            return N.Mask(N.LAMP_MASK_BITS_U32, 0, bits.data_ptr(), 0, bits.size(1), *tl)
+            sparse = self.label_rows_sparse and self.use_sparse_rows
+            return N.Mask(N.LAMP_MASK_BITS_U32, N.LAMP_MASK_SPARSE_ROWS if sparse else 0, bits.data_ptr(), 0, bits.size(1), *tl,
+                          self.label_allowed_pairs if sparse else 0)
         return N.Mask(N.LAMP_MASK_U8, 0, m.data_ptr(), 0, L, *tl)
+
+    use_sparse_rows = True   # A/B switch of the pair kernel (False: the dense tile kernels visit every key)
 
     def forward(self, tgt, src_seq, enc_output, return_attns=False, int_preds=False):
         B = src_seq.size(0)
@@ -80,7 +100,7 @@ class GraphDecoder(nn.Module):
             from . import training
             y = training._LabelRowsFn.apply(self.tgt_word_emb.weight, B)
             if label_mask is not None:
-                label_mask = N.Mask(label_mask.kind, 0, label_mask.ptr, label_mask.stride_b, label_mask.stride_q, None, 0)
+                label_mask = N.Mask(label_mask.kind, 0, label_mask.ptr, label_mask.stride_b, label_mask.stride_q, None, 0, 0)
         else:
             y = self.tgt_word_emb.weight.unsqueeze(0).expand(B, -1, -1).contiguous()
         # lamp/Decoders.py:136-138: with a vector encoder there is nothing to pad-mask

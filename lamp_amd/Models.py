@@ -186,8 +186,9 @@ class LAMP(nn.Module):
         hoist = self.cache_layer0_query and not replica   # the hoisted projection needs a one-off stream sync
         packs = self.use_chain_packs and not replica      # weights-only repacks: same one-off cost, same staleness rule
         fold = self.fold_embedding and not replica and len(self.encoder.layer_stack) > 0   # weights-only tables, likewise
+        sparse = bool(self.use_sparse_label_attention and self.use_mask_bits and self.decoder.label_rows_sparse)
         key = tuple(p.data_ptr() for p in params) + (N.ptr(mask), N.ptr(bits), N.ptr(tiles), self.use_label_tiles,
-                                                      hoist, self.use_mask_bits, packs, fold)
+                                                      hoist, self.use_mask_bits, packs, fold, sparse)
         if hoist:  # the hoisted projection below is stale once either operand changes
             l0 = self.decoder.layer_stack[0].enc_attn
             key += (self.decoder.tgt_word_emb.weight._version, l0.w_qs.weight._version)
@@ -217,9 +218,10 @@ class LAMP(nn.Module):
             raise NotImplementedError('proj_share_weight=False read-out is not on the graph path')
         m = N.Model(enc.src_word_emb.weight.size(0), pos.size(0) if pos is not None else 0, self.n_labels,
                     self.d_model, self.d_inner, self.d_k, self.d_v, len(enc.layer_stack), len(dec.layer_stack),
-                    0, N.ptr(enc.src_word_emb.weight), N.ptr(pos), N.ptr(dec.tgt_word_emb.weight),
+                    N.LAMP_MASK_SPARSE_ROWS if sparse else 0, N.ptr(enc.src_word_emb.weight), N.ptr(pos), N.ptr(dec.tgt_word_emb.weight),
                     N.ptr(w_out), N.ptr(mask), N.ptr(bits) if self.use_mask_bits else 0,
                     N.ptr(tiles) if self.use_label_tiles else 0, enc_arr, dec_arr, 0)
+        m.label_mask_allowed = self.decoder.label_allowed_pairs if sparse else 0
         q0 = None
         if hoist and len(dec.layer_stack) > 0:
             # decoder layer 0's query = label table x W_q: weights only, so it is projected here once per
@@ -382,5 +384,8 @@ class LAMP(nn.Module):
     fold_embedding = True
     # Skip fully blocked 32x32 tiles of the label graph in the label->label attention.
     use_label_tiles = True
+    # Compute only the allowed (query, key) pairs of a sparse, unstructured label graph (csrc/attention_sparse.hip; the
+    # decoder flags such graphs, GraphDecoder.label_rows_sparse).  False = the dense tile kernels.
+    use_sparse_label_attention = True
     # Read the label mask bit-packed (one 32-bit word per 32-key tile and row) instead of as bytes.
     use_mask_bits = True

@@ -17,6 +17,7 @@ TUNING_LIB_PATH = os.path.join(_HERE, 'liblamp_hip_tuning.so')
 
 ABI_VERSION = 5
 LAMP_MASK_NONE, LAMP_MASK_U8, LAMP_MASK_KEY_TOKENS_I64, LAMP_MASK_BITS_U32 = 0, 1, 2, 3
+LAMP_MASK_SPARSE_ROWS = 1   # lamp_mask.flags (include/lamp_hip.h)
 K_EMBED, K_GEMM, K_ATTN, K_LAYERNORM, K_DIAG, K_COUNT = 0, 1, 2, 3, 4, 5
 KERNEL_CLASS_NAMES = ('embed', 'gemm', 'attention', 'layernorm', 'diag_readout')
 
@@ -33,9 +34,9 @@ _vp = C.c_void_p
 
 
 class Mask(C.Structure):
-    _fields_ = [('kind', C.c_int32), ('reserved', C.c_int32), ('ptr', _vp),
+    _fields_ = [('kind', C.c_int32), ('flags', C.c_int32), ('ptr', _vp),
                 ('stride_b', C.c_int64), ('stride_q', C.c_int64),
-                ('tile_list', _vp), ('tile_list_stride', C.c_int64)]
+                ('tile_list', _vp), ('tile_list_stride', C.c_int64), ('allowed_pairs', C.c_int64)]
 
 
 class AttnLayout(C.Structure):
@@ -68,11 +69,11 @@ class ChainPack(C.Structure):  # include/lamp_hip.h: lamp_chain_pack
 class Model(C.Structure):
     _fields_ = [('n_src_vocab', C.c_int32), ('n_position', C.c_int32), ('n_labels', C.c_int32),
                 ('d_model', C.c_int32), ('d_inner', C.c_int32), ('d_k', C.c_int32), ('d_v', C.c_int32),
-                ('n_layers_enc', C.c_int32), ('n_layers_dec', C.c_int32), ('reserved', C.c_int32),
+                ('n_layers_enc', C.c_int32), ('n_layers_dec', C.c_int32), ('label_mask_flags', C.c_int32),
                 ('src_word_emb', _vp), ('position_enc', _vp), ('tgt_word_emb', _vp), ('w_out', _vp),
                 ('label_mask', _vp), ('label_mask_bits', _vp), ('label_tiles', _vp), ('enc_layers', C.POINTER(EncLayer)), ('dec_layers', C.POINTER(DecLayer)),
                 ('dec0_query', _vp), ('chain_packs', C.POINTER(ChainPack)),
-                ('enc0_emb_w1', _vp), ('enc0_pos_w1', _vp)]
+                ('enc0_emb_w1', _vp), ('enc0_pos_w1', _vp), ('label_mask_allowed', C.c_int64)]
 
 
 class GemmDesc(C.Structure):  # include/lamp_hip.h: lamp_gemm_desc
@@ -845,14 +846,20 @@ def prior_graph(label_ids, offsets, n_labels, want_blocked=False):
     return (adj, blocked) if want_blocked else adj
 
 
-def sigmoid_bce(logits, targets=None):
-    """-> (sigmoid(logits), per-row summed BCE-with-logits or None)   (test.py:49-51)."""
-    require_device(logits, targets)
+def sigmoid_bce(logits, targets=None, probs_out=None, row_loss_out=None):
+    """-> (sigmoid(logits), per-row summed BCE-with-logits or None)   (test.py:49-51).  probs_out (B, L) / row_loss_out (B,):
+    contiguous fp32 device buffers to write into (an evaluation epoch keeps one of each for the whole split)."""
+    require_device(logits, targets, probs_out, row_loss_out)
     x = f32c(logits)
     B, L = x.shape
-    probs = torch.empty_like(x)
+    for o, shape in ((probs_out, (B, L)), (row_loss_out, (B,))):
+        if o is not None and (tuple(o.shape) != shape or o.dtype != torch.float32 or not o.is_contiguous()):
+            raise ValueError('sigmoid_bce: output buffer must be contiguous fp32 of shape %s' % (shape,))
+    probs = probs_out if probs_out is not None else torch.empty_like(x)
     z = f32c(targets) if targets is not None else None
-    row_loss = torch.empty((B,), dtype=torch.float32, device=x.device) if z is not None else None
+    row_loss = None
+    if z is not None:
+        row_loss = row_loss_out if row_loss_out is not None else torch.empty((B,), dtype=torch.float32, device=x.device)
     check(lib().lamp_sigmoid_bce_fwd(ptr(x), ptr(z), B, L, ptr(probs), ptr(row_loss), stream()),
           'lamp_sigmoid_bce_fwd')
     return probs, row_loss

@@ -28,9 +28,10 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'liblamp_hip.so')
 LIB_TUNING = os.path.join(HERE, 'liblamp_hip_tuning.so')
-SOURCES = ['gemm.hip', 'gemm_gen.hip', 'attention.hip', 'attention_tile.hip', 'attention_small.hip', 'attention_general.hip', 'pointwise.hip',
+SOURCES = ['gemm.hip', 'gemm_gen.hip', 'attention.hip', 'attention_tile.hip', 'attention_small.hip', 'attention_general.hip', 'attention_sparse.hip',
+           'pointwise.hip',
            'backward.hip', 'chain.hip', 'api.hip']
-TUNING_SOURCES = {'gemm.hip', 'attention.hip', 'attention_tile.hip', 'attention_small.hip', 'chain.hip'}
+TUNING_SOURCES = {'gemm.hip', 'attention.hip', 'attention_tile.hip', 'attention_small.hip', 'attention_sparse.hip', 'chain.hip'}
 TUNING_ONLY = ['slab.hip']   # experiments kept bit-identical and benchmarkable, not part of the product library   # the units that contain LAMP_TUNING code
 HEADERS = [os.path.join(CSRC, 'lamp_kernels.h'), os.path.join(CSRC, 'lamp_asm.h'), os.path.join(HERE, '..', 'include', 'lamp_hip.h')]
 REMARKS = ['-Rpass-analysis=kernel-resource-usage']   # per-kernel VGPR / AGPR / scratch report, saved beside each object

@@ -206,6 +206,8 @@ static int mha_core(const float* xq, bool xq_shared, const float* xkv, int B, in
     a.m_sq = mask ? mask->stride_q : 0;
     a.tiles = (mask && !attn) ? mask->tile_list : nullptr;
     a.tiles_stride = mask ? mask->tile_list_stride : 0;
+    a.sparse_rows = mask && (mask->flags & LAMP_MASK_SPARSE_ROWS) != 0;
+    a.allowed_pairs = mask ? mask->allowed_pairs : 0;
     if (keys && mask && mask->kind == LAMP_MASK_KEY_TOKENS_I64) {
         a.kv_len = keys->klen;
         a.kv_off = keys->off;
@@ -365,6 +367,8 @@ int sdpa_impl(const float* q, const float* k, const float* v, float* out, float*
     a.m_sq = mask ? mask->stride_q : 0;
     a.tiles = (mask && !attn) ? mask->tile_list : nullptr;
     a.tiles_stride = mask ? mask->tile_list_stride : 0;
+    a.sparse_rows = mask && (mask->flags & LAMP_MASK_SPARSE_ROWS) != 0;
+    a.allowed_pairs = mask ? mask->allowed_pairs : 0;
     return launch_attn(a, hipStream_t(stream));
 }
 }  // namespace
@@ -480,7 +484,8 @@ int lamp_diag_logits_fwd(const float* y, const float* w_out, int32_t B, int32_t 
 }
 
 static_assert(sizeof(lamp_gemm_desc) == 160, "lamp_gemm_desc layout is part of the ABI");
-static_assert(sizeof(lamp_model) == 144, "lamp_model layout is part of the ABI (lamp_amd/_native.py: Model)");
+static_assert(sizeof(lamp_mask) == 56, "lamp_mask layout is part of the ABI (lamp_amd/_native.py: Mask)");
+static_assert(sizeof(lamp_model) == 152, "lamp_model layout is part of the ABI (lamp_amd/_native.py: Model)");
 
 size_t lamp_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t batch) {
     return gemm_gen_workspace_bytes(M, N, K, batch);
@@ -970,8 +975,8 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         // the label graph: bit-packed rows when the caller provides them (one dword per 32-key tile), else bytes
         lamp_mask label_mask{LAMP_MASK_NONE, 0, nullptr, 0, 0, nullptr, 0};
         if (m->label_mask_bits)
-            label_mask = lamp_mask{LAMP_MASK_BITS_U32, 0, m->label_mask_bits, 0, (L + 31) / 32, m->label_tiles,
-                                   (L + 31) / 32 + 1};
+            label_mask = lamp_mask{LAMP_MASK_BITS_U32, m->label_mask_flags, m->label_mask_bits, 0, (L + 31) / 32, m->label_tiles,
+                                   (L + 31) / 32 + 1, m->label_mask_allowed};
         else if (m->label_mask)
             label_mask = lamp_mask{LAMP_MASK_U8, 0, m->label_mask, 0, L, m->label_tiles, (L + 31) / 32 + 1};
         const int64_t Md = int64_t(nb) * L;

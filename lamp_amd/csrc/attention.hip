@@ -513,7 +513,10 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
         !aligned16(p.Q) || !aligned16(p.K) || (p.V && !aligned16(p.V)))
         return LAMP_E_ALIGN;
     if (p.dk > 128 || p.dv > 128) return launch_attn_general(p, s);  // beyond the fused kernel's register budget
-    const double flops = 2.0 * p.B * p.H * double(p.lq) * p.lk * (p.dk + p.dv) * (p.P ? 1.5 : 1.0);
+    const bool sparse = !(g_force_attn & 0x200) && attn_sparse_applies(p);   // bit 9 of the tuning hook: never the pair kernel
+    // the pair kernel executes the allowed pairs only: count what is executed (a roofline fraction must not exceed 1)
+    const double pairs = sparse && p.allowed_pairs > 0 ? double(p.allowed_pairs) : double(p.lq) * p.lk;
+    const double flops = 2.0 * p.B * p.H * pairs * (p.dk + p.dv) * (p.P ? 1.5 : 1.0);
     const double bytes = 4.0 * p.B * p.H * (double(p.lq) * (p.dk + p.dv) + double(p.lk) * (p.dk + p.dv)) +
                          (p.P ? 4.0 * p.B * p.H * double(p.lq) * p.lk : 0.0);
     ProfScope prof(LAMP_K_ATTN, flops, bytes, s);
@@ -533,7 +536,9 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     if (ksplit == 4 && p.lse) ksplit = 2;
     int rc;
     // at most 256 queries: 16-query blocks on 16x16x4 (attention_small.hip); bit 7 of the tuning hook lifts the limit
-    if (attn_small_applies(p, (g_force_attn & 0x80) != 0))
+    if (sparse)
+        rc = launch_attn_sparse(p, s);
+    else if (attn_small_applies(p, (g_force_attn & 0x80) != 0))
         rc = launch_attn_small(p, g_force_attn, s);
     else if (ksplit == 1 && !(g_force_attn & 0x100) && attn_tile_applies(p))   // bit 8 of the tuning hook: attn_kernel instead
         rc = launch_attn_tile(p, s);

@@ -62,6 +62,8 @@ struct AttnParams {
     int64_t m_sb, m_sq;
     const int* tiles;      // optional per-32-query-block active key-tile lists (shared masks), or nullptr
     int64_t tiles_stride;
+    int sparse_rows;       // lamp_mask.flags & LAMP_MASK_SPARSE_ROWS: the shared mask's rows allow few keys, unstructured
+    int64_t allowed_pairs; // unblocked entries of that mask (0 = unknown): the FLOPs attention_sparse.hip executes
     // Ragged keys (lamp_forward's enc-dec attention; SeqPlan): sample b has kv_len[b] <= lk keys -- every key past it is a PAD
     // token, i.e. exactly masked -- and its K / V rows start at row kv_off[b] of the K / V matrices (packed token rows;
     // lay.k_b / lay.v_b are then unused).  Both in device memory, both or neither.  The key loop stops at kv_len[b] and
@@ -83,6 +85,9 @@ int launch_attn_small(const AttnParams& p, int force_ksplit, hipStream_t s);
 // attention_tile.hip: long key sequences, K / V tiles shared by a workgroup through LDS-DMA; the bits of attn_kernel<128, 1, 0, MK>
 bool attn_tile_applies(const AttnParams& p);
 int launch_attn_tile(const AttnParams& p, hipStream_t s);
+// attention_sparse.hip: only the allowed (query, key) pairs of a sparse, unstructured shared mask (exact; not the dense kernels' bits)
+bool attn_sparse_applies(const AttnParams& p);
+int launch_attn_sparse(const AttnParams& p, hipStream_t s);
 size_t gemm_gen_workspace_bytes(int M, int N, int K, int batch);
 int launch_gemm_gen(const lamp_gemm_desc& d, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_gemm_group(const lamp_gemm_desc* descs, int n, hipStream_t s);

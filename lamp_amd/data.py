@@ -68,17 +68,43 @@ def pad_to_longest(insts):
     return torch.from_numpy(ids), torch.from_numpy(pos)
 
 
+class _Flat(object):
+    """A list of variable-length id lists stored once as ONE int64 array + offsets (CSR), so that padding a batch is a single
+    masked store instead of a Python loop over its instances (the reference converts list by list on every batch,
+    utils/data_loader.py:261-279; at reuters' size that loop costs more host time than the batch costs the GPU)."""
+
+    def __init__(self, insts):
+        import itertools
+        self.lens = np.fromiter((len(x) for x in insts), dtype=np.int64, count=len(insts))
+        self.offs = np.zeros(len(insts) + 1, dtype=np.int64)
+        np.cumsum(self.lens, out=self.offs[1:])
+        self.ids = np.fromiter(itertools.chain.from_iterable(insts), dtype=np.int64, count=int(self.offs[-1]))
+
+    def pad(self, lo, hi):
+        """pad_to_longest(insts[lo:hi]) -> (ids, positions) as torch int64 (B, T)."""
+        lens = self.lens[lo:hi]
+        T = int(lens.max())
+        live = np.arange(T, dtype=np.int64)[None, :] < lens[:, None]
+        ids = np.full((hi - lo, T), Constants.PAD, dtype=np.int64)
+        ids[live] = self.ids[self.offs[lo]:self.offs[hi]]     # row-major order of the mask == concatenation order
+        pos = np.where(ids != Constants.PAD, np.arange(1, T + 1, dtype=np.int64)[None, :], 0)
+        return torch.from_numpy(ids), torch.from_numpy(pos)
+
+
 class EvalBatcher(object):
     """Sequential (unshuffled) batches in the reference DataLoader's format
     ``((src_seq, src_pos), None, tgt)`` -- utils/data_loader.py:129-312 with shuffle=False, drop_last=False,
-    as process_data builds the valid/test loaders.  Tensors are moved to `device` if given."""
+    as process_data builds the valid/test loaders.  Tensors are moved to `device` if given.  The instances are flattened
+    once at construction (_Flat); every batch is then padded by vectorised numpy, same tensors as pad_to_longest."""
 
     def __init__(self, src_insts, tgt_insts, batch_size, device=None):
         if not src_insts or len(src_insts) < batch_size:
             raise ValueError('need at least batch_size instances (reference: data_loader.py:139)')
         if tgt_insts is not None and len(tgt_insts) != len(src_insts):
             raise ValueError('src / tgt instance counts differ')
-        self._src_insts, self._tgt_insts = src_insts, tgt_insts
+        self._n = len(src_insts)
+        self._src = _Flat(src_insts)
+        self._tgt = _Flat(tgt_insts) if tgt_insts is not None else None
         self._batch_size = batch_size
         self._n_batch = (len(src_insts) + batch_size - 1) // batch_size
         self.device = device
@@ -88,7 +114,7 @@ class EvalBatcher(object):
 
     @property
     def n_insts(self):
-        return len(self._src_insts)
+        return self._n
 
     def __iter__(self):
         return self.iter_range(0, self._n_batch)
@@ -96,11 +122,11 @@ class EvalBatcher(object):
     def iter_range(self, b_lo, b_hi):
         """Batches b_lo .. b_hi - 1 only: a rank of a sharded evaluation materialises (pads, uploads) just its own share."""
         for b in range(max(b_lo, 0), min(b_hi, self._n_batch)):
-            lo, hi = b * self._batch_size, (b + 1) * self._batch_size
-            src_seq, src_pos = pad_to_longest(self._src_insts[lo:hi])
+            lo, hi = b * self._batch_size, min((b + 1) * self._batch_size, self._n)
+            src_seq, src_pos = self._src.pad(lo, hi)
             tgt = None
-            if self._tgt_insts is not None:
-                tgt, _ = pad_to_longest(self._tgt_insts[lo:hi])
+            if self._tgt is not None:
+                tgt, _ = self._tgt.pad(lo, hi)
             if self.device is not None:
                 src_seq, src_pos = src_seq.to(self.device), src_pos.to(self.device)
             yield (src_seq, src_pos), None, tgt

@@ -5,15 +5,23 @@ multi_gpu, test.py:35-39; the all-PAD rows come out NaN and are sliced off again
 run ``model(src, adj, None, None)`` on the MI355X, sigmoid + BCE-with-logits on the device
 (lamp_sigmoid_bce_fwd), gold-binary targets on the host.
 
-Unlike the reference, which pulls every batch's predictions to the CPU before starting the next forward
-(test.py:49-56), results stay on the device until the end of the epoch; with ``streams=n`` consecutive
-batches are issued round-robin on n HIP streams, so one batch's kernel ramps / tails are filled by the
-other batches' kernels (the batch-32 forward is a chain of ~35 short kernels: 38k -> 46k / 50k samples/s with
-2 / 4 batches in flight on reuters).
+The reference pulls every batch's predictions to the CPU before it starts the next forward (test.py:49-56): host and GPU
+alternate.  Here they overlap (round 6):
+  * a PRODUCER thread pads the next `prefetch` batches (utils/data_loader.py:261-279), builds their gold-binary rows and
+    packs token ids, positions and targets into pinned host buffers while the device runs the previous stage;
+  * the issuing thread uploads a stage with ONE asynchronous copy on a copy stream, makes the forward stream(s) wait for
+    it on the device, and issues forward + sigmoid / BCE per batch;
+  * sigmoid + BCE write every batch's probabilities and per-row losses straight into ONE device matrix / vector for the whole
+    split (one launch per batch, nothing else); both come back with one copy each after the last batch, and the per-batch
+    mean losses (reduction='mean', test.py:51) are taken on the host in float64.
+The only host-side wait is the final synchronize.  With ``streams=n`` consecutive batches are issued round-robin on n HIP
+streams, so one batch's kernel ramps / tails are filled by the other batches' kernels (tools/bench_eval_epoch.py).
 Each sample's numbers are identical in every mode.
 """
-import itertools
+import queue
+import threading
 
+import numpy as np
 import torch
 
 from . import _native as N
@@ -21,8 +29,93 @@ from . import sharding
 from .data import get_gold_binary
 
 
+class _Stage(object):
+    """`prefetch` consecutive batches, ready to upload: ids = every batch's tokens then positions (int64, pinned), gold = their
+    target rows (float32, pinned), items = (batch index, first row, rows, T, offset into ids, first gold row, adj)."""
+    __slots__ = ('ids', 'gold', 'items', 'device_batches', 'slot')
+
+
+class _Slot(object):
+    """One of the producer's pinned staging buffers (a ring of four, grown on demand, allocated ONCE per epoch: hipHostMalloc
+    is not something to call per stage next to a busy device).  `uploaded` = the event behind the stage's host-to-device copies:
+    the producer waits for it before it overwrites the buffers -- four slots, because stage k - 3 may have been taken off the
+    queue without its copies being issued yet, while stage k - 4 certainly has been."""
+    __slots__ = ('ids', 'gold', 'uploaded')
+
+    def __init__(self):
+        self.ids = self.gold = self.uploaded = None
+
+    def take(self, n_ids, n_rows, n_labels, pin):
+        if self.uploaded is not None:
+            self.uploaded.synchronize()
+            self.uploaded = None
+        if self.ids is None or self.ids.numel() < n_ids:
+            self.ids = torch.empty(max(n_ids, 1) * 3 // 2, dtype=torch.int64, pin_memory=pin)
+        if self.gold is None or self.gold.size(0) < n_rows:
+            self.gold = torch.empty((max(n_rows, 1) * 3 // 2, n_labels), dtype=torch.float32, pin_memory=pin)
+        return self.ids[:n_ids], self.gold[:n_rows]
+
+
+def _hand_over(out_q, item, stop):
+    while not stop.is_set():
+        try:
+            out_q.put(item, timeout=0.05)
+            return True
+        except queue.Full:
+            pass
+    return False
+
+
+def _produce(it, n_labels, batch_size, prefetch, all_targets, out_q, pin, device, stop):
+    """Producer thread: the host side of utils/data_loader.py:242-312 + utils/utils.py:205-216 for stage after stage."""
+    try:
+        if pin:
+            torch.cuda.set_device(device)    # pinned allocations belong to THIS rank's device context, not to device 0's
+        ring, n_stage = [_Slot() for _ in range(4)], 0
+        while not stop.is_set():
+            host = []
+            for _ in range(prefetch):
+                nxt = next(it, None)
+                if nxt is None:
+                    break
+                host.append(nxt)
+            if not host:
+                break
+            st = _Stage()
+            st.items, st.device_batches = [], None
+            golds, total_ids, row = [], 0, 0
+            on_device = all(b[1][0][0].is_cuda for b in host)
+            for bi, ((src_seq, src_pos), adj, tgt) in host:
+                real = src_seq.size(0)
+                gold = get_gold_binary(tgt[:, 1:], n_labels)
+                lo = bi * batch_size
+                all_targets[lo:lo + real] = gold
+                golds.append(gold)
+                st.items.append((bi, lo, real, src_seq.size(1), total_ids, row, adj))
+                total_ids += 2 * src_seq.numel()
+                row += real
+            st.slot = ring[n_stage % len(ring)]
+            n_stage += 1
+            st.ids, st.gold = st.slot.take(0 if on_device else total_ids, row, n_labels, pin)
+            torch.cat(golds, out=st.gold)
+            if on_device:    # the batcher already put the tokens on the device (EvalBatcher(device=...))
+                st.ids = None
+                st.device_batches = [(b[1][0][0], b[1][0][1]) for b in host]
+            else:
+                flat = st.ids.numpy()
+                for (bi, lo, real, T, off, _, _), (_, ((src_seq, src_pos), _, _)) in zip(st.items, host):
+                    cnt = real * T
+                    flat[off:off + cnt] = src_seq.numpy().reshape(-1)
+                    flat[off + cnt:off + 2 * cnt] = src_pos.numpy().reshape(-1)
+            if not _hand_over(out_q, st, stop):
+                return
+        _hand_over(out_q, None, stop)
+    except BaseException as e:  # noqa: BLE001  -- handed to the issuing thread, which re-raises it
+        _hand_over(out_q, e, stop)
+
+
 def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True, int_preds=False, streams=1,
-               prefetch=256, world_size=1, rank=0, group=None):
+               prefetch=8, world_size=1, rank=0, group=None, timeline=None):
     """-> (all_predictions (n, L) cpu, all_targets (n, L) cpu, bce_total float), as test.py:16-78 returns
     them.  `batches` yields ((src_seq, src_pos), adj, tgt) like lamp_amd.data.EvalBatcher.
 
@@ -32,67 +125,90 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
     prediction / target rows and BCE sums are combined once (all_reduce over disjoint rows), so every rank returns the
     full matrices.  A sample's numbers do not depend on world_size.
 
-    Up to `prefetch` batches are staged on the device before their forwards are issued: a host-to-device copy from
-    pageable memory blocks the host until the stream reaches it, so copies interleaved with forwards (as the
-    reference's loop does) serialise host and GPU -- measured 18k vs 30k+ samples/s on a reuters-sized test split."""
+    `prefetch` = batches per stage (module docstring): the first forward is issued after ONE stage has been padded, and
+    at most two further stages wait in the producer's queue.  `timeline` (a dict, optional) receives host timestamps in
+    seconds from the call's start: 'issued' = the last batch was enqueued, 'done' = the device finished
+    (tools/bench_eval_epoch.py: issued ~ done means the issuing thread, not the GPU, bounds the epoch)."""
+    import time
+    t_start = time.perf_counter()
     model.eval()
     n = batches.n_insts
+    pin = torch.cuda.is_available()
     all_targets = torch.zeros(n, n_labels)
-    all_predictions = torch.zeros(n, n_labels)
-    bce_total = 0.0
-    lanes = [torch.cuda.Stream(device=device) for _ in range(streams)] if streams > 1 else [None]
     b_lo, b_hi = sharding.shard_bounds(len(batches), world_size, rank) if world_size > 1 else (0, len(batches))
     if hasattr(batches, 'iter_range'):   # EvalBatcher: only this rank's batches are padded and uploaded at all
         it = zip(range(b_lo, b_hi), batches.iter_range(b_lo, b_hi))
     else:
         it = iter((bi, b) for bi, b in enumerate(batches) if b_lo <= bi < b_hi)
+    main = torch.cuda.current_stream(device)
+    lanes = [torch.cuda.Stream(device=device) for _ in range(streams)] if streams > 1 else [main]
+    copier = torch.cuda.Stream(device=device)
+    # this rank's rows of the result: probabilities and summed BCE per row, filled batch by batch on the device
+    r_lo, r_hi = min(b_lo * batch_size, n), min(b_hi * batch_size, n)
+    probs_d = torch.empty((max(r_hi - r_lo, 1), n_labels), dtype=torch.float32, device=device)
+    row_loss_d = torch.empty((max(r_hi - r_lo, 1),), dtype=torch.float32, device=device)
+    for lane in lanes:
+        lane.wait_stream(main)    # the buffers (and the model's weights) are ready on every lane
+    stages, stop = queue.Queue(maxsize=2), threading.Event()
+    producer = threading.Thread(target=_produce, name='lamp-eval-producer', daemon=True,
+                                args=(it, n_labels, batch_size, max(int(prefetch), 1), all_targets, stages, pin, device, stop))
+    producer.start()
+    try:
+        _issue(model, stages, lanes, copier, device, batch_size, pad_last_batch, int_preds, probs_d, row_loss_d, r_lo)
+    finally:
+        stop.set()          # an exception on this side must not leave the producer blocked on a full queue
+        producer.join()
+    for lane in lanes:
+        main.wait_stream(lane)
+    all_predictions = torch.zeros(n, n_labels)
+    bce_total = 0.0
+    if r_hi > r_lo:
+        all_predictions[r_lo:r_hi] = probs_d[:r_hi - r_lo].cpu()     # (synchronises with the main stream, which waited for the lanes)
+        row_loss = row_loss_d[:r_hi - r_lo].cpu().numpy().astype(np.float64)
+        # the reference adds one python float per batch, the batch's MEAN loss (test.py:51-52): same order, float64
+        for lo in range(r_lo, r_hi, batch_size):
+            real = min(lo + batch_size, r_hi) - lo
+            bce_total += float(row_loss[lo - r_lo:lo - r_lo + real].sum()) / (real * n_labels)
+    return _combine_ranks(all_predictions, all_targets, bce_total, n, n_labels, world_size, device, group)
+
+
+def _issue(model, stages, lanes, copier, device, batch_size, pad_last_batch, int_preds, probs_d, row_loss_d, r_lo):
+    """The issuing side: upload a stage, then forward + sigmoid / BCE per batch into the epoch's result buffers.  Buffers that
+    cross streams are handed to the caching allocators' own bookkeeping (record_stream for device blocks; pinned blocks are
+    not reused before the copies that read them have run), so nothing here waits for the device."""
     while True:
-        host = []
-        for bi, ((src_seq, src_pos), adj, tgt) in itertools.islice(it, prefetch):
-            real = src_seq.size(0)
-            gold_binary = get_gold_binary(tgt[:, 1:], n_labels)
-            lo = bi * batch_size
-            all_targets[lo:lo + real] = gold_binary
-            host.append((bi, lo, real, src_seq, src_pos, adj, gold_binary))
-        if not host:
-            break
-        # ONE host-to-device copy per stage for the token ids + positions and one for the targets (each small pageable
-        # copy costs ~0.25 ms of blocked host time); the batches are views into the device buffers
-        if all(h[3].is_cuda for h in host):
-            ids_d = None
-        else:
-            ids_d = torch.cat([torch.stack((h[3].reshape(-1), h[4].reshape(-1))).reshape(-1) for h in host]).to(device)
-        gold_d_all = torch.cat([h[6] for h in host]).to(device)
-        staged, off, row = [], 0, 0
-        for bi, lo, real, src_seq, src_pos, adj, gold_binary in host:
-            if ids_d is None:
-                seq_d, pos_d = src_seq, src_pos
-            else:
-                cnt = src_seq.numel()
-                seq_d = ids_d[off:off + cnt].view(src_seq.shape)
-                pos_d = ids_d[off + cnt:off + 2 * cnt].view(src_seq.shape)
-                off += 2 * cnt
-            staged.append((bi, lo, real, seq_d, pos_d, adj, gold_d_all[row:row + real]))
-            row += real
-        done = []  # (row offset, real rows, probs (device), mean BCE of the batch (device scalar))
-        for bi, lo, real, src_seq, src_pos, adj, gold_d in staged:
+        st = stages.get()
+        if st is None:
+            return
+        if isinstance(st, BaseException):
+            raise st
+        with torch.cuda.stream(copier):
+            ids_d = st.ids.to(device, non_blocking=True) if st.ids is not None else None
+            gold_d = st.gold.to(device, non_blocking=True)
+        uploaded = copier.record_event()
+        st.slot.uploaded = uploaded      # the producer may refill this slot's pinned buffers once these copies have run
+        for k, (bi, lo, real, T, off, row, adj) in enumerate(st.items):
             lane = lanes[bi % len(lanes)]
-            with torch.cuda.stream(lane) if lane is not None else _null():
+            lane.wait_event(uploaded)
+            with torch.cuda.stream(lane):
+                if ids_d is not None:
+                    cnt = real * T
+                    src_seq = ids_d[off:off + cnt].view(real, T)
+                    src_pos = ids_d[off + cnt:off + 2 * cnt].view(real, T)
+                    ids_d.record_stream(lane)
+                else:
+                    src_seq, src_pos = st.device_batches[k]
+                gold_d.record_stream(lane)
                 if pad_last_batch and real < batch_size:
-                    pad = torch.zeros((batch_size - real, src_seq.size(1)), dtype=src_seq.dtype, device=device)
+                    pad = torch.zeros((batch_size - real, T), dtype=src_seq.dtype, device=device)
                     src_seq = torch.cat((src_seq, pad), 0)
                     src_pos = torch.cat((src_pos, pad), 0)
                 pred = model((src_seq, src_pos), adj, None, None, int_preds=int_preds)[0]
-                probs, row_loss = N.sigmoid_bce(pred[:real], gold_d)
-                done.append((lo, real, probs, row_loss.double().sum() / (real * n_labels)))  # reduction='mean' per batch
-        torch.cuda.synchronize(device)
-        probs_all = torch.cat([p for _, _, p, _ in done]).cpu()      # one device-to-host copy per stage
-        bce_total += float(torch.stack([l for _, _, _, l in done]).sum().cpu())
-        off = 0
-        for lo, real, _, _ in done:
-            all_predictions[lo:lo + real] = probs_all[off:off + real]
-            off += real
-        del staged, done, host
+                N.sigmoid_bce(pred[:real], gold_d[row:row + real], probs_out=probs_d[lo - r_lo:lo - r_lo + real],
+                              row_loss_out=row_loss_d[lo - r_lo:lo - r_lo + real])
+
+
+def _combine_ranks(all_predictions, all_targets, bce_total, n, n_labels, world_size, device, group):
     if world_size > 1:
         import torch.distributed as dist
         on_gpu = dist.get_backend(group) == 'nccl'
@@ -111,11 +227,3 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
         all_targets = packed[k:2 * k].view(n, n_labels)
         bce_total = float(bce.cpu())
     return all_predictions, all_targets, bce_total
-
-
-class _null(object):
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *exc):
-        return False

@@ -551,7 +551,7 @@ def forward_train(model, src_seq, src_pos, return_attns=False, int_preds=False):
     y = _LabelRowsFn.apply(dec.tgt_word_emb.weight, B)
     label_mask = dec.label_mask_struct()
     if label_mask is not None:  # the map-writing attention variant visits every tile
-        label_mask = N.Mask(label_mask.kind, 0, label_mask.ptr, label_mask.stride_b, label_mask.stride_q, None, 0)
+        label_mask = N.Mask(label_mask.kind, 0, label_mask.ptr, label_mask.stride_b, label_mask.stride_q, None, 0, 0)
     int_outs, slf_attns, enc_dec_attns = [], [], []
     for layer in dec.layer_stack:
         y, a_enc = mha_train(layer.enc_attn, y, x, pad_mask, keep, seeds)

@@ -141,6 +141,68 @@ def test_bench_and_eval_with_eight_ranks_on_one_device(dev, tmp_path):
         assert out['host_issue_us_per_forward'] == max(p['host_issue_us_per_forward'] for p in out['per_rank'])
 
 
+CONTRACT_KEYS = {'metric': str, 'value': float, 'unit': str, 'n_gpus': int, 'steps': int, 'warmup': int, 'ms_per_step': float,
+                 'higher_is_better': bool, 'scaling': str, 'dtype': str, 'data': str, 'config': dict}
+
+
+def _assert_contract(line, n, steps, warmup, workload='reuters'):
+    """The fields the round-end driver parses from bench.py's one JSON line (and computes its scaling efficiency from)."""
+    for k, t in CONTRACT_KEYS.items():
+        assert k in line and isinstance(line[k], t), (k, line.get(k))
+    assert 'vs_baseline' in line and line['vs_baseline'] is None        # BASELINE.md publishes no number for this metric
+    assert line['n_gpus'] == n and line['steps'] == steps and line['warmup'] == warmup
+    assert line['unit'] == 'samples/s' and line['higher_is_better'] is True and line['scaling'] == 'weak'
+    assert line['dtype'] == 'f32' and line['data'] == 'synthetic' and workload in line['config']['workload']
+    assert 'model' not in line['config'] and line['value'] > 0 and line['ms_per_step'] > 0
+    assert line['ranks_seen'] == list(range(n)) and len(line['per_rank']) == n
+    batch = line['config']['batch_per_gpu']
+    assert abs(line['value'] - n * batch / (line['ms_per_step'] * 1e-3)) < 1e-6 * line['value']   # whole job / slowest rank
+
+
+def test_the_drivers_scaling_commands_rehearsed_on_one_device(dev):
+    """the exact launches of the round-end scaling run -- `python bench.py --gpus 1 ...` and, for N = 2, 4, 8,
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+    --steps K --warmup W` -- with the N ranks sharing this box's one device over gloo (RCCL refuses two ranks on one device),
+    plus BASELINE configs[4]'s command at a batch that fits eight ranks on one device.  Every line must parse and satisfy the
+    contract; the N = 1 line carries roofline and cpu_baseline; with no RCCL the reason is in config.backend_note."""
+    r1, one = _bench(['--gpus', '1', '--steps', '5', '--warmup', '2', '--no-pipelined', '--cpu-budget', '4'])
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    _assert_contract(one, 1, 5, 2)
+    roof, cpu = one['roofline'], one['cpu_baseline']
+    assert roof['bound'] == 'mfma' and roof['unit'] == 'TFLOP/s' and 0.0 < roof['frac'] < 1.0 and roof['peak'] == 157.3
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-9 and roof['traffic'] is not None
+    assert cpu['kind'] == 'port' and cpu['cores'] >= 1 and cpu['value'] > 0 and cpu['unit'] == 'samples/s' and cpu['sample']
+    assert one['config']['weights_only_precomputation']['embed_fold'] is True
+    assert one['forward']['executed_gflop_per_sample'] < one['forward']['f_live_gflop_per_sample']
+    env = dict(os.environ, LAMP_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+
+    def launched(n, extra, port):
+        r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+                            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+                            '--gpus', str(n)] + extra, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, lines        # ONE line, from rank 0
+        return json.loads(lines[0])
+    values = {1: one['value']}
+    for n, port in ((2, 29531), (4, 29532), (8, 29533)):
+        line = launched(n, ['--steps', '5', '--warmup', '2'], port)
+        _assert_contract(line, n, 5, 2)
+        assert line['config']['launcher'] == 'torch.distributed.run' and line['backend'] == 'gloo'
+        assert line['config']['backend_note']                      # why this is not an RCCL group
+        assert line['cross_rank_check']['bitwise_equal'] is True and line['cross_rank_check']['ranks_checked'] == list(range(1, n))
+        assert 'cpu_baseline' not in line
+        values[n] = line['value']
+    # one device shared by N ranks: the aggregate must not collapse (the ranks' forwards interleave on the device)
+    assert all(values[n] > 0.5 * values[1] for n in (2, 4, 8)), values
+    c5 = launched(8, ['--workload', 'synthetic4096', '--batch', '4', '--steps', '2', '--warmup', '1'], 29534)
+    _assert_contract(c5, 8, 2, 1, workload='synthetic4096')
+    assert c5['metric'] == 'forward samples/sec, synthetic4096 d1024 2+2L 8h' and c5['config']['batch_per_gpu'] == 4
+    assert c5['cross_rank_check']['bitwise_equal'] is True
+
+
 def test_rccl_control_plane_calls_work(dev):
     """bench.py's control plane class with its "nccl" (= RCCL) group -- probe all_reduce, barrier(device_ids), gathers of
     device tensors -- as a one-rank group (RCCL refuses two ranks on one device, so the 2-rank tests above run on gloo)."""

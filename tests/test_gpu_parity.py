@@ -914,6 +914,87 @@ def test_embedding_fold_against_the_unfolded_route_and_the_oracle(dev, name):
     assert max_abs_diff(after, folded) > 1e-4
 
 
+@pytest.mark.parametrize('L,B,H,p', [(1024, 2, 2, 0.05), (1100, 1, 3, 0.10), (2085, 1, 1, 0.02)])
+def test_sdpa_pair_kernel_for_sparse_unstructured_masks(dev, tuning, L, B, H, p):
+    """csrc/attention_sparse.hip (LAMP_MASK_SPARSE_ROWS): only the allowed (query, key) pairs of a shared bit-packed mask are
+    computed.  Exact masked softmax -- against the fp64 oracle arithmetic and against the dense kernels on the same inputs;
+    label counts that are no multiple of the 64-key tile / the 128-query block / the 32-bit mask word, a row that allows a
+    single key, a row that allows none (NaN, as the reference's softmax of an all -inf row)."""
+    import ctypes
+    from lamp_amd import _native as N
+    dk = 128
+    g = torch.Generator().manual_seed(L)
+    q = torch.randn(B, L, H * dk, generator=g)
+    k = torch.randn(B, L, H * dk, generator=g)
+    v = torch.randn(B, L, H * dk, generator=g)
+    blocked = (R.make_adjacency(L, p, 1) == 0)
+    blocked[3, :] = True
+    blocked[3, L - 1] = False        # one key, the very last
+    blocked[7, :] = True             # no key at all
+    bits = N.pack_mask_bits(blocked.to(torch.uint8)).to(dev)
+    allowed = int((~blocked).sum())
+    lay = N.AttnLayout(L * H * dk, dk, H * dk, L * H * dk, dk, H * dk, L * H * dk, dk, H * dk, L * H * dk, dk, H * dk)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    outs = {}
+    tuning.lamp_debug_sparse_lpq.argtypes = [ctypes.c_int]
+    tuning.lamp_debug_sparse_lpq.restype = None
+    # the product library's route, and both lanes-per-query variants forced in the tuning build
+    for name, flags, lib, lanes in (('dense', 0, N.lib(), 0), ('pairs', N.LAMP_MASK_SPARSE_ROWS, N.lib(), 0),
+                                    ('pairs8', N.LAMP_MASK_SPARSE_ROWS, tuning, 8), ('pairs4', N.LAMP_MASK_SPARSE_ROWS, tuning, 4)):
+        o = torch.full((B, L, H * dk), 7.0, device=dev)
+        ms = N.Mask(N.LAMP_MASK_BITS_U32, flags, bits.data_ptr(), 0, bits.size(1), None, 0, allowed if flags else 0)
+        try:
+            if lanes:
+                tuning.lamp_debug_sparse_lpq(lanes)
+            N.check(lib.lamp_sdpa_fwd(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), None, B, H, L, L, dk, dk,
+                                      dk ** -0.5, ctypes.byref(ms), ctypes.byref(lay), N.stream()), 'sdpa')
+        finally:
+            if lanes:
+                tuning.lamp_debug_sparse_lpq(0)
+        outs[name] = o.cpu()
+    qh = q.view(B, L, H, dk).permute(0, 2, 1, 3).double()
+    kh = k.view(B, L, H, dk).permute(0, 2, 1, 3).double()
+    vh = v.view(B, L, H, dk).permute(0, 2, 1, 3).double()
+    sc = (qh @ kh.transpose(-1, -2)) / dk ** 0.5
+    sc = sc.masked_fill(blocked[None, None], float('-inf'))
+    ref = (torch.softmax(sc, dim=-1) @ vh).permute(0, 2, 1, 3).reshape(B, L, H * dk)
+    assert torch.isnan(ref[:, 7]).all() and max_abs_diff(outs['dense'], ref) < 2e-5
+    for name in ('pairs', 'pairs8', 'pairs4'):
+        assert torch.isnan(outs[name][:, 7]).all() and max_abs_diff(outs[name], ref) < 2e-5, name
+        assert max_abs_diff(outs[name][:, 3], v[:, L - 1]) < 1e-6, name      # softmax over one key = that key's value row
+    assert torch.equal(outs['pairs'], outs['pairs8'])     # product route == the tuning build's default variant
+
+
+def test_model_takes_the_pair_kernel_on_a_sparse_unstructured_label_graph(dev):
+    """configs[4]'s label graph (Bernoulli(0.05) prior over 4096 labels: every 32 x 32 tile holds an edge, every row ~5 % of the
+    keys): the decoder drops the tile-list hint, flags the mask LAMP_MASK_SPARSE_ROWS, and lamp_forward's label self-attention
+    runs attention_sparse.hip -- same logits as with the dense tile kernel up to summation order, both within the oracle's bar;
+    a sample's bits do not depend on the micro-batch split."""
+    from lamp_amd import _native as N
+    m, sd, blocked, seq, spos, h = make_case(CONFIGS['labels4096'], dev)
+    # symmetric Bernoulli(0.05) or identity: 1 - 0.95^2 = 9.75 % of the pairs are allowed
+    assert m.decoder.label_tiles is None and m.decoder.label_rows_sparse and 0.09 < m.decoder.label_allowed_pairs / 4096 ** 2 < 0.105
+    src = (seq.to(dev), spos.to(dev))
+    with torch.no_grad():
+        ref_logits, ref_enc, _ = R.forward(sd, seq, spos, h, blocked)
+    pairs, _, _ = m(src, None, None, None)
+    desc = m._native_model()[0]
+    assert desc.label_mask_flags == N.LAMP_MASK_SPARSE_ROWS and desc.label_mask_allowed == m.decoder.label_allowed_pairs
+    m.use_sparse_label_attention = False
+    dense, _, _ = m(src, None, None, None)
+    assert m._native_model()[0].label_mask_flags == 0
+    assert max_abs_diff(pairs, ref_logits) < TOL_LOGIT and max_abs_diff(dense, ref_logits) < TOL_LOGIT
+    assert 0.0 < max_abs_diff(pairs, dense) < 2e-5      # two kernels, two summation orders
+    del m.use_sparse_label_attention
+    m.workspace_limit_bytes = 200 << 20     # one sample per pass
+    split, _, _ = m(src, None, None, None)
+    assert torch.equal(split, pairs)
+    # the module-by-module route takes the same kernel
+    enc2, _ = m.encoder(src[0], None, src[1])
+    y, _ = m.decoder(None, src[0], enc2)
+    assert max_abs_diff(N.diag_logits(y, m.tgt_word_proj.linear.weight), pairs) < 2e-5
+
+
 def test_layer0_query_cache_tracks_weight_updates(dev):
     """The hoisted label-table x W_q projection is bit-identical to projecting per call, and is refreshed
     when either operand is modified in place (load_state_dict / optimiser step keep data_ptr)."""

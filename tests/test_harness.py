@@ -61,6 +61,46 @@ def test_pad_to_longest_edge_cases():
     assert pos.tolist() == [[1, 2, 3, 0, 0], [1, 2, 0, 0, 0], [1, 2, 3, 4, 5]]
 
 
+def test_eval_producer_stages_hold_exactly_the_batches(fx):
+    """Host side of evaluate.test_epoch (round 6: a producer thread packs `prefetch` batches per stage into one id buffer
+    and one target block): every stage, unpacked, is the batcher's own tensors and get_gold_binary's rows."""
+    import queue
+    import threading
+    from lamp_amd import evaluate as E
+    d, sd, splits = fx
+    L = sd['decoder.tgt_word_emb.weight'].size(0)
+    bs = d['batch_size']
+    b = D.EvalBatcher(splits['test']['src'], splits['test']['tgt'], bs)
+    want = list(b)
+    for prefetch in (1, 3, 64):
+        q, stop = queue.Queue(), threading.Event()
+        targets = torch.zeros(b.n_insts, L)
+        E._produce(zip(range(len(b)), iter(b)), L, bs, prefetch, targets, q, False, torch.device('cpu'), stop)
+        stages = []
+        while True:
+            st = q.get_nowait()
+            if st is None:
+                break
+            assert not isinstance(st, BaseException), st
+            stages.append(st)
+        assert len(stages) == (len(b) + prefetch - 1) // prefetch and q.empty()
+        seen = 0
+        for st in stages:
+            for bi, lo, real, T, off, row, adj in st.items:
+                (seq, pos), _, tgt = want[bi]
+                assert bi == seen and lo == bi * bs and (real, T) == tuple(seq.shape)
+                assert torch.equal(st.ids[off:off + real * T].view(real, T), seq)
+                assert torch.equal(st.ids[off + real * T:off + 2 * real * T].view(real, T), pos)
+                assert torch.equal(st.gold[row:row + real], D.get_gold_binary(tgt[:, 1:], L))
+                seen += 1
+        assert seen == len(b) and torch.equal(targets, d['targets'])
+    # an exception inside the producer reaches the consumer instead of hanging it
+    q, stop = queue.Queue(), threading.Event()
+    E._produce(iter([(0, ((torch.zeros(2, 3, dtype=torch.long),) * 2, None, None))]), L, bs, 2, targets, q, False,
+               torch.device('cpu'), stop)
+    assert isinstance(q.get_nowait(), BaseException)
+
+
 @pytest.mark.gpu
 def test_test_epoch_matches_reference(fx):
     d, sd, splits = fx

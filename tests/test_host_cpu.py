@@ -49,13 +49,13 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header_sizes():
     # sizes the C compiler produces for the same declarations (x86-64 SysV)
-    assert ctypes.sizeof(N.Mask) == 48
+    assert ctypes.sizeof(N.Mask) == 56
     assert ctypes.sizeof(N.AttnLayout) == 96
     assert ctypes.sizeof(N.MhaWeights) == 56
     assert ctypes.sizeof(N.FfnWeights) == 48
     assert ctypes.sizeof(N.EncLayer) == 104
     assert ctypes.sizeof(N.DecLayer) == 208
-    assert ctypes.sizeof(N.Model) == 144
+    assert ctypes.sizeof(N.Model) == 152
     assert ctypes.sizeof(N.ChainPack) == 48
     assert ctypes.sizeof(N.Aux) == 40
     assert ctypes.sizeof(N.GemmDesc) == 160
@@ -132,6 +132,25 @@ def test_active_tile_list_of_a_clustered_label_graph():
     assert tl[1].tolist() == [4, 0, 1, 2, 3]
     assert tl[2].tolist() == [3, 1, 2, 3, 0]
     assert tl[3].tolist() == [3, 1, 2, 3, 0]
+
+
+def test_tile_list_hint_is_dropped_on_graphs_it_cannot_help():
+    """BASELINE configs[4]'s Bernoulli(0.05) prior graph has an edge in every 32x32 tile; walking the active-tile
+    list there only costs.  GraphDecoder keeps the hint for block-structured graphs and drops it from 90 % active tiles on."""
+    from lamp_amd.Decoders import GraphDecoder
+    from lamp_amd import synthetic as S
+    L = 256
+    dense = GraphDecoder(L, L, n_layers=1, n_head=2, n_head2=2, d_k=8, d_v=8, d_word_vec=16, d_model=16, d_inner_hid=32,
+                         label_adj_matrix=S.make_adjacency(L, 0.05, 0), label_mask='prior')
+    assert dense.label_tile_density == 1.0 and dense.label_tiles is None and dense.label_mask_bits is not None
+    adj = torch.eye(L)
+    for c in range(0, L, 64):
+        adj[c:c + 64, c:c + 64] = 1
+    clustered = GraphDecoder(L, L, n_layers=1, n_head=2, n_head2=2, d_k=8, d_v=8, d_word_vec=16, d_model=16, d_inner_hid=32,
+                             label_adj_matrix=adj, label_mask='prior')
+    assert clustered.label_tile_density == 0.25 and clustered.label_tiles is not None
+    assert GraphDecoder(L, L, n_layers=1, n_head=2, n_head2=2, d_k=8, d_v=8, d_word_vec=16, d_model=16, d_inner_hid=32,
+                        label_mask='none').label_tile_density is None
 
 
 def test_pack_mask_bits_layout():

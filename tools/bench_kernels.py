@@ -301,6 +301,45 @@ def sparse():
                   (n_clusters, 100.0 * tiles[:, 0].float().mean().item() / (tiles.size(1) - 1), name, us))
 
 
+def sparse_rows():
+    """Label self-attention at L = 4096 over UNSTRUCTURED graphs (symmetric Bernoulli(p) + identity, BASELINE configs[4]'s
+    generator): the dense tile kernel against the pair kernel (attention_sparse.hip, LAMP_MASK_SPARSE_ROWS)."""
+    from lamp_amd import synthetic as S
+    dev = torch.device('cuda:0')
+    B, H, L, dk = 16, 8, 4096, 128
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(B, L, H * dk, generator=g).to(dev)
+    k = torch.randn(B, L, H * dk, generator=g).to(dev)
+    v = torch.randn(B, L, H * dk, generator=g).to(dev)
+    lay = N.AttnLayout(L * H * dk, dk, H * dk, L * H * dk, dk, H * dk, L * H * dk, dk, H * dk, L * H * dk, dk, H * dk)
+    for p in (0.005, 0.01, 0.025, 0.05, 0.075, 0.10, 0.15):   # symmetrised: ~ 2 p of the pairs are allowed
+        blocked = (S.make_adjacency(L, p, 0) == 0).to(torch.uint8)
+        bits = N.pack_mask_bits(blocked).to(dev)
+        allowed = int((blocked == 0).sum())
+        outs, times = {}, {}
+        lpq = N.lib().lamp_debug_sparse_lpq
+        lpq.argtypes = [ctypes.c_int]
+        lpq.restype = None
+        for name, flags, lanes in (('dense', 0, 0), ('pairs', N.LAMP_MASK_SPARSE_ROWS, 8), ('pairs4', N.LAMP_MASK_SPARSE_ROWS, 4)):
+            lpq(lanes)
+            o = torch.empty_like(q)
+            ms = N.Mask(N.LAMP_MASK_BITS_U32, flags, bits.data_ptr(), 0, bits.size(1), None, 0, allowed if flags else 0)
+
+            def fn():
+                N.check(N.lib().lamp_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), None, B, H, L, L,
+                                              dk, dk, dk ** -0.5, ctypes.byref(ms), ctypes.byref(lay), N.stream()), 'sdpa')
+            times[name] = time_fn(fn, iters=5, warm=2)
+            outs[name] = o
+        lpq(0)
+        diff = max((outs['dense'] - outs[k]).abs().max().item() for k in ('pairs', 'pairs4'))
+        best = min(times['pairs'], times['pairs4'])
+        pair_tf = 2.0 * B * H * allowed * 2 * dk / (best * 1e-6) / 1e12
+        print('L=4096 B=%d H=%d  p=%.3f (%.2f%% of the pairs allowed)  dense %9.1f us   pairs: 8 lanes/query %9.1f us (x%.2f), 4 lanes/query '
+              '%9.1f us (x%.2f)   executed %.1f TFLOP/s   max|dense - pairs| %.2g' %
+              (B, H, p, 100.0 * allowed / (L * L), times['dense'], times['pairs'], times['dense'] / times['pairs'], times['pairs4'],
+               times['dense'] / times['pairs4'], pair_tf, diff))
+
+
 def attn():
     dev = torch.device('cuda:0')
     cases = [('reuters enc-attn', 32, 4, 90, 302, 128), ('reuters self', 32, 4, 90, 90, 128),
@@ -966,5 +1005,5 @@ def ffn_pair():
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
-    {'gemm': gemm, 'gemm_ab': gemm_ab, 'lib_ab': lib_ab, 'walk': walk, 'walk_pmc': walk_pmc, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse,
+    {'gemm': gemm, 'gemm_ab': gemm_ab, 'lib_ab': lib_ab, 'walk': walk, 'walk_pmc': walk_pmc, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse, 'sparse_rows': sparse_rows,
      'gemm_trace': gemm_trace, 'gemm_clock': gemm_clock, 'attn_lib_ab': attn_lib_ab, 'attn_tile': attn_tile, 'chain': chain, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency, 'ffn_pair': ffn_pair, 'slab': slab, 'gemm_packed': gemm_packed}[which]()
