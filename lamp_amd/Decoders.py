@@ -32,7 +32,7 @@ def build_label_mask(n_tgt_vocab, label_adj_matrix, label_mask):
 
 class GraphDecoder(nn.Module):
     TILE_HINT_MAX_DENSITY = 0.9   # active 32x32 tiles / all tiles from which the tile-list hint is not handed to the kernels
-    SPARSE_ROWS_MAX_DENSITY = 0.125   # allowed pairs / L^2 up to which an unstructured graph is flagged LAMP_MASK_SPARSE_ROWS
+    SPARSE_ROWS_MAX_DENSITY = 0.20   # allowed pairs / L^2 up to which an unstructured graph is flagged LAMP_MASK_SPARSE_ROWS
 
     def __init__(self, n_tgt_vocab, n_max_seq, n_layers=6, n_head=8, n_head2=8, d_k=64, d_v=64,
                  d_word_vec=512, d_model=512, d_inner_hid=1024, dropout=0.1, dropout2=0.1,

@@ -3,17 +3,19 @@
 // 4096), but no 32 x 32 tile of the mask is empty, so the tile lists of attention_tile.hip skip nothing and 95 % of the dense
 // kernel's 4 L^2 d FLOPs go to blocked pairs.  Here only the ALLOWED (query, key) pairs are computed:
 //
-//   * one workgroup = 128 queries of one (sample, head), 16 waves; a wave owns 8 queries, 8 lanes per query ("slot"), a lane holds
-//     16 of the query's 128 dimensions (q pre-scaled by 1/temperature * log2 e, the running output o, 16 + 16 registers);
+//   * one workgroup = 256 queries of one (sample, head), 16 waves; a wave owns 16 queries, 4 lanes per query ("slot"), a lane holds
+//     32 of the query's 128 dimensions (q pre-scaled by 1/temperature * log2 e, the running output o: 32 + 32 registers).  (An
+//     8-lanes-per-query instantiation -- 128 queries per workgroup, 16 dimensions per lane -- is kept for the tuning build: the
+//     fixed part of a step is shared by half as many pairs, 14-16 % slower on every density measured);
 //   * K / V stream through LDS in 64-key tiles shared by the whole workgroup (double buffered, 2 x (32 + 32) KiB), fetched by
 //     LDS-DMA through the compiler's own builtin (tracked: no hand-counted waits, no inline-assembly loads): every wave requests
 //     1/16 of the next tile at the top of a step, one barrier per tile;
 //   * per tile a slot takes its row's 64 mask bits (two words of the bit-packed shared mask) and walks the SET bits: per pair
-//     4 x ds_read_b128 of the key row, 8 packed FMAs + a 3-step DPP sum over the slot's 8 lanes = the score, lazy online softmax
-//     (rescale only when the score exceeds the running maximum by 2^32, as attention_tile.hip), 4 x ds_read_b128 of the value
-//     row, 8 packed FMAs.  Slots without a pair left in the tile run along with a score of -inf (probability 0) until the
-//     wave's longest list ends: the price of lock-step, ~55 % useful slots at p = 0.05 (a SIMD's other waves fill the issue
-//     slots of a wave that waits at the barrier);
+//     8 x ds_read_b128 of the key row, 16 packed FMAs + a 2-step DPP sum over the slot's 4 lanes = the score, lazy online softmax
+//     (rescale only when the score exceeds the running maximum by 2^32, as attention_tile.hip), 8 x ds_read_b128 of the value
+//     row, 16 packed FMAs.  Slots without a pair left in the tile run along with a score of -inf (probability 0) until the
+//     wave's longest list ends: the price of lock-step, ~57 % useful slots at configs[4]'s density (a SIMD's other waves fill
+//     the issue slots of a wave that waits at the barrier);
 //   * LDS reads are conflict-free for ARBITRARY key rows: a ds_read_b128 is served in lane groups {0-3, 12-15, 20-27},
 //     {4-11, 16-19, 28-31} (+32), i.e. a quarter of four different slots each; slot s reads the 128-byte halves of its row in
 //     the order r ^ ((s >> 1) & 1), so the four quarters always fall on four different 16-bank quarters (rows are 512 bytes:
@@ -30,7 +32,7 @@ namespace lamp {
 namespace {
 
 constexpr int SP_WAVES = 16;
-constexpr int SP_LPQ_DEFAULT = 8;          // lanes per query of the product route (profiles/r06_sparse_label_attention.txt)
+constexpr int SP_LPQ_DEFAULT = 4;          // lanes per query of the product route (profiles/r06_sparse_label_attention.txt)
 constexpr int SP_TILE = 64;                // keys per tile: one 64-bit mask word pair per query
 constexpr int SP_D = 128;                  // d_k = d_v
 constexpr int SP_BUF = SP_TILE * SP_D;     // floats of one K or V tile (32 KiB)

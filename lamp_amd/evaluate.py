@@ -9,8 +9,8 @@ The reference pulls every batch's predictions to the CPU before it starts the ne
 alternate.  Here they overlap (round 6):
   * a PRODUCER thread pads the next `prefetch` batches (utils/data_loader.py:261-279), builds their gold-binary rows and
     packs token ids, positions and targets into pinned host buffers while the device runs the previous stage;
-  * the issuing thread uploads a stage with ONE asynchronous copy on a copy stream, makes the forward stream(s) wait for
-    it on the device, and issues forward + sigmoid / BCE per batch;
+  * the issuing thread uploads a stage with ONE asynchronous copy per buffer (ids, targets) in front of the stage's first
+    forward, and issues forward + sigmoid / BCE per batch;
   * sigmoid + BCE write every batch's probabilities and per-row losses straight into ONE device matrix / vector for the whole
     split (one launch per batch, nothing else); both come back with one copy each after the last batch, and the per-batch
     mean losses (reduction='mean', test.py:51) are taken on the host in float64.
@@ -142,7 +142,6 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
         it = iter((bi, b) for bi, b in enumerate(batches) if b_lo <= bi < b_hi)
     main = torch.cuda.current_stream(device)
     lanes = [torch.cuda.Stream(device=device) for _ in range(streams)] if streams > 1 else [main]
-    copier = torch.cuda.Stream(device=device)
     # this rank's rows of the result: probabilities and summed BCE per row, filled batch by batch on the device
     r_lo, r_hi = min(b_lo * batch_size, n), min(b_hi * batch_size, n)
     probs_d = torch.empty((max(r_hi - r_lo, 1), n_labels), dtype=torch.float32, device=device)
@@ -154,12 +153,16 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
                                 args=(it, n_labels, batch_size, max(int(prefetch), 1), all_targets, stages, pin, device, stop))
     producer.start()
     try:
-        _issue(model, stages, lanes, copier, device, batch_size, pad_last_batch, int_preds, probs_d, row_loss_d, r_lo)
+        _issue(model, stages, lanes, device, batch_size, pad_last_batch, int_preds, probs_d, row_loss_d, r_lo)
     finally:
         stop.set()          # an exception on this side must not leave the producer blocked on a full queue
         producer.join()
+    t_issued = time.perf_counter()
     for lane in lanes:
         main.wait_stream(lane)
+    if timeline is not None:
+        torch.cuda.synchronize(device)
+        timeline.update(issued=t_issued - t_start, done=time.perf_counter() - t_start)
     all_predictions = torch.zeros(n, n_labels)
     bce_total = 0.0
     if r_hi > r_lo:
@@ -172,7 +175,7 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
     return _combine_ranks(all_predictions, all_targets, bce_total, n, n_labels, world_size, device, group)
 
 
-def _issue(model, stages, lanes, copier, device, batch_size, pad_last_batch, int_preds, probs_d, row_loss_d, r_lo):
+def _issue(model, stages, lanes, device, batch_size, pad_last_batch, int_preds, probs_d, row_loss_d, r_lo):
     """The issuing side: upload a stage, then forward + sigmoid / BCE per batch into the epoch's result buffers.  Buffers that
     cross streams are handed to the caching allocators' own bookkeeping (record_stream for device blocks; pinned blocks are
     not reused before the copies that read them have run), so nothing here waits for the device."""
@@ -182,14 +185,18 @@ def _issue(model, stages, lanes, copier, device, batch_size, pad_last_batch, int
             return
         if isinstance(st, BaseException):
             raise st
-        with torch.cuda.stream(copier):
+        # the stage's two uploads go out on the FIRST lane, in order with its forwards: asynchronous for the host (pinned
+        # source), ~0.1 ms of copy per stage for the device.  (A separate copy stream + an event wait per batch measured the same
+        # median and a long tail -- epochs of 90-150 ms instead of 60 -- on some boxes: profiles/r06_eval_epoch_end_to_end.json.)
+        with torch.cuda.stream(lanes[0]):
             ids_d = st.ids.to(device, non_blocking=True) if st.ids is not None else None
             gold_d = st.gold.to(device, non_blocking=True)
-        uploaded = copier.record_event()
+            uploaded = lanes[0].record_event()
         st.slot.uploaded = uploaded      # the producer may refill this slot's pinned buffers once these copies have run
         for k, (bi, lo, real, T, off, row, adj) in enumerate(st.items):
             lane = lanes[bi % len(lanes)]
-            lane.wait_event(uploaded)
+            if lane is not lanes[0]:
+                lane.wait_event(uploaded)
             with torch.cuda.stream(lane):
                 if ids_d is not None:
                     cnt = real * T
