@@ -238,6 +238,25 @@ def f_live(w, n_enc=2, n_dec=2):
             n_dec * (8 * L * d * d + 4 * L * L * d) + n_dec * 8 * L * d * dff + 2 * L * d)
 
 
+def executed_flops(w, model, n_enc=2, n_dec=2):
+    """GEMM-class + attention FLOPs per sample the kernels really EXECUTE: F_live minus what the weights-only
+    precomputations remove (decoder layer 0's hoisted query, encoder layer 0's folded W1) and, when the label self-attention runs
+    the pair kernel (attention_sparse.hip), with its 4 L^2 d replaced by 4 nnz d.  -> (flops, dict of what was subtracted)."""
+    from lamp_amd.Models import LAMP
+    T, L, d, dff = w['T'], w['L'], w['d'], w['dff']
+    fl = float(f_live(w, n_enc, n_dec))
+    sub = {}
+    if LAMP.cache_layer0_query:
+        sub['hoisted_dec0_query'] = 2.0 * L * d * d
+    if LAMP.fold_embedding:
+        sub['folded_enc0_w1'] = 2.0 * T * d * dff
+    dec = model.decoder
+    dk = d // w['h']
+    if (LAMP.use_sparse_label_attention and getattr(dec, 'label_rows_sparse', False) and L >= 1024 and dk == 128):
+        sub['blocked_label_pairs_skipped'] = n_dec * 4.0 * d * (float(L) * L - dec.label_allowed_pairs)
+    return fl - sum(sub.values()), sub
+
+
 def build(w, batch, device, seed=0, lengths=None, n_max=None):
     """Model + one batch.  The weights and the label graph are the same on every rank (seed 0: what replicating a
     checkpoint gives); `seed` only draws the batch, so that ranks work on different samples."""
@@ -792,11 +811,10 @@ def main():
         kernels['gemm']['tflops'] = tf
     # what the model object computed ONCE per weight version, outside every forward (all of it a function of the weights alone)
     from lamp_amd.Models import LAMP as _LAMP
-    hoisted = 2.0 * w['L'] * w['d'] * w['d'] if _LAMP.cache_layer0_query else 0.0            # SURVEY.md G11, per sample
-    folded = 2.0 * w['T'] * w['d'] * w['dff'] if _LAMP.fold_embedding else 0.0               # encoder layer 0's W1, per sample
+    fx_head, fx_head_sub = executed_flops(w, model)
     weights_only = {
         'dec0_query': bool(_LAMP.cache_layer0_query), 'chain_packs': bool(_LAMP.use_chain_packs),
-        'embed_fold': bool(_LAMP.fold_embedding),
+        'embed_fold': bool(_LAMP.fold_embedding), 'sparse_label_attention': 'blocked_label_pairs_skipped' in fx_head_sub,
         'note': 'decoder layer 0 query = label table x W_q (SURVEY.md G11); encoder layer 0 hidden = relu((Emb W1^T)[tok] + '
                 '(Pos W1^T + b1)[pos]) -- the gather is a one-hot product, so W1 folds into the tables; both re-associations '
                 'of the same linear maps, built once per weight version with lamp_linear_fwd.  F_live (SURVEY.md 8d) is NOT '
@@ -838,8 +856,9 @@ def main():
             'f_live_gflop_per_sample': fl / 1e9,
             'achieved_tflops_per_gpu': value / n_gpus * fl / 1e12,
             'frac_of_fp32_mfma_peak': value / n_gpus * fl / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-            'executed_gflop_per_sample': (fl - hoisted - folded) / 1e9,
-            'executed_frac_of_fp32_mfma_peak': value / n_gpus * (fl - hoisted - folded) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            'executed_gflop_per_sample': fx_head / 1e9,
+            'executed_frac_of_fp32_mfma_peak': value / n_gpus * fx_head / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            'not_executed_gflop_per_sample': {k: x / 1e9 for k, x in fx_head_sub.items()},
             'kernel_time_us_per_step': sum(k['us_per_step'] for k in kernels.values()),
             'kernel_time_note': 'HIP-event durations of an INSTRUMENTED replay (an event pair around every launch adds '
                                 '~2-3 us per kernel): the sum may exceed ms_per_step; rocprofv3 kernel-only figures are '
@@ -865,6 +884,7 @@ def main():
             pe, ke = profile_steps(N, me['step'], psteps)
             v = eb * steps / me['elapsed']
             fe = f_live(we)
+            fx, fx_sub = executed_flops(we, me['model'])
             rf = roofline_of(pe, psteps, name if eb == 32 else None)
             extra[name] = {
                 'value': v, 'unit': 'samples/s', 'batch': eb, 'steps': steps, 'warmup': warm,
@@ -874,7 +894,12 @@ def main():
                 'roofline': {'achieved': rf['achieved'], 'frac': rf['frac'], 'unit': 'TFLOP/s', 'traffic': rf['traffic'],
                              'traffic_stale': rf.get('traffic_stale')},
                 'attention_tflops': ke.get('attention', {}).get('tflops'),
-                'forward_frac_of_fp32_mfma_peak': v * fe / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                # utilisation on EXECUTED FLOPs (never above 1); the F_live figure is a dense-equivalent rate: where the pair
+                # kernel skips blocked label pairs it says how fast a dense implementation would have to be, not how busy the chip is
+                'forward_frac_of_fp32_mfma_peak': v * fx / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                'executed_gflop_per_sample': fx / 1e9, 'f_live_gflop_per_sample': fe / 1e9,
+                'not_executed_gflop_per_sample': {k: x / 1e9 for k, x in fx_sub.items()},
+                'f_live_equivalent_tflops': v * fe / 1e12,
             }
             me.clear()
             torch.cuda.empty_cache()

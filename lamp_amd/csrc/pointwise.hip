@@ -37,32 +37,9 @@ __device__ __forceinline__ void gather_row(int64_t tok, int64_t ps, const float*
     const float4* q1 = fold.p1 ? reinterpret_cast<const float4*>(fold.p1 + (ok ? ps : 0) * fold.dff) : nullptr;
     float4* h = reinterpret_cast<float4*>(fold.hid + dst * fold.dff);
     const int nx = d / 4, nh = fold.dff / 4;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nx <= 128 && nh <= 128) {
-        // rows of up to 512 floats: ALL table reads of the wave go out before the first store (clamped addresses instead of
-        // guarded loads: a guarded load is a branch plus a full wait) -- every row of the batch is resident at once, so the wave
-        // is latency-bound and a second dependent round trip for the hidden row would cost its whole latency
-        float4 a[2], pa[2], b[2], pb[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = lane + 64 * i, cx = c < nx ? c : 0, ch = c < nh ? c : 0;
-            a[i] = e[cx];
-            pa[i] = q ? q[cx] : zero;
-            b[i] = e1[ch];
-            pb[i] = q1 ? q1[ch] : zero;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = lane + 64 * i;
-            float4 v = make_float4(a[i].x + pa[i].x, a[i].y + pa[i].y, a[i].z + pa[i].z, a[i].w + pa[i].w);
-            float4 u = make_float4(fmaxf(b[i].x + pb[i].x, 0.f), fmaxf(b[i].y + pb[i].y, 0.f), fmaxf(b[i].z + pb[i].z, 0.f),
-                                   fmaxf(b[i].w + pb[i].w, 0.f));
-            if (!ok) v = u = make_float4(nan, nan, nan, nan);
-            if (c < nx) o[c] = v;
-            if (c < nh) h[c] = u;
-        }
-        return;
-    }
+    // Two plain passes, the embedded row then the hidden row.  Both "all table reads in flight before the first store"
+    // forms (one fused loop; clamped loads into registers up front) measured SLOWER in the forward: 23.6-28 us against 21-22
+    // (profiles/r06_rejected_experiments.txt #1); the plain form is kept because it measures fastest.
     for (int c = lane; c < nx; c += 64) {
         float4 v = e[c];
         if (q) {

@@ -25,7 +25,10 @@ for k, v in d['kernels'].items():
     print('  %-12s %5.1f launches %8.1f us/step  %s TF' % (k, v['launches_per_step'], v['us_per_step'], v['tflops'] and round(v['tflops'], 1)))
 print('  pipelined', d['pipelined_batches_in_flight'] and round(d['pipelined_batches_in_flight']['value']))
 for k, v in d.get('workloads', {}).items():
-    print('  %-14s %9.1f samples/s  %8.3f ms  gemm %.3f  attn %.1f TF  fwd %.3f' % (k, v['value'], v['ms_per_step'], v['roofline']['frac'], v['attention_tflops'], v['forward_frac_of_fp32_mfma_peak']))
+    if 'roofline' in v:
+        print('  %-14s %9.1f samples/s  %8.3f ms  gemm %.3f  attn %.1f TF  fwd %.3f' % (k, v['value'], v['ms_per_step'], v['roofline']['frac'], v['attention_tflops'], v['forward_frac_of_fp32_mfma_peak']))
+    else:
+        print('  %-14s %9.1f samples/s  %8.3f ms  fwd %.3f' % (k, v['value'], v['ms_per_step'], v['forward_frac_of_fp32_mfma_peak']))
 print('  cpu', d.get('cpu_baseline', {}).get('value'))
 PY
       ;;
