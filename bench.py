@@ -641,6 +641,9 @@ def main():
     ap.add_argument('--no-embed-fold', action='store_true',
                     help="A/B switch: launch encoder layer 0's first FFN GEMM instead of gathering its hidden rows from the "
                          'weights-only folded tables (LAMP.fold_embedding)')
+    ap.add_argument('--no-sparse-label-attention', action='store_true',
+                    help='A/B switch: the dense tile kernels for the label self-attention even where the decoder flags the label '
+                         'graph as sparse and unstructured (LAMP.use_sparse_label_attention; synthetic4096)')
     ap.add_argument('--mask', default=None, choices=['prior', 'none', 'inveye'], help='override the workload label mask')
     args = ap.parse_args()
 
@@ -678,6 +681,9 @@ def main():
     if args.no_embed_fold:
         from lamp_amd.Models import LAMP
         LAMP.fold_embedding = False
+    if args.no_sparse_label_attention:
+        from lamp_amd.Models import LAMP
+        LAMP.use_sparse_label_attention = False
     w_base = dict(WORKLOADS[args.workload])
     if args.mask:
         w_base['mask'] = args.mask

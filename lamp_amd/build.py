@@ -32,7 +32,7 @@ SOURCES = ['gemm.hip', 'gemm_gen.hip', 'attention.hip', 'attention_tile.hip', 'a
            'pointwise.hip',
            'backward.hip', 'chain.hip', 'api.hip']
 TUNING_SOURCES = {'gemm.hip', 'attention.hip', 'attention_tile.hip', 'attention_small.hip', 'attention_sparse.hip', 'chain.hip'}
-TUNING_ONLY = ['slab.hip']   # experiments kept bit-identical and benchmarkable, not part of the product library   # the units that contain LAMP_TUNING code
+TUNING_ONLY = ['experiments/slab.hip']   # experiments kept bit-identical and benchmarkable, never part of the product library
 HEADERS = [os.path.join(CSRC, 'lamp_kernels.h'), os.path.join(CSRC, 'lamp_asm.h'), os.path.join(HERE, '..', 'include', 'lamp_hip.h')]
 REMARKS = ['-Rpass-analysis=kernel-resource-usage']   # per-kernel VGPR / AGPR / scratch report, saved beside each object
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-fvisibility-inlines-hidden', '-Wno-unused-result']
@@ -69,9 +69,13 @@ def _run(cmd, verbose, remarks=None):
             f.write(r.stderr)
 
 
+def _stem(source):
+    return os.path.basename(source)
+
+
 def resources_path(source, tuning=False):
     """Where build() keeps hipcc's -Rpass-analysis=kernel-resource-usage report of one translation unit."""
-    return os.path.join(OBJ, source.replace('.hip', '.tuning.resources.txt' if tuning else '.resources.txt'))
+    return os.path.join(OBJ, _stem(source).replace('.hip', '.tuning.resources.txt' if tuning else '.resources.txt'))
 
 
 def kernel_resources(source, tuning=False):
@@ -135,7 +139,7 @@ def _guard_stamp(source, tuning, tool):
     for f in [os.path.join(CSRC, source)] + HEADERS + [os.path.join(HERE, 'isa_guard.py')]:
         with open(f, 'rb') as fh:
             h.update(fh.read())
-    return os.path.join(OBJ, source.replace('.hip', '.tuning.guard' if tuning else '.guard')), h.hexdigest()
+    return os.path.join(OBJ, _stem(source).replace('.hip', '.tuning.guard' if tuning else '.guard')), h.hexdigest()
 
 
 def _guard(source, tuning, tool):
@@ -163,7 +167,7 @@ def verify(verbose=False):
     tool = toolchain()
     jobs = []
     for s in SOURCES + TUNING_ONLY:
-        if s not in isa_guard.GUARDED:
+        if _stem(s) not in isa_guard.GUARDED:
             continue
         if s in SOURCES:
             jobs.append((s, False))
@@ -196,14 +200,14 @@ def build(force=False, verbose=False):
                 jobs.append(([cc] + FLAGS + REMARKS + ['-DLAMP_TUNING', '-c', src, '-o', tobj], resources_path(s, True)))
     for s in TUNING_ONLY:
         src = os.path.join(CSRC, s)
-        tobj = os.path.join(OBJ, s.replace('.hip', '.tuning.o'))
+        tobj = os.path.join(OBJ, _stem(s).replace('.hip', '.tuning.o'))
         if force or _newer(tobj, [src] + HEADERS) or not os.path.exists(resources_path(s, True)):
             jobs.append(([cc] + FLAGS + REMARKS + ['-DLAMP_TUNING', '-c', src, '-o', tobj], resources_path(s, True)))
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4) or 1) as ex:
         list(ex.map(lambda j: _run(j[0], verbose, j[1]), jobs))
     objs = [os.path.join(OBJ, s.replace('.hip', '.o')) for s in SOURCES]
     tobjs = [os.path.join(OBJ, s.replace('.hip', '.tuning.o' if s in TUNING_SOURCES else '.o')) for s in SOURCES]
-    tobjs += [os.path.join(OBJ, s.replace('.hip', '.tuning.o')) for s in TUNING_ONLY]
+    tobjs += [os.path.join(OBJ, _stem(s).replace('.hip', '.tuning.o')) for s in TUNING_ONLY]
     problems = verify(verbose)
     if problems:
         for lib in (LIB, LIB_TUNING):   # never leave a library of unsound kernels behind

@@ -18,7 +18,7 @@
 // Ragged batches: the live row count comes from device memory (m_dev); the kernel spreads THOSE rows over the grid (rows per
 // workgroup = the fewest groups of four that cover them) and dispatches on its own group count, so a half-empty batch costs
 // half the MFMAs -- down to the floor of streaming W once per CU.
-#include "lamp_asm.h"
+#include "../lamp_asm.h"
 
 namespace lamp {
 

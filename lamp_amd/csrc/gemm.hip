@@ -70,14 +70,6 @@ struct GemmTile {
     static constexpr int A_LD = BM * BK / 4 / NT;  // float4 loads per thread per tile
     static constexpr int B_LD = BN * BK / 4 / NT;
     static constexpr size_t LDS_BYTES = size_t(2) * (BM + BN) * LDS_STRIDE * sizeof(float);
-    // Direct-to-LDS staging (DMA = true, see gemm_nt_kernel): two or three unpadded [BM + BN][BK] images, filled by
-    // buffer_load_dwordx4 ... lds in 1 KiB pieces (one wave instruction = 64 lanes x 16 B = RPP whole rows).
-    static constexpr int QPR = BK / 4;            // 16-byte quads per row
-    static constexpr int RPP = 64 / QPR;          // rows per 1 KiB piece
-    static constexpr int A_PW = BM / RPP / (NT / 64);   // pieces per wave and k-step
-    static constexpr int B_PW = BN / RPP / (NT / 64);
-    static constexpr size_t DMA_STAGE_BYTES = size_t(BM + BN) * BK * sizeof(float);   // x 2 (DMA mode 1) or 3 (mode 2)
-    static constexpr bool DMA_OK = (BK == 16 || BK == 32 || BK == 64) && BM % (RPP * (NT / 64)) == 0 && BN % (RPP * (NT / 64)) == 0;
     // Waves per SIMD the register allocator must leave room for.  The 64x64x16 tile serves launches of ~1200 tiles
     // (encoder FFN at batch 32: 1208): five workgroups per CU hold them all at once, four leave a second, mostly empty
     // round (44 -> 51 us when the 16-byte epilogue operands pushed the kernel from 92 to 100 registers).
@@ -95,66 +87,18 @@ struct GemmTile {
 // round trip over 8-16x more matrix work per wave and keep the registers for occupancy.
 // VEC: bias / residual / C move as 16-byte accesses (N, ldc, ldr multiples of 4 and 16-byte aligned bases -- every shape
 // of the forward); the scalar instantiation serves odd widths.
-//
-// DMA (round 4): the K-step tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction), no
-// staging registers and no ds_write pass.  The LDS-DMA destination is wave-uniform base + lane * 16, so the image cannot be
-// padded; rows are BK floats, stored back to back, and bank conflicts are avoided by an XOR on the 16-byte quad index:
-// quad q of row r sits in slot q ^ f(r & 15), applied to the SOURCE address of the filling lane and to the fragment read
-// (f: see dma_swz; checked against the ds_read_b128 lane groups of MI355X_MICROARCH.md: conflict-free for BK = 16 / 32 / 64
-// and both MFMA shapes, where the padded image is 2-way).  A fragment still holds k = 16c + 4 hi + j: same products, same
-// k-order, same bits as the register-staged kernel.
-//   DMA = 1: fragment reads are ordinary loads.  hipcc (ROCm 7.2) orders every LDS read behind ALL earlier LDS-DMA
-//            (s_waitcnt vmcnt(0) in front of the first ds_read that follows one -- it cannot tell the stages apart), so the
-//            step is: drain, barrier, read ALL fragments of tile t, request tile t + 1, multiply.  Two stages; the request
-//            is covered by one step of MFMAs (and by the other workgroups of the CU).
-//   DMA = 2: fragment reads are inline-asm ds_read_b128 (invisible to that pass; waited for by hand, lgkmcnt + sched_barrier).
-//            Three stages: while tile t is multiplied, t + 1 has landed or is landing and t + 2 is requested; ONE raw
-//            s_barrier per K step, and the only vector-memory wait in the loop is a counted s_waitcnt vmcnt(pieces of one
-//            tile) -- __syncthreads() would drain the DMA queue at every step.
-template <int BK>
-__device__ __forceinline__ int dma_swz(int r) {   // r = row & 15
-    if constexpr (BK == 16) return (0x1230 >> (r & 12)) & 3;   // rows 0-3 / 4-7 / 8-11 / 12-15 -> 0, 3, 2, 1
-    else if constexpr (BK == 32) return (r >> 1) & 7;
-    else return r & 15;
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ const float* uniform_ptr(const float* q) {
     const uint64_t b = reinterpret_cast<uint64_t>(q);
     const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(b)), hi = __builtin_amdgcn_readfirstlane(unsigned(b >> 32));
     return reinterpret_cast<const float*>((uint64_t(hi) << 32) | lo);
 }
-// One LDS-DMA instruction: 64 lanes x 16 bytes from per-lane buffer offsets to LDS [dst, dst + 1 KiB) in lane order (dst
-// wave-uniform).  (A plain function, not code inside the kernel template: with the builtin spelled in the template hipcc's
-// host pass silently drops the kernel's launch stub -- the library then fails to load with an undefined symbol.)
-typedef __attribute__((address_space(3))) void* lds_ptr;
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, float* dst, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, voff, soff, 0, 0);
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkmcnt() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);   // hipcc moves register-only MFMAs across an asm wait otherwise
-}
-__device__ __forceinline__ f32x4 lds_read16(unsigned addr) {   // LDS byte address
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// The whole tile program.  EXPL = false: the tile is derived from blockIdx (gemm_nt_kernel: one tile per workgroup);
-// EXPL = true: the caller names the tile (x_tm, x_tn) -- a persistent workgroup running one tile after another (gemm_pair_kernel).
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC, int DMA, bool EXPL>
+// The whole tile program: one tile per workgroup, derived from blockIdx.  (Staging variants that lost their measurements --
+// LDS-DMA with compiler-scheduled / inline-assembly fragment reads, W fragments straight from global memory or from a packed
+// copy, two dependent GEMMs in one persistent launch -- are not carried here any more: csrc/experiments/README.md.)
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, int tiles_n, int tiles_m, int panel_split,
-                                          FastDiv fd_group, FastDiv fd_seg, int x_tm, int x_tn) {
+                                          FastDiv fd_group, FastDiv fd_seg) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
     // lane -> (row within an MFMA block, which group of 4 consecutive k this lane's b128 read covers)
     constexpr int KQ = 64 / MF;             // 2 for 32x32x2, 4 for 16x16x4
@@ -164,13 +108,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
     constexpr int S = T::LDS_STRIDE;
     constexpr int C4 = BK / 4;  // float4 per tile row
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;               // [2][BM][S]                    (DMA: stage s = smem + s * (BM + BN) * BK, A then W rows)
+    float* As = smem;               // [2][BM][S]
     float* Bs = smem + 2 * BM * S;  // [2][BN][S]
-    // DMA = 3 (experiment): the W fragments come straight from global memory in MFMA layout (a lane's b128 = the four
-    // consecutive k of ITS weight row: exactly its fragment of an NT product) -- no LDS pass for W at all; A is staged as ever.
-    constexpr bool WDIR = DMA == 3;
-    constexpr int LDMA = WDIR ? 0 : DMA;   // the LDS-DMA mode proper
-    static_assert(!DMA || (T::DMA_OK && !KTAIL), "direct-to-LDS staging: whole 1 KiB pieces per wave, K a multiple of BK");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -204,8 +143,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
         panel_split = tiles_m >= 16 && (pan_xcd * tiles_n + 31) / 32 <= ((nwg + 7) / 8 + 31) / 32;
     }
     int item = 0, pan0 = 0, pan1 = tiles_m;
-    int tn_all = x_tn, tm = x_tm;
-    if constexpr (!EXPL) {
+    int tn_all = 0, tm = 0;
     if (panel_split) {
         const int q = tiles_m >> 3, r = tiles_m & 7, xcd = blockIdx.x & 7;
         pan0 = xcd * q + (xcd < r ? xcd : r);
@@ -243,7 +181,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
         tn_all = div_1_to_8(in_grp, gm);
         tm = first_m + (in_grp - tn_all * gm);
     }
-    }   // !EXPL
     const int seg = fdiv(tn_all, fd_seg);       // tn_all / tiles_n_seg
     const int tn = tn_all - seg * tiles_n_seg;
     const int64_t m0 = int64_t(tm) * BM;
@@ -260,12 +197,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
     // held in vector registers compiles to a waterfall loop -- hand the compiler scalars)
     const __amdgpu_buffer_rsrc_t rsA =
         make_rsrc(uniform_ptr(Abase + m0 * p.lda), __builtin_amdgcn_readfirstlane(unsigned((uint64_t(rows_m - 1) * lda + p.K) * 4u)));
-    // WDIR with a packed copy (lamp_pack_weight format 0: per 16 columns and 32 k the two fragment chunks lane by lane): a fragment
-    // load is one contiguous KiB instead of 16 rows x 64 bytes
-    const bool wpk = WDIR && MF == 16 && p.Wp[seg] != nullptr;
-    const __amdgpu_buffer_rsrc_t rsW = wpk
-        ? make_rsrc(uniform_ptr(p.Wp[seg]), __builtin_amdgcn_readfirstlane(unsigned(uint64_t(p.N) * uint64_t(p.K) * 4u)))
-        : make_rsrc(uniform_ptr(p.W[seg] + int64_t(n0) * p.ldw), __builtin_amdgcn_readfirstlane(unsigned((uint64_t(rows_n - 1) * ldw + p.K) * 4u)));
+    const __amdgpu_buffer_rsrc_t rsW =
+        make_rsrc(uniform_ptr(p.W[seg] + int64_t(n0) * p.ldw), __builtin_amdgcn_readfirstlane(unsigned((uint64_t(rows_n - 1) * ldw + p.K) * 4u)));
 
     acc_t acc[T::MI][T::NI];
 #pragma unroll
@@ -280,22 +213,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
     // does not cover an L2/MALL round trip).
     float4 ra0[T::A_LD], rb0[T::B_LD], ra1[T::A_LD], rb1[T::B_LD];
     unsigned voa[T::A_LD], vob[T::B_LD];  // byte offsets of this thread's float4s inside the tile
-    constexpr int NWF = WDIR ? (BK / KCH) * T::NI : 1;
-    float4 wf0[NWF], wf1[NWF];            // WDIR: W fragments of the even / odd k-step, [chunk][block]
-    unsigned vow[NWF];
-    if constexpr (WDIR) {
-#pragma unroll
-        for (int c = 0; c < BK / KCH; ++c)
-#pragma unroll
-            for (int j = 0; j < T::NI; ++j)
-                vow[c * T::NI + j] = wpk ? unsigned((n0 + wn * T::WTN + j * MF) / 16) * unsigned(p.K / 32) * 2048u + unsigned(c) * 1024u + unsigned(lane) * 16u
-                                         : unsigned((wn * T::WTN + j * MF + l31) * ldw + c * KCH + hi * 4) * 4u;
-    }
-    auto wload = [&](int k0, float4 (&wf)[NWF]) {
-        const unsigned so = wpk ? unsigned(k0) * 64u : unsigned(k0) * 4u;
-#pragma unroll
-        for (int x = 0; x < NWF; ++x) wf[x] = bload4(rsW, vow[x], so);
-    };
 #pragma unroll
     for (int i = 0; i < T::A_LD; ++i) {
         const int idx = tid + i * T::NT;
@@ -326,10 +243,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
             const unsigned so = unsigned(k0) * 4u;  // uniform -> soffset
 #pragma unroll
             for (int i = 0; i < T::A_LD; ++i) ra[i] = bload4(rsA, voa[i], so);
-            if constexpr (!WDIR) {
 #pragma unroll
-                for (int i = 0; i < T::B_LD; ++i) rb[i] = bload4(rsW, vob[i], so);
-            }
+            for (int i = 0; i < T::B_LD; ++i) rb[i] = bload4(rsW, vob[i], so);
         }
     };
     auto lstore = [&](int buf, const float4 (&ra)[T::A_LD], const float4 (&rb)[T::B_LD]) {
@@ -341,13 +256,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
             const int row = idx / C4, c4 = idx - row * C4;
             *reinterpret_cast<float4*>(a + row * S + c4 * 4) = ra[i];
         }
-        if constexpr (!WDIR) {
 #pragma unroll
-            for (int i = 0; i < T::B_LD; ++i) {
-                const int idx = tid + i * T::NT;
-                const int row = idx / C4, c4 = idx - row * C4;
-                *reinterpret_cast<float4*>(b + row * S + c4 * 4) = rb[i];
-            }
+        for (int i = 0; i < T::B_LD; ++i) {
+            const int idx = tid + i * T::NT;
+            const int row = idx / C4, c4 = idx - row * C4;
+            *reinterpret_cast<float4*>(b + row * S + c4 * 4) = rb[i];
         }
     };
     auto mfma_chunk = [&](const float4 (&fa)[T::MI], const float4 (&fb)[T::NI]) {
@@ -374,7 +287,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
         __builtin_amdgcn_s_setprio(0);
 #endif
     };
-    auto compute = [&](int buf, const float4 (&wf)[NWF]) {
+    auto compute = [&](int buf) {
         const float* a = As + buf * BM * S + (wm * T::WTM + l31) * S + hi * 4;
         const float* b = Bs + buf * BN * S + (wn * T::WTN + l31) * S + hi * 4;
 #pragma unroll
@@ -383,96 +296,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
 #pragma unroll
             for (int i = 0; i < T::MI; ++i) fa[i] = *reinterpret_cast<const float4*>(a + i * MF * S + c * KCH);
 #pragma unroll
-            for (int j = 0; j < T::NI; ++j) {
-                if constexpr (WDIR) fb[j] = wf[c * T::NI + j];
-                else fb[j] = *reinterpret_cast<const float4*>(b + j * MF * S + c * KCH);
-            }
+            for (int j = 0; j < T::NI; ++j) fb[j] = *reinterpret_cast<const float4*>(b + j * MF * S + c * KCH);
             mfma_chunk(fa, fb);
         }
-    };
-
-    // ---- direct-to-LDS staging (DMA) ----
-    constexpr int STAGE = (BM + BN) * BK;   // floats per LDS stage
-    constexpr int PW = T::A_PW + T::B_PW;   // LDS-DMA instructions per wave and k-step
-    unsigned dva[LDMA ? T::A_PW : 1], dvb[LDMA ? T::B_PW : 1];   // source byte offsets of this lane's quads inside the tile
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    if constexpr (LDMA) {
-        const int prow = lane / T::QPR, pq = lane % T::QPR;   // row inside a piece, LDS slot inside the row
-#pragma unroll
-        for (int i = 0; i < T::A_PW; ++i) {
-            const int row = (wave_u * T::A_PW + i) * T::RPP + prow;
-            dva[i] = unsigned(row * lda + ((pq ^ dma_swz<BK>(row & 15)) << 2)) * 4u;
-        }
-#pragma unroll
-        for (int i = 0; i < T::B_PW; ++i) {
-            const int row = (wave_u * T::B_PW + i) * T::RPP + prow;
-            dvb[i] = unsigned(row * ldw + ((pq ^ dma_swz<BK>(row & 15)) << 2)) * 4u;
-        }
-    }
-    auto dma_stage = [&](int kt, int st) {
-        const unsigned so = unsigned(kt * BK) * 4u;   // uniform -> soffset
-        float* base = smem + st * STAGE;
-#pragma unroll
-        for (int i = 0; i < T::A_PW; ++i)
-            lds_dma16(rsA, base + (wave_u * T::A_PW + i) * 256, dva[i], so);
-#pragma unroll
-        for (int i = 0; i < T::B_PW; ++i)
-            lds_dma16(rsW, base + BM * BK + (wave_u * T::B_PW + i) * 256, dvb[i], so);
-    };
-    int qoff[BK / KCH];   // float offset of this lane's quad of chunk c inside its (swizzled) row
-#pragma unroll
-    for (int c = 0; c < BK / KCH; ++c) qoff[c] = ((c * KQ + hi) ^ dma_swz<BK>(l31 & 15)) << 2;
-    constexpr int NCH = BK / KCH;
-    // DMA = 1: all fragments of a stage into registers (ordinary loads), then -- by the caller -- the next request, then the MFMAs
-    float4 fra[LDMA == 1 ? NCH : 1][T::MI], frb[LDMA == 1 ? NCH : 1][T::NI];
-    auto dma_read = [&](int st) {
-        const float* a = smem + st * STAGE + (wm * T::WTM + l31) * BK;
-        const float* b = smem + st * STAGE + BM * BK + (wn * T::WTN + l31) * BK;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-#pragma unroll
-            for (int i = 0; i < T::MI; ++i) fra[c][i] = *reinterpret_cast<const float4*>(a + i * MF * BK + qoff[c]);
-#pragma unroll
-            for (int j = 0; j < T::NI; ++j) frb[c][j] = *reinterpret_cast<const float4*>(b + j * MF * BK + qoff[c]);
-        }
-    };
-    // DMA = 2: inline-asm reads, chunk c + 1 requested before chunk c is multiplied
-    const unsigned lds0 = unsigned(reinterpret_cast<uintptr_t>((lds_ptr)smem));
-    auto dma_compute_asm = [&](int st) {
-        const unsigned a = lds0 + unsigned(st * STAGE + (wm * T::WTM + l31) * BK) * 4u;
-        const unsigned b = lds0 + unsigned(st * STAGE + BM * BK + (wn * T::WTN + l31) * BK) * 4u;
-        f32x4 ra[2][T::MI], rb[2][T::NI];
-        auto rd = [&](int c, f32x4 (&xa)[T::MI], f32x4 (&xb)[T::NI]) {
-#pragma unroll
-            for (int i = 0; i < T::MI; ++i) xa[i] = lds_read16(a + unsigned(i * MF * BK + qoff[c]) * 4u);
-#pragma unroll
-            for (int j = 0; j < T::NI; ++j) xb[j] = lds_read16(b + unsigned(j * MF * BK + qoff[c]) * 4u);
-        };
-        rd(0, ra[0], rb[0]);
-        static_for<0, NCH>([&](auto C) {
-            constexpr int c = decltype(C)::value;
-            if constexpr (c + 1 < NCH) {
-                rd(c + 1, ra[(c + 1) & 1], rb[(c + 1) & 1]);
-                wait_lgkmcnt<T::MI + T::NI>();
-            } else {
-                wait_lgkmcnt<0>();
-            }
-            float4 fa[T::MI], fb[T::NI];
-#pragma unroll
-            for (int i = 0; i < T::MI; ++i) fa[i] = make_float4(ra[c & 1][i].x, ra[c & 1][i].y, ra[c & 1][i].z, ra[c & 1][i].w);
-#pragma unroll
-            for (int j = 0; j < T::NI; ++j) fb[j] = make_float4(rb[c & 1][j].x, rb[c & 1][j].y, rb[c & 1][j].z, rb[c & 1][j].w);
-            mfma_chunk(fa, fb);
-            if constexpr (c + 1 < NCH) __builtin_amdgcn_sched_barrier(0);   // the next chunk's wait stays behind these MFMAs
-        });
     };
 
     const int nk = (p.K + BK - 1) / BK;
-    if constexpr (!LDMA) gload(0, ra0, rb0);
-    if constexpr (WDIR) {
-        wload(0, wf0);
-        if (nk > 1) wload(BK, wf1);
-    }
+    gload(0, ra0, rb0);
 
     // Epilogue operands.  The products are issued TRANSPOSED -- W fragment as the MFMA's A operand, activation fragment as
     // its B operand -- so the accumulator block holds C^T: lane (m = lane & (MF-1), hi) owns, for ITS output row m, four
@@ -517,60 +347,26 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
             }
     }
 
-    if constexpr (LDMA) {
-        // after the epilogue operands' loads: vector-memory operations retire in order, and the counted wait of step 0 must
-        // not have younger register loads between itself and tile 0
-        dma_stage(0, 0);
-        if (LDMA == 2 && nk > 1) dma_stage(1, 1);
-    } else {
-        lstore(0, ra0, rb0);
-        if (nk > 1) gload(BK, ra0, rb0);      // tile 1 -> set 0
-        if (nk > 2) gload(2 * BK, ra1, rb1);  // tile 2 -> set 1
-        __syncthreads();
-    }
+    lstore(0, ra0, rb0);
+    if (nk > 1) gload(BK, ra0, rb0);      // tile 1 -> set 0
+    if (nk > 2) gload(2 * BK, ra1, rb1);  // tile 2 -> set 1
+    __syncthreads();
 #ifdef LAMP_TUNING
     const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
     const unsigned long long c_loop = p.trace ? __builtin_readcyclecounter() : 0ull;   // shader-clock cycles (s_memtime)
 #endif
 
-    if constexpr (LDMA == 1) {
-        for (int kt = 0; kt < nk; ++kt) {
-            wait_vmcnt<0>();                 // tile kt has landed (this wave's pieces; the barrier makes it everyone's)
-            __builtin_amdgcn_s_barrier();    // ... and every wave is past its reads of tile kt - 1, whose stage is refilled below
-            asm volatile("" ::: "memory");
-            dma_read(kt & 1);
-            if (kt + 1 < nk) dma_stage(kt + 1, (kt + 1) & 1);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) mfma_chunk(fra[c], frb[c]);
-        }
-    } else if constexpr (LDMA == 2) {
-        // step kt: tile kt in stage kt % 3 (requested two steps ago), tile kt + 1 in flight, tile kt + 2 requested here --
-        // into the stage tile kt - 1 was read from: every wave is past those reads once it has passed this step's barrier
-        // (its MFMAs of step kt - 1 consumed them).  Loads retire in order, so "at most one tile's pieces outstanding" =
-        // this wave's pieces of tile kt have landed; the barrier then makes that true for every wave's pieces.
-        int st = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) wait_vmcnt<PW>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt + 2 < nk) dma_stage(kt + 2, st >= 1 ? st - 1 : 2);
-            dma_compute_asm(st);
-            st = st == 2 ? 0 : st + 1;
-        }
-    } else
     for (int kt = 0; kt < nk; kt += 2) {
         // even step: tile kt in LDS[0]; tile kt+1 in set 0, tile kt+2 in set 1
-        compute(0, wf0);
+        compute(0);
         if (kt + 1 < nk) lstore(1, ra0, rb0);
         if (kt + 3 < nk) gload((kt + 3) * BK, ra0, rb0);
-        if constexpr (WDIR) { if (kt + 2 < nk) wload((kt + 2) * BK, wf0); }   // into the set this step's MFMAs have read
         __syncthreads();
         if (kt + 1 >= nk) break;
         // odd step: tile kt+1 in LDS[1]; tile kt+2 in set 1, tile kt+3 in set 0
-        compute(1, wf1);
+        compute(1);
         if (kt + 2 < nk) lstore(0, ra1, rb1);
         if (kt + 4 < nk) gload((kt + 4) * BK, ra1, rb1);
-        if constexpr (WDIR) { if (kt + 3 < nk) wload((kt + 3) * BK, wf1); }
         __syncthreads();
     }
 #ifdef LAMP_TUNING
@@ -641,151 +437,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
 #endif
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC, int DMA = 0>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, MF))) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
                                                                           int tiles_n, int tiles_m,
                                                                           int panel_split, FastDiv fd_group,
                                                                           FastDiv fd_seg) {
-    gemm_body<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC, DMA, false>(p, tiles_n_seg, tiles_n, tiles_m, panel_split, fd_group,
-                                                                            fd_seg, 0, 0);
+    gemm_body<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC>(p, tiles_n_seg, tiles_n, tiles_m, panel_split, fd_group, fd_seg);
 }
-
-#ifdef LAMP_TUNING
-// ---- EXPERIMENT (tuning build): two dependent GEMMs in ONE launch, row-panel-local hand-off through counters ----
-//   H = act(X . W1^T + b1)   then   Y = H . W2^T + b2 (+ R)        (the encoder's FFN pair, lamp/SubLayers.py:133-142 before the LayerNorm)
-// Persistent workgroups (at most the resident capacity), one task queue per XCD: row-panel tm belongs to XCD tm % 8 -- a workgroup
-// reads its XCD from HW_REG_XCC_ID and only ever takes that XCD's tasks, so a panel's H rows are written and read through ONE L2
-// (no cross-XCD coherence traffic: the producer waits for its stores' acknowledgements, vmcnt(0), and bumps the panel's counter;
-// the consumer sees the counter reach the panel's tile count, invalidates its L1 and reads).  Queue order per XCD: all stage-0
-// tiles (panel-major), then all stage-1 tiles in the same panel order -- when a stage-1 tile is taken every stage-0 tile of that XCD
-// has been taken by a running workgroup that waits for nothing: no deadlock, whatever the residency.  The tiles are the ordinary
-// tile program (gemm_body): same products, same k-order, same bits as two launches.
-#ifndef PAIR_POLL_SLEEP
-#define PAIR_POLL_SLEEP 32   // x 64 cycles between two looks at a panel counter
-#endif
-struct PairParams {
-    const GemmParams* g;   // [2] in device memory (a kernarg array indexed at run time would be copied to scratch)
-    int* queue;            // [8] task cursors + [8] = workgroups that have left: the last one out zeroes the cursors for the next launch
-    int* done;             // [tiles_m] stage-0 tiles finished per row-panel, one counter per 128-byte line (640 pollers on two lines
-                           // slowed every tile 3x); zeroed by the last workgroup out, like the cursors
-    int tiles_m, tiles_n0, tiles_n1;
-    FastDiv fd0, fd1;      // / tiles_n0, / tiles_n1
-    unsigned long long* trace;   // nullable: per workgroup [wait cycles, tasks, first task start, last task end]
-};
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF, bool RPRE, bool TRACE, int OCC>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, OCC) void gemm_pair_kernel(PairParams q) {
-    __shared__ int task_s;
-    const int tid = threadIdx.x;
-    const int xcc = __builtin_amdgcn_readfirstlane(int(__builtin_amdgcn_s_getreg((31 << 11) | 20)) & 7);
-    const int npan = (q.tiles_m - xcc + 7) >> 3;          // row-panels xcc, xcc + 8, ...
-    const int n0 = npan * q.tiles_n0, n1 = npan * q.tiles_n1;
-    const FastDiv fd0 = q.fd0, fd1 = q.fd1;
-    const int want = q.tiles_n0;
-    unsigned long long waited = 0, t_first = 0, t_last = 0;
-    int ntask = 0;
-    // Loop shape (matters): ONE single-thread region per iteration, between two workgroup barriers, and nothing divergent next to
-    // the back edge.  With the panel counter's increment as a second `if (tid == 0)` at the END of the body hipcc merged it with the
-    // next iteration's task fetch across the back edge and let the other lanes run ahead into the next barrier -- wave 0 then
-    // arrives at that s_barrier twice per iteration and the workgroup hangs.
-    int finished_tm = -1;   // stage-0 tile whose stores the closing barrier of the last iteration has seen complete
-    for (;;) {
-        if (tid == 0) {
-            if (finished_tm >= 0) __hip_atomic_fetch_add(q.done + finished_tm * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            task_s = __hip_atomic_fetch_add(q.queue + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        const int task = __builtin_amdgcn_readfirstlane(task_s);
-        if (task >= n0 + n1) break;
-        const int stage = task >= n0 ? 1 : 0;
-        const int t = stage ? task - n0 : task;
-        const int tn_per = stage ? q.tiles_n1 : q.tiles_n0;
-        const int pl = fdiv(t, stage ? fd1 : fd0);
-        const int tn = t - pl * tn_per, tm = pl * 8 + xcc;
-        if (stage) {
-            if (tid == 0) {
-                const unsigned long long c0 = TRACE ? __builtin_readcyclecounter() : 0ull;
-                // (bounded: a broken hand-off must show up as a wrong result in the experiment's check, not as a hung GPU)
-                for (int spin = 0; spin < (1 << 16) && __hip_atomic_load(q.done + tm * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spin)
-                    __builtin_amdgcn_s_sleep(PAIR_POLL_SLEEP);
-                if constexpr (TRACE) waited += __builtin_readcyclecounter() - c0;
-            }
-            __syncthreads();
-            asm volatile("buffer_inv sc0" ::: "memory");   // L1 only (H lines this CU may hold from an earlier launch / layer); producer and consumer share the L2
-        }
-        if constexpr (TRACE) { if (tid == 0 && ntask == 0) t_first = wall_clock64(); }
-        const GemmParams& gp = q.g[stage];
-        gemm_body<BM, BN, BK, WAVES_M, WAVES_N, false, MF, RPRE, true, 0, true>(gp, tn_per, tn_per, q.tiles_m, 0, fd0, stage ? fd1 : fd0, tm, tn);
-        finished_tm = stage ? -1 : tm;
-        if constexpr (TRACE) {
-            ++ntask;
-            if (tid == 0) t_last = wall_clock64();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's stores are in the L2 ...
-        __syncthreads();                                    // ... everyone's are; and the next tile's staging may overwrite the LDS
-    }
-    if constexpr (TRACE) {
-        if (tid == 0) {
-            unsigned long long* tr = q.trace + size_t(blockIdx.x) * 4;
-            tr[0] = waited; tr[1] = unsigned(ntask); tr[2] = t_first; tr[3] = t_last;
-        }
-    }
-    // last workgroup out: every cursor and counter has been read for the last time -- zero them for the next launch
-    if (tid == 0) task_s = __hip_atomic_fetch_add(q.queue + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (task_s == int(gridDim.x) - 1) {
-        for (int i = tid; i < q.tiles_m; i += int(blockDim.x)) __hip_atomic_store(q.done + i * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < 9) __hip_atomic_store(q.queue + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// scratch (device, 256-byte aligned, zeroed ONCE by the caller): [0, 1024) two GemmParams, [1024, 1088) cursors, [2048, ...) panel counters
-extern "C" __attribute__((visibility("default"))) int lamp_debug_ffn_pair_prepare(
-    const float* x, long long M, int d, const float* w1, const float* b1, int dff, const float* w2, const float* b2, const float* r,
-    float* H, float* Y, void* scratch, void* stream) {
-    static_assert(2 * sizeof(GemmParams) <= 1024, "scratch layout");
-    GemmParams g[2] = {};
-    g[0].A = x; g[0].lda = d; g[0].M = M; g[0].K = d; g[0].N = dff; g[0].nseg = 1; g[0].W[0] = w1; g[0].ldw = d; g[0].bias[0] = b1;
-    g[0].C[0] = H; g[0].ldc = dff; g[0].relu = 1; g[0].vec_epilogue = 1;
-    g[1].A = H; g[1].lda = dff; g[1].M = M; g[1].K = dff; g[1].N = d; g[1].nseg = 1; g[1].W[0] = w2; g[1].ldw = dff; g[1].bias[0] = b2;
-    g[1].C[0] = Y; g[1].ldc = d; g[1].R = r; g[1].ldr = d; g[1].vec_epilogue = 1;
-    if (int e = int(hipMemsetAsync(scratch, 0, 2048 + 128 * size_t((M + 31) / 32), hipStream_t(stream)))) return e;
-    if (int e = int(hipMemcpyAsync(scratch, g, sizeof g, hipMemcpyHostToDevice, hipStream_t(stream)))) return e;
-    return int(hipStreamSynchronize(hipStream_t(stream)));
-}
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int OCC>
-static int launch_pair(long long M, int d, int dff, void* scratch, int wg_per_cu, unsigned long long* trace, hipStream_t s) {
-    using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, 16>;
-    constexpr bool RPRE = T::MI * T::NI * 4 <= 16;
-    auto kern = trace ? gemm_pair_kernel<BM, BN, BK, WAVES_M, WAVES_N, 16, RPRE, true, OCC> : gemm_pair_kernel<BM, BN, BK, WAVES_M, WAVES_N, 16, RPRE, false, OCC>;
-    static AttrOnce once, once_t;
-    if (int e = (trace ? once_t : once).set(reinterpret_cast<const void*>(kern), T::LDS_BYTES)) return e;
-    PairParams q{};
-    q.g = reinterpret_cast<const GemmParams*>(scratch);
-    q.queue = reinterpret_cast<int*>(static_cast<char*>(scratch) + 1024);
-    q.done = reinterpret_cast<int*>(static_cast<char*>(scratch) + 2048);
-    q.tiles_m = int((M + BM - 1) / BM);
-    q.tiles_n0 = (dff + BN - 1) / BN;
-    q.tiles_n1 = (d + BN - 1) / BN;
-    q.fd0 = make_fastdiv(unsigned(q.tiles_n0));
-    q.fd1 = make_fastdiv(unsigned(q.tiles_n1));
-    q.trace = trace;
-    hipLaunchKernelGGL(kern, dim3(unsigned(256 * wg_per_cu)), dim3(T::NT), T::LDS_BYTES, s, q);
-    return int(hipGetLastError());
-}
-// tile: 0 = 64x64x16 (the encoder FFN's tile; 5 waves per SIMD, a few spilled dwords), 3 = the same at 4 waves, 1 = 32x64x32, 2 = 128x64x16.  K must be a multiple of the tile's BK, N of 4.
-extern "C" __attribute__((visibility("default"))) int lamp_debug_ffn_pair_launch(long long M, int d, int dff, void* scratch, int tile,
-                                                                              int wg_per_cu, unsigned long long* trace, void* stream) {
-    hipStream_t s = hipStream_t(stream);
-    if ((d % 32) || (dff % 32)) return LAMP_E_UNSUPPORTED;
-    switch (tile) {
-        case 0: return launch_pair<64, 64, 16, 2, 2, 5>(M, d, dff, scratch, wg_per_cu, trace, s);
-        case 1: return launch_pair<32, 64, 32, 1, 4, 4>(M, d, dff, scratch, wg_per_cu, trace, s);
-        case 2: return launch_pair<128, 64, 16, 2, 2, 3>(M, d, dff, scratch, wg_per_cu, trace, s);
-        case 3: return launch_pair<64, 64, 16, 2, 2, 4>(M, d, dff, scratch, wg_per_cu, trace, s);
-    }
-    return LAMP_E_UNSUPPORTED;
-}
-#endif
 
 #ifdef LAMP_TUNING
 static int g_force_walk = -1;   // -1 = heuristic; 0 = row-panel groups; n > 0 = W-resident walk with n column panels per group
@@ -795,12 +453,12 @@ static size_t g_extra_lds = 0;
 extern "C" __attribute__((visibility("default"))) void lamp_debug_set_gemm_extra_lds(int bytes) { g_extra_lds = size_t(bytes); }
 #endif
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool VEC, int DMA>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool VEC>
 static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
     constexpr bool RPRE = T::MI * T::NI * (MF == 32 ? 16 : 4) <= 16;
-    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC, DMA>;
-    size_t LDS = (DMA == 1 || DMA == 2) ? T::DMA_STAGE_BYTES * (DMA == 1 ? 2 : 3) : T::LDS_BYTES;
+    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC>;
+    size_t LDS = T::LDS_BYTES;
     static AttrOnce once;
 #ifdef LAMP_TUNING
     LDS += g_extra_lds;   // residency experiments: more LDS per workgroup = fewer workgroups per CU
@@ -841,24 +499,21 @@ static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     return int(hipGetLastError());
 }
 
-// DMA: direct-to-LDS staging; a K that is not a multiple of BK (columns past K must read as zeros, which only the
-// register path's per-element offsets can arrange) takes the register-staged kernel of the same tile -- same bits.
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF = 32, int DMA = 0>
+// a K that is not a multiple of BK takes the KTAIL instantiation (columns past K read as zeros): same bits
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF = 32>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
     if (p.vec_epilogue) {
-        if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF, true, 0>(p, s);
-        return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF, true, DMA>(p, s);
+        if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF, true>(p, s);
+        return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF, true>(p, s);
     }
-    if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF, false, 0>(p, s);
-    return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF, false, DMA>(p, s);
+    if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF, false>(p, s);
+    return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF, false>(p, s);
 }
 
 #ifdef LAMP_TUNING
 // Tuning build only (liblamp_hip_tuning.so: tools/bench_kernels.py and the every-variant tests): force a tile
 // configuration (0 = heuristic) and collect a per-workgroup timeline.  The production library has neither.
 static int g_force_tile = 0;
-static const float* g_gemm_wp = nullptr;   // packed copy of the NEXT launches' weight matrix (single segment), for the W-direct tiles
-extern "C" __attribute__((visibility("default"))) void lamp_debug_gemm_packed_w(const float* wp) { g_gemm_wp = wp; }
 static unsigned long long* g_gemm_trace = nullptr;  // n_slabs slabs of slab_words u64: launch i records into slab i % n_slabs,
 static long long g_trace_slab = 0;                  // 8 words per workgroup (entry, loop start, loop end, exit: wall_clock64
 static int g_trace_slabs = 0, g_trace_count = 0;    // ticks; HW_ID; XCC_ID; work item; main loop in shader cycles)
@@ -891,7 +546,6 @@ int launch_gemm(const GemmParams& p_in, hipStream_t s) {
     for (int i = 0; i < p.nseg; ++i) vec = vec && aligned16(p.C[i]) && (!p.bias[i] || aligned16(p.bias[i]));
     p.vec_epilogue = vec ? 1 : 0;
 #ifdef LAMP_TUNING
-    if (g_gemm_wp && p.nseg == 1 && p.N % 16 == 0 && p.K % 32 == 0) p.Wp[0] = g_gemm_wp;
     if (g_gemm_trace && g_trace_slabs > 0) {
         // upper bound of the grid over the tile menu: 32x64 tiles
         const long long wg_max = ((p.M + 31) / 32) * ((p.N + 63) / 64) * p.nseg;
@@ -917,31 +571,6 @@ int launch_gemm(const GemmParams& p_in, hipStream_t s) {
         case 16: return launch_cfg<128, 64, 32, 2, 2, 16>(p, s);
         case 17: return launch_cfg<64, 128, 32, 2, 2, 16>(p, s);
         case 18: return launch_cfg<128, 64, 16, 2, 2, 16>(p, s);
-        // direct-to-LDS staging: 20-29 inline-asm reads + counted vmcnt (DMA = 2), 40-49 the same tiles with compiler-scheduled reads (DMA = 1)
-        case 20: return launch_cfg<32, 64, 32, 1, 4, 16, 2>(p, s);
-        case 21: return launch_cfg<64, 64, 16, 2, 2, 16, 2>(p, s);
-        case 22: return launch_cfg<64, 64, 32, 2, 2, 16, 2>(p, s);
-        case 23: return launch_cfg<128, 64, 16, 2, 2, 16, 2>(p, s);
-        case 24: return launch_cfg<128, 64, 32, 2, 2, 16, 2>(p, s);
-        case 25: return launch_cfg<128, 128, 16, 2, 2, 16, 2>(p, s);
-        case 26: return launch_cfg<128, 128, 32, 2, 2, 16, 2>(p, s);
-        case 27: return launch_cfg<128, 128, 32, 2, 2, 32, 2>(p, s);
-        case 28: return launch_cfg<32, 64, 64, 1, 4, 16, 2>(p, s);
-        case 29: return launch_cfg<64, 64, 64, 2, 2, 16, 2>(p, s);
-        case 30: return launch_cfg<64, 64, 16, 2, 2, 16, 3>(p, s);     // W fragments straight from global memory
-        case 31: return launch_cfg<64, 64, 32, 2, 2, 16, 3>(p, s);
-        case 32: return launch_cfg<32, 64, 32, 1, 4, 16, 3>(p, s);
-        case 33: return launch_cfg<128, 64, 16, 2, 2, 16, 3>(p, s);
-        case 40: return launch_cfg<32, 64, 32, 1, 4, 16, 1>(p, s);
-        case 41: return launch_cfg<64, 64, 16, 2, 2, 16, 1>(p, s);
-        case 42: return launch_cfg<64, 64, 32, 2, 2, 16, 1>(p, s);
-        case 43: return launch_cfg<128, 64, 16, 2, 2, 16, 1>(p, s);
-        case 44: return launch_cfg<128, 64, 32, 2, 2, 16, 1>(p, s);
-        case 45: return launch_cfg<128, 128, 16, 2, 2, 16, 1>(p, s);
-        case 46: return launch_cfg<128, 128, 32, 2, 2, 16, 1>(p, s);
-        case 47: return launch_cfg<128, 128, 32, 2, 2, 32, 1>(p, s);
-        case 48: return launch_cfg<32, 64, 64, 1, 4, 16, 1>(p, s);
-        case 49: return launch_cfg<64, 64, 64, 2, 2, 16, 1>(p, s);
         default: break;
     }
 #endif

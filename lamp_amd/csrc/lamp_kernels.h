@@ -24,8 +24,6 @@ struct GemmParams {
     int N;  // per segment
     int nseg;
     const float* W[GEMM_MAX_SEG];
-    const float* Wp[GEMM_MAX_SEG];   // nullable: the same matrices in format 0 of lamp_pack_weight (gemm.hip: W fragments straight from
-                                     // the packed copy, no LDS pass for W; experiment, tuning build)
     int64_t ldw;
     const float* bias[GEMM_MAX_SEG];
     float* C[GEMM_MAX_SEG];

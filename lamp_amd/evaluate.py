@@ -32,7 +32,7 @@ from .data import get_gold_binary
 class _Stage(object):
     """`prefetch` consecutive batches, ready to upload: ids = every batch's tokens then positions (int64, pinned), gold = their
     target rows (float32, pinned), items = (batch index, first row, rows, T, offset into ids, first gold row, adj)."""
-    __slots__ = ('ids', 'gold', 'items', 'device_batches', 'slot')
+    __slots__ = ('ids', 'gold', 'items', 'device_batches', 'slot', 'merged')
 
 
 class _Slot(object):
@@ -66,7 +66,7 @@ def _hand_over(out_q, item, stop):
     return False
 
 
-def _produce(it, n_labels, batch_size, prefetch, all_targets, out_q, pin, device, stop):
+def _produce(it, n_labels, batch_size, prefetch, all_targets, out_q, pin, device, stop, merge=False):
     """Producer thread: the host side of utils/data_loader.py:242-312 + utils/utils.py:205-216 for stage after stage."""
     try:
         if pin:
@@ -82,9 +82,10 @@ def _produce(it, n_labels, batch_size, prefetch, all_targets, out_q, pin, device
             if not host:
                 break
             st = _Stage()
-            st.items, st.device_batches = [], None
+            st.items, st.device_batches, st.merged = [], None, None
             golds, total_ids, row = [], 0, 0
             on_device = all(b[1][0][0].is_cuda for b in host)
+            merged = merge and not on_device and len(host) > 1 and all(b[1][1] is None for b in host)
             for bi, ((src_seq, src_pos), adj, tgt) in host:
                 real = src_seq.size(0)
                 gold = get_gold_binary(tgt[:, 1:], n_labels)
@@ -96,11 +97,23 @@ def _produce(it, n_labels, batch_size, prefetch, all_targets, out_q, pin, device
                 row += real
             st.slot = ring[n_stage % len(ring)]
             n_stage += 1
+            if merged:   # ONE token / position matrix for the whole stage, padded to its longest batch
+                t_max = max(item[3] for item in st.items)
+                total_ids = 2 * row * t_max
+                st.merged = (row, t_max)
             st.ids, st.gold = st.slot.take(0 if on_device else total_ids, row, n_labels, pin)
             torch.cat(golds, out=st.gold)
             if on_device:    # the batcher already put the tokens on the device (EvalBatcher(device=...))
                 st.ids = None
                 st.device_batches = [(b[1][0][0], b[1][0][1]) for b in host]
+            elif merged:
+                seq_m = st.ids.numpy()[:row * t_max].reshape(row, t_max)
+                pos_m = st.ids.numpy()[row * t_max:].reshape(row, t_max)
+                seq_m[:] = 0
+                pos_m[:] = 0
+                for (bi, lo, real, T, off, r0, _), (_, ((src_seq, src_pos), _, _)) in zip(st.items, host):
+                    seq_m[r0:r0 + real, :T] = src_seq.numpy()
+                    pos_m[r0:r0 + real, :T] = src_pos.numpy()
             else:
                 flat = st.ids.numpy()
                 for (bi, lo, real, T, off, _, _), (_, ((src_seq, src_pos), _, _)) in zip(st.items, host):
@@ -115,7 +128,7 @@ def _produce(it, n_labels, batch_size, prefetch, all_targets, out_q, pin, device
 
 
 def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True, int_preds=False, streams=1,
-               prefetch=8, world_size=1, rank=0, group=None, timeline=None):
+               prefetch=8, world_size=1, rank=0, group=None, timeline=None, merge_stage=False):
     """-> (all_predictions (n, L) cpu, all_targets (n, L) cpu, bce_total float), as test.py:16-78 returns
     them.  `batches` yields ((src_seq, src_pos), adj, tgt) like lamp_amd.data.EvalBatcher.
 
@@ -128,7 +141,12 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
     `prefetch` = batches per stage (module docstring): the first forward is issued after ONE stage has been padded, and
     at most two further stages wait in the producer's queue.  `timeline` (a dict, optional) receives host timestamps in
     seconds from the call's start: 'issued' = the last batch was enqueued, 'done' = the device finished
-    (tools/bench_eval_epoch.py: issued ~ done means the issuing thread, not the GPU, bounds the epoch)."""
+    (tools/bench_eval_epoch.py: issued ~ done means the issuing thread, not the GPU, bounds the epoch).
+
+    `merge_stage=True`: the `prefetch` batches of a stage go through the model as ONE forward, padded to the stage's longest
+    batch (no all-PAD filler rows).  A sample's outputs do not depend on the batch it travels in nor on the padded length, bit
+    for bit (DESIGN.md 3b), so predictions, targets and the per-batch mean losses are the ones of the batch-by-batch loop;
+    the issuing thread makes one call per stage instead of one per batch and the kernels see `prefetch` times the rows."""
     import time
     t_start = time.perf_counter()
     model.eval()
@@ -150,7 +168,7 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
         lane.wait_stream(main)    # the buffers (and the model's weights) are ready on every lane
     stages, stop = queue.Queue(maxsize=2), threading.Event()
     producer = threading.Thread(target=_produce, name='lamp-eval-producer', daemon=True,
-                                args=(it, n_labels, batch_size, max(int(prefetch), 1), all_targets, stages, pin, device, stop))
+                                args=(it, n_labels, batch_size, max(int(prefetch), 1), all_targets, stages, pin, device, stop, bool(merge_stage)))
     producer.start()
     try:
         _issue(model, stages, lanes, device, batch_size, pad_last_batch, int_preds, probs_d, row_loss_d, r_lo)
@@ -193,6 +211,16 @@ def _issue(model, stages, lanes, device, batch_size, pad_last_batch, int_preds, 
             gold_d = st.gold.to(device, non_blocking=True)
             uploaded = lanes[0].record_event()
         st.slot.uploaded = uploaded      # the producer may refill this slot's pinned buffers once these copies have run
+        if st.merged is not None:
+            rows, t_max = st.merged
+            lo0 = st.items[0][1]
+            with (torch.cuda.stream(lanes[0]) if len(lanes) > 1 else _SAME_STREAM):
+                src_seq = ids_d[:rows * t_max].view(rows, t_max)
+                src_pos = ids_d[rows * t_max:2 * rows * t_max].view(rows, t_max)
+                pred = model((src_seq, src_pos), None, None, None, int_preds=int_preds)[0]
+                N.sigmoid_bce(pred, gold_d, probs_out=probs_d[lo0 - r_lo:lo0 - r_lo + rows],
+                              row_loss_out=row_loss_d[lo0 - r_lo:lo0 - r_lo + rows])
+            continue
         for k, (bi, lo, real, T, off, row, adj) in enumerate(st.items):
             lane = lanes[bi % len(lanes)]
             if lane is not lanes[0]:

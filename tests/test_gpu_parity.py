@@ -53,14 +53,10 @@ def test_linear_vs_torch_fp64(dev, M, K, N_):
     assert max_abs_diff(N.linear(x.to(dev), w.to(dev)), ref2) < 2e-5
 
 
-GEMM_DMA_CFGS = list(range(20, 34)) + list(range(40, 50))   # direct-to-LDS staging: inline-asm reads / compiler reads;
-                                                             # 30-33: W fragments straight from global memory
-
-
-@pytest.mark.parametrize('cfg', list(range(1, 19)) + GEMM_DMA_CFGS)
+@pytest.mark.parametrize('cfg', list(range(1, 19)))
 def test_linear_every_tile_config(dev, tuning, cfg):
-    """Every GEMM tile configuration (32x32x2 and 16x16x4 MFMA variants, register-staged and direct-to-LDS) against
-    fp64, on shapes with ragged M / N edges and a K that is not a multiple of BK (tuning build of the library)."""
+    """Every GEMM tile configuration of the tuning build (32x32x2 and 16x16x4 MFMA variants) against fp64, on shapes with
+    ragged M / N edges and a K that is not a multiple of BK."""
     from lamp_amd import _native as N
     force = tuning.lamp_debug_force_gemm_tile
     try:
@@ -76,68 +72,6 @@ def test_linear_every_tile_config(dev, tuning, cfg):
             assert max_abs_diff(out, ref) < 2e-5, (cfg, M, K, N_)
     finally:
         force(0)
-
-
-@pytest.mark.parametrize('cfg', GEMM_DMA_CFGS)
-def test_linear_direct_to_lds_staging_is_bit_identical(dev, tuning, cfg):
-    """The direct-to-LDS (LDS-DMA) staging of gemm.hip moves the same values into the same MFMA fragments: results must
-    equal the register-staged kernel bit for bit (every 16x16x4 tile shares one k-order; config 27 is the 32x32x2 tile
-    of config 1).  Shapes: ragged M and N edges, several K steps, one K step, rows past M inside the last row panel."""
-    from lamp_amd import _native as N
-    force = tuning.lamp_debug_force_gemm_tile
-    ref_cfg = 1 if cfg % 20 == 7 else 9
-    try:
-        for M, K, N_ in ((300, 512, 200), (2880, 512, 512), (97, 64, 1536), (1000, 1024, 130), (5, 2048, 64)):
-            g = torch.Generator().manual_seed(cfg * 1000 + M)
-            x = torch.randn(M, K, generator=g).to(dev)
-            w = (torch.randn(N_, K, generator=g) / K ** 0.5).to(dev)
-            b = torch.randn(N_, generator=g).to(dev)
-            r = torch.randn(M, N_, generator=g).to(dev)
-            force(ref_cfg)
-            want = N.linear(x, w, b, residual=r, relu=True, _lib=tuning)
-            force(cfg)
-            for _ in range(3):   # a race between the DMA queue and the fragment reads would not repeat
-                got = N.linear(x, w, b, residual=r, relu=True, _lib=tuning)
-                assert torch.equal(got, want), (cfg, M, K, N_)
-    finally:
-        force(0)
-
-
-@pytest.mark.parametrize('tile,wg', [(0, 5), (3, 4), (1, 4), (2, 3)])
-def test_ffn_pair_in_one_persistent_launch_is_bit_identical(dev, tuning, tile, wg):
-    """Experiment kept in the tuning build (gemm.hip: gemm_pair_kernel, profiles/r04_rejected_experiments.txt #11): two
-    dependent GEMMs -- the FFN pair before its LayerNorm -- in one persistent launch with per-row-panel counters run the same
-    tile program as two launches, so H and Y must come out bit for bit; repeated launches reuse the counters (the last
-    workgroup out resets them)."""
-    import ctypes
-    from lamp_amd import _native as N
-    prep, launch = tuning.lamp_debug_ffn_pair_prepare, tuning.lamp_debug_ffn_pair_launch
-    prep.restype = launch.restype = ctypes.c_int
-    prep.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                     ctypes.c_void_p]
-    launch.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                       ctypes.c_void_p, ctypes.c_void_p]
-    for M, d, dff in ((2880, 512, 512), (1000, 256, 1024), (70, 512, 256)):
-        g = torch.Generator().manual_seed(M + tile)
-        x = torch.randn(M, d, generator=g).to(dev)
-        w1 = (torch.randn(dff, d, generator=g) / d ** 0.5).to(dev)
-        b1 = torch.randn(dff, generator=g).to(dev)
-        w2 = (torch.randn(d, dff, generator=g) / dff ** 0.5).to(dev)
-        b2 = torch.randn(d, generator=g).to(dev)
-        h_want = N.linear(x, w1, b1, relu=True, _lib=tuning)
-        y_want = N.linear(h_want, w2, b2, residual=x, _lib=tuning)
-        h, y = torch.empty_like(h_want), torch.empty_like(y_want)
-        scratch = torch.zeros(4096 + 32 * ((M + 31) // 32) + 64, dtype=torch.int32, device=dev)
-        N.check(prep(x.data_ptr(), M, d, w1.data_ptr(), b1.data_ptr(), dff, w2.data_ptr(), b2.data_ptr(), x.data_ptr(),
-                     h.data_ptr(), y.data_ptr(), scratch.data_ptr(), N.stream()), 'pair prepare')
-        for _ in range(3):
-            h.zero_()
-            y.zero_()
-            N.check(launch(M, d, dff, scratch.data_ptr(), tile, wg, None, N.stream()), 'pair launch')
-            torch.cuda.synchronize()
-            assert torch.equal(h, h_want) and torch.equal(y, y_want), (tile, M, d, dff)
-        assert int(scratch[256:265].abs().sum()) == 0   # cursors back at zero
 
 
 def test_linear_detects_transposed_or_shifted_tiles(dev):

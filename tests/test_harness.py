@@ -94,6 +94,24 @@ def test_eval_producer_stages_hold_exactly_the_batches(fx):
                 assert torch.equal(st.gold[row:row + real], D.get_gold_binary(tgt[:, 1:], L))
                 seen += 1
         assert seen == len(b) and torch.equal(targets, d['targets'])
+    # merged stages: ONE (rows, longest T) token matrix and one position matrix per stage, zero-padded
+    q, stop = queue.Queue(), threading.Event()
+    E._produce(zip(range(len(b)), iter(b)), L, bs, 3, torch.zeros(b.n_insts, L), q, False, torch.device('cpu'), stop, True)
+    while True:
+        st = q.get_nowait()
+        if st is None:
+            break
+        if len(st.items) == 1:
+            assert st.merged is None
+            continue
+        rows, t_max = st.merged
+        assert rows == sum(i[2] for i in st.items) and t_max == max(i[3] for i in st.items)
+        seq_m = st.ids[:rows * t_max].view(rows, t_max)
+        pos_m = st.ids[rows * t_max:].view(rows, t_max)
+        for bi, lo, real, T, off, r0, adj in st.items:
+            (seq, pos), _, _ = want[bi]
+            assert torch.equal(seq_m[r0:r0 + real, :T], seq) and torch.equal(pos_m[r0:r0 + real, :T], pos)
+            assert not seq_m[r0:r0 + real, T:].any() and not pos_m[r0:r0 + real, T:].any()
     # an exception inside the producer reaches the consumer instead of hanging it
     q, stop = queue.Queue(), threading.Event()
     E._produce(iter([(0, ((torch.zeros(2, 3, dtype=torch.long),) * 2, None, None))]), L, bs, 2, targets, q, False,
@@ -127,6 +145,10 @@ def test_test_epoch_matches_reference(fx):
     # two batches in flight on two HIP streams: same numbers
     preds3, targets3, bce3 = test_epoch(m, batches, L, d['batch_size'], dev, streams=2)
     assert torch.equal(preds3, preds) and torch.equal(targets3, targets) and abs(bce3 - bce) < 1e-7
+    # stages of several batches as ONE forward (padded to the stage's longest batch), small stages too: same numbers
+    for prefetch in (2, 8):
+        preds4, targets4, bce4 = test_epoch(m, batches, L, d['batch_size'], dev, prefetch=prefetch, merge_stage=True)
+        assert torch.equal(preds4, preds) and torch.equal(targets4, targets) and abs(bce4 - bce) < 1e-7
 
 
 @pytest.mark.gpu

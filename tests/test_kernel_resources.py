@@ -126,7 +126,7 @@ _ZN4lamp16slab_gemm_kernelILi10EEEvNS_10SlabParamsE:
 
 
 @pytest.mark.parametrize('unit,flags,n_kernels,n_loads', [('chain.hip', (), 12, 500), ('chain.hip', ('-DLAMP_TUNING',), 12, 500),
-                                                          ('slab.hip', ('-DLAMP_TUNING',), 1, 500), ('attention_tile.hip', (), 2, 3)])
+                                                          ('experiments/slab.hip', ('-DLAMP_TUNING',), 1, 500), ('attention_tile.hip', (), 2, 3)])
 def test_no_instruction_touches_an_inline_assembly_load_before_a_wait(unit, flags, n_kernels, n_loads):
     """... nor does one overwrite a register in flight, nor does an inline-assembly memory instruction read a scalar the vector
     unit wrote fewer than five wait states earlier (tools/check_untracked_loads.py: the three rules)."""

@@ -38,8 +38,9 @@ def main():
     m = m.to(dev).eval()
     out = {'documents': n_docs, 'batch': bs, 'mean_length': sum(lengths) / n_docs + 2}
     prefetch = int(os.environ.get('LAMP_EVAL_PREFETCH', '8'))
+    ref = None
     out['prefetch'] = prefetch
-    for streams in (1, 2, 4):
+    for streams, merge in ((1, False), (2, False), (4, False), (1, True)):
         rates, rates_all, lines = [], [], []
         for rep in range(6):   # first repetition warms the allocator and the clocks
             torch.cuda.synchronize()
@@ -47,7 +48,10 @@ def main():
             batches = D.EvalBatcher(src, tgt, bs)      # flattens the split once (the reference's DataLoader.__init__)
             t0 = time.perf_counter()
             tl = {}
-            preds, targets, bce = test_epoch(m, batches, L, bs, dev, streams=streams, prefetch=prefetch, timeline=tl)
+            preds, targets, bce = test_epoch(m, batches, L, bs, dev, streams=streams, prefetch=prefetch, timeline=tl, merge_stage=merge)
+            if ref is None:
+                ref = (preds, bce)
+            assert torch.equal(preds, ref[0]) and abs(bce - ref[1]) < 1e-9      # every mode: the same numbers
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             if rep:
@@ -57,12 +61,15 @@ def main():
         assert preds.shape == (n_docs, L) and not torch.isnan(preds).any()
         rates.sort()
         rates_all.sort()
-        out['streams_%d' % streams] = rates[len(rates) // 2]                 # median of five
-        out['streams_%d_best' % streams] = rates[-1]
-        out['streams_%d_including_batcher_construction' % streams] = rates_all[len(rates_all) // 2]
-        out['streams_%d_repetitions' % streams] = lines
+        key = 'streams_%d' % streams + ('_merged_stages' if merge else '')
+        out[key] = rates[len(rates) // 2]                 # median of five
+        out[key + '_best'] = rates[-1]
+        out[key + '_including_batcher_construction'] = rates_all[len(rates_all) // 2]
+        out[key + '_repetitions'] = lines
     out['note'] = ('documents / wall time of one test_epoch call (padding, upload, forward, sigmoid + BCE, copy back); the second '
-                   'figure also counts EvalBatcher.__init__, which flattens the split once')
+                   'figure also counts EvalBatcher.__init__, which flattens the split once; _merged_stages: the %d batches of a stage '
+                   'as ONE forward padded to the longest (evaluate.test_epoch(merge_stage=True): same predictions, targets and '
+                   'losses bit for bit -- checked in this run -- one host call per stage)' % prefetch)
     print(json.dumps(out))
 
 

@@ -20,14 +20,6 @@ TILES = {0: 'heuristic', 1: '128x128x32', 2: '64x64x32', 3: '128x64x32', 4: '64x
          6: '64x64x16', 7: '128x64x16', 8: '256x128x16(8w)', 9: 'm16:32x64x32',
          10: 'm16:64x32x32', 11: 'm16:64x64x16', 12: 'm16:64x64x32', 13: 'm16:32x128x32',
          14: 'm16:128x128x32', 15: 'm16:128x128x16', 16: 'm16:128x64x32', 17: 'm16:64x128x32', 18: 'm16:128x64x16'}
-_DMA = {0: 'm16:32x64x32', 1: 'm16:64x64x16', 2: 'm16:64x64x32', 3: 'm16:128x64x16', 4: 'm16:128x64x32', 5: 'm16:128x128x16',
-        6: 'm16:128x128x32', 7: '128x128x32', 8: 'm16:32x64x64', 9: 'm16:64x64x64'}
-for _i, _n in _DMA.items():   # direct-to-LDS staging: 20-29 inline-asm reads + counted vmcnt, 40-49 compiler-scheduled reads
-    TILES[20 + _i] = 'A:' + _n.replace('m16:', '')
-    TILES[40 + _i] = 'C:' + _n.replace('m16:', '')
-# W fragments straight from global memory (no LDS pass for W), A staged as ever
-TILES.update({30: 'W:64x64x16', 31: 'W:64x64x32', 32: 'W:32x64x32', 33: 'W:128x64x16'})
-
 
 def time_fn(fn, iters=30, warm=5):
     for _ in range(warm):
@@ -480,43 +472,6 @@ def chain():
                                                            cyc(g[:, 3] - g[:, 0]), q(g[:, 3] - g[:, 0], 0.5) / ghz / 1e3, ghz))
 
 
-def gemm_packed():
-    """W fragments straight from a PACKED weight copy in the tile GEMM (gemm.hip DMA = 3 with GemmParams::Wp): the W-direct tiles
-    30-33 with and without the pack against the production tiles, bit identity and round-robin medians on the token-row shapes."""
-    import statistics
-    lib = N.lib()
-    force = lib.lamp_debug_force_gemm_tile
-    force.argtypes = [ctypes.c_int]; force.restype = None
-    setwp = lib.lamp_debug_gemm_packed_w
-    setwp.argtypes = [ctypes.c_void_p]; setwp.restype = None
-    dev = torch.device('cuda:0')
-    shapes = [('encFFN 9664x512x512', 9664, 512, 512), ('encKV 9664x2048x512', 9664, 2048, 512), ('dec 2880x512x512', 2880, 512, 512),
-              ('decQKV 2880x1536x512', 2880, 1536, 512), ('delic ffn1 31456x2048x1024', 31456, 2048, 1024)]
-    cfgs = [(0, False), (11, False), (12, False), (18, False), (9, False), (30, False), (30, True), (31, True), (33, True), (32, True)]
-    print('%-28s' % 'shape (median us)' + ''.join('%14s' % (TILES[c] + ('+pk' if pk else '')) for c, pk in cfgs))
-    for name, M, Nn, K in shapes:
-        x = torch.randn(M, K, device=dev)
-        w = torch.randn(Nn, K, device=dev) / K ** 0.5
-        wp = N.weight_pack(w, 0)
-        b = torch.randn(Nn, device=dev)
-        r = torch.randn(M, Nn, device=dev)
-        out = torch.empty(M, Nn, device=dev)
-
-        def fn():
-            N.check(lib.lamp_linear_fwd(x.data_ptr(), M, K, K, w.data_ptr(), Nn, K, b.data_ptr(), r.data_ptr(), Nn, 1, out.data_ptr(), Nn, N.stream()), 'linear')
-        force(0); setwp(None); fn(); want = out.clone()
-        samples = {c: [] for c in cfgs}
-        same = {}
-        for rnd in range(5):
-            for c in cfgs:
-                force(c[0]); setwp(wp.data_ptr() if c[1] else None)
-                if rnd == 0:
-                    out.zero_(); fn(); torch.cuda.synchronize(); same[c] = torch.equal(out, want)
-                samples[c].append(time_fn(fn, iters=5 if M * Nn * K > 1e11 else 20, warm=2))
-        force(0); setwp(None)
-        print('%-28s' % name + ''.join('%8.1f%s/%4.0f' % (statistics.median(samples[c]), ' ' if same[c] else '!', 2.0 * M * Nn * K / statistics.median(samples[c]) / 1e6) for c in cfgs))
-
-
 def slab():
     """The slab kernel (slab.hip: one slab of rows per CU, packed weights, 4x4x1 MFMA) against the tile kernel on the token-row GEMMs:
     bit identity and round-robin median times.  argv[2:]: row counts."""
@@ -919,91 +874,7 @@ def gemm_clock():
         force(0)
 
 
-def ffn_pair():
-    """EXPERIMENT: the encoder's FFN pair (two dependent GEMMs) as ONE persistent launch with per-row-panel counters
-    (gemm.hip: gemm_pair_kernel, tuning build) against the two launches it would replace: bit-identity, then round-robin
-    medians.  argv[2]: 'trace' adds the per-workgroup wait / task statistics of one traced launch."""
-    import statistics
-    lib = N.lib()
-    prep, launch = lib.lamp_debug_ffn_pair_prepare, lib.lamp_debug_ffn_pair_launch
-    prep.restype = launch.restype = ctypes.c_int
-    prep.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                     ctypes.c_void_p]
-    launch.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                       ctypes.c_void_p, ctypes.c_void_p]
-    force = lib.lamp_debug_force_gemm_tile
-    force.argtypes = [ctypes.c_int]
-    force.restype = None
-    dev = torch.device('cuda:0')
-    want_trace = len(sys.argv) > 2 and sys.argv[2] == 'trace'
-    print('%-26s %-34s %9s %9s' % ('shape (M x d x d_ff)', 'route', 'us', 'TFLOP/s'))
-    for name, M, d, dff in (('reuters enc', 9664, 512, 512), ('bibtex enc', 3200, 512, 1024), ('reuters dec', 2880, 512, 512),
-                            ('delicious enc', 1280, 1024, 2048)):
-        g = torch.Generator().manual_seed(M)
-        x = torch.randn(M, d, generator=g).to(dev)
-        w1 = (torch.randn(dff, d, generator=g) / d ** 0.5).to(dev)
-        b1 = torch.randn(dff, generator=g).to(dev)
-        w2 = (torch.randn(d, dff, generator=g) / dff ** 0.5).to(dev)
-        b2 = torch.randn(d, generator=g).to(dev)
-        Hs, Ys = torch.empty(M, dff, device=dev), torch.empty(M, d, device=dev)     # two launches
-        Hp, Yp = torch.empty(M, dff, device=dev), torch.empty(M, d, device=dev)     # one launch
-        scratch = torch.zeros(4096 + 32 * ((M + 31) // 32) + 64, dtype=torch.int32, device=dev)
-        N.check(prep(x.data_ptr(), M, d, w1.data_ptr(), b1.data_ptr(), dff, w2.data_ptr(), b2.data_ptr(), x.data_ptr(),
-                     Hp.data_ptr(), Yp.data_ptr(), scratch.data_ptr(), N.stream()), 'pair prepare')
-        flops = 4.0 * M * d * dff
-
-        def two(cfg):
-            def fn():
-                force(cfg)
-                N.check(lib.lamp_linear_fwd(x.data_ptr(), M, d, d, w1.data_ptr(), dff, d, b1.data_ptr(), None, dff, 1,
-                                            Hs.data_ptr(), dff, N.stream()), 'ffn1')
-                N.check(lib.lamp_linear_fwd(Hs.data_ptr(), M, dff, dff, w2.data_ptr(), d, dff, b2.data_ptr(), x.data_ptr(), d, 0,
-                                            Ys.data_ptr(), d, N.stream()), 'ffn2')
-            return fn
-
-        def one(tile, wg):
-            def fn():
-                N.check(launch(M, d, dff, scratch.data_ptr(), tile, wg, None, N.stream()), 'pair launch')
-            return fn
-        routes = [('two launches, heuristic', two(0)), ('two launches, 64x64x16', two(11)), ('two launches, 32x64x32', two(9)),
-                  ('one launch 64x64x16, 5 wg/CU', one(0, 5)), ('one launch 64x64x16, 4 wg/CU', one(3, 4)),
-                  ('one launch 64x64x16 (occ 5), 4 wg/CU', one(0, 4)),
-                  ('one launch 32x64x32, 4 wg/CU', one(1, 4)), ('one launch 128x64x16, 3 wg/CU', one(2, 3))]
-        # bit-identity of every single-launch route with the two launches (several repetitions: a race would not repeat)
-        two(0)()
-        torch.cuda.synchronize()
-        for rname, fn in routes[3:]:
-            for _ in range(3):
-                Hp.zero_(); Yp.zero_()
-                fn()
-                torch.cuda.synchronize()
-                if not (torch.equal(Hp, Hs) and torch.equal(Yp, Ys)):
-                    print('%-26s %-34s MISMATCH  H %.3g  Y %.3g' % (name, rname, (Hp - Hs).abs().max().item(), (Yp - Ys).abs().max().item()))
-                    break
-        force(0)
-        times = {r: [] for r, _ in routes}
-        for _ in range(7):
-            for rname, fn in routes:
-                times[rname].append(time_fn(fn, iters=20, warm=3))
-        force(0)
-        for rname, _ in routes:
-            us = statistics.median(times[rname])
-            print('%-26s %-34s %9.1f %9.1f' % (name, rname, us, flops / us / 1e6))
-        if want_trace:
-            tr = torch.zeros(256 * 5 * 4, dtype=torch.int64, device=dev)
-            N.check(launch(M, d, dff, scratch.data_ptr(), 0, 5, tr.data_ptr(), N.stream()), 'pair launch (traced)')
-            torch.cuda.synchronize()
-            t = tr.cpu().view(-1, 4)
-            live = t[t[:, 1] > 0]
-            span = (live[:, 3].max() - live[:, 2].min()).item() * 0.01
-            print('    traced launch: %d of %d workgroups ran tasks (min %d, max %d each); span %.1f us; stage-1 wait per workgroup: '
-                  'median %.0f, p90 %.0f, max %.0f shader cycles' %
-                  (len(live), len(t), live[:, 1].min(), live[:, 1].max(), span, live[:, 0].double().median(),
-                   live[:, 0].double().quantile(0.9), live[:, 0].max()))
-
-
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'gemm'
     {'gemm': gemm, 'gemm_ab': gemm_ab, 'lib_ab': lib_ab, 'walk': walk, 'walk_pmc': walk_pmc, 'gemm_gen': gemm_gen, 'attn': attn, 'steady': steady, 'sparse': sparse, 'sparse_rows': sparse_rows,
-     'gemm_trace': gemm_trace, 'gemm_clock': gemm_clock, 'attn_lib_ab': attn_lib_ab, 'attn_tile': attn_tile, 'chain': chain, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency, 'ffn_pair': ffn_pair, 'slab': slab, 'gemm_packed': gemm_packed}[which]()
+     'gemm_trace': gemm_trace, 'gemm_clock': gemm_clock, 'attn_lib_ab': attn_lib_ab, 'attn_tile': attn_tile, 'chain': chain, 'ln': ln, 'attn_one': attn_one, 'attn_maps': attn_maps, 'attn_trace': attn_trace, 'residency': residency, 'slab': slab}[which]()

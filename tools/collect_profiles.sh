@@ -25,7 +25,13 @@ python tools/bench_eval_epoch.py > "$OUT/eval_epoch_end_to_end.json" 2>/dev/null
 python tools/bench_kernels.py gemm_ab 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles.txt"
 python tools/bench_kernels.py gemm 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_tiles_sweep.txt"
 python tools/bench_kernels.py attn 2>&1 | grep -v amdgpu.ids > "$OUT/attn_variants.txt"
-python tools/bench_kernels.py sparse 2>&1 | grep -v amdgpu.ids > "$OUT/sparse_label_attention.txt"
+python tools/bench_kernels.py sparse_rows 2>&1 | grep -v amdgpu.ids > "$OUT/sparse_label_attention.txt"
+python tools/bench_kernels.py sparse 2>&1 | grep -v amdgpu.ids >> "$OUT/sparse_label_attention.txt"
+python bench.py --workload synthetic4096 --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined --no-sparse-label-attention > "$OUT/bench_synthetic4096_dense_label_attention.json" 2>/dev/null
+# same-box A/B of the weights-only embedding fold (round 6), three round-robin rounds per workload
+AB_STEPS=200 bash tools/ab_flags.sh "$TAG" "" "" "--no-embed-fold" > /dev/null
+AB_STEPS=200 bash tools/ab_flags.sh "$TAG" "--ragged" "" "--no-embed-fold" > /dev/null
+AB_STEPS=100 bash tools/ab_flags.sh "$TAG" "--workload bibtex" "" "--no-embed-fold" > /dev/null
 python tools/bench_kernels.py gemm_trace 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_trace.txt"
 python tools/bench_kernels.py gemm_clock 2>&1 | grep -v amdgpu.ids > "$OUT/gemm_clock.txt"
 python tools/bench_kernels.py chain 2880 17 0,12,17 2>&1 | grep -v amdgpu.ids > "$OUT/chain.txt"
