@@ -153,6 +153,29 @@ def test_tile_list_hint_is_dropped_on_graphs_it_cannot_help():
                         label_mask='none').label_tile_density is None
 
 
+def test_bench_counts_executed_flops_not_f_live():
+    """bench.py's utilisation figures are on EXECUTED FLOPs (no fraction above 1): F_live minus the weights-only
+    hoist / fold and, where the label self-attention runs the pair kernel, with 4 L^2 d replaced by 4 nnz d."""
+    import bench
+
+    class _Dec(object):
+        label_rows_sparse, label_allowed_pairs = False, 0
+
+    class _M(object):
+        decoder = _Dec()
+    w = dict(bench.WORKLOADS['reuters'])
+    fx, sub = bench.executed_flops(w, _M())
+    assert set(sub) == {'hoisted_dec0_query', 'folded_enc0_w1'}
+    assert sub['hoisted_dec0_query'] == 2 * 90 * 512 * 512 and sub['folded_enc0_w1'] == 2 * 302 * 512 * 512
+    assert fx == bench.f_live(w) - sum(sub.values()) and bench.f_live(w) == 2354997248      # SURVEY.md Appendix D
+    w5 = dict(bench.WORKLOADS['synthetic4096'])
+    _Dec.label_rows_sparse, _Dec.label_allowed_pairs = True, int(0.0978 * 4096 * 4096)
+    fx5, sub5 = bench.executed_flops(w5, _M())
+    skipped = sub5['blocked_label_pairs_skipped']
+    assert abs(skipped - 2 * 4 * 1024 * (4096 * 4096 - _Dec.label_allowed_pairs)) < 1 and 0.25 < skipped / bench.f_live(w5) < 0.35
+    assert 0 < fx5 < bench.f_live(w5)
+
+
 def test_pack_mask_bits_layout():
     g = torch.Generator().manual_seed(0)
     blocked = (torch.rand(70, 100, generator=g) < 0.5).to(torch.uint8)
