@@ -77,13 +77,26 @@ struct Carver {
     }
 };
 
+// The residual of a GEMM as a gather from the embedding tables (GemmParams::rg_tok): the encoder's first layer, whose input rows
+// are then never written (EmbedFold::row_tok).
+struct ResGather {
+    const int* tok;
+    const int* pos;
+    const float* emb;
+    const float* pos_table;
+};
+
 static int linear(const float* A, int64_t M, int K, int64_t lda, const float* const* W, int nseg, int N,
                   int64_t ldw, const float* const* bias, const float* R, int64_t ldr, int relu,
                   float* const* C, int64_t ldc, hipStream_t s, const int* m_dev = nullptr,
-                  const float* A_dense = nullptr) {
+                  const float* A_dense = nullptr, const ResGather* rg = nullptr) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.M = M; p.K = K; p.N = N; p.nseg = nseg; p.ldw = ldw; p.ldc = ldc;
     p.R = R; p.ldr = ldr; p.relu = relu; p.m_dev = m_dev; p.A_dense = A_dense;
+    if (rg) {
+        p.R = nullptr;
+        p.rg_tok = rg->tok; p.rg_pos = rg->pos; p.rg_emb = rg->emb; p.rg_pos_table = rg->pos_table;
+    }
     for (int i = 0; i < nseg; ++i) {
         p.W[i] = W[i];
         p.bias[i] = bias ? bias[i] : nullptr;
@@ -314,8 +327,9 @@ static int project_kv_layers(const float* x, int64_t Me, int d, int dk, int dv, 
 static int ffn_core(const float* x, int64_t M, int d, int dff, const lamp_ffn_weights& w, float* out,
                     float* hidden, hipStream_t s, const float* w_out = nullptr, int n_labels = 0,
                     float* logits = nullptr, const int* rows_dev = nullptr, const SeqPlan* scatter = nullptr,
-                    int nb = 0, int T = 0, float* y_flat = nullptr, bool hidden_ready = false) {
+                    int nb = 0, int T = 0, float* y_flat = nullptr, bool hidden_ready = false, const ResGather* rg = nullptr) {
     if (!w.w1 || !w.b1 || !w.w2 || !w.b2 || !w.ln_g || !w.ln_b) return LAMP_E_NULL;
+    if (rg && !hidden_ready) return LAMP_E_UNSUPPORTED;   // x itself does not exist then: only the residual may ask for it
     if (!hidden_ready) {
         const float* W[1] = {w.w1};
         const float* b[1] = {w.b1};
@@ -326,7 +340,7 @@ static int ffn_core(const float* x, int64_t M, int d, int dff, const lamp_ffn_we
         const float* W[1] = {w.w2};
         const float* b[1] = {w.b2};
         float* C[1] = {out};
-        LAMP_CK(linear(hidden, M, dff, dff, W, 1, d, dff, b, x, d, 0, C, d, s, rows_dev));
+        LAMP_CK(linear(hidden, M, dff, dff, W, 1, d, dff, b, x, d, 0, C, d, s, rows_dev, nullptr, rg));
     }
     if (scatter)
         return launch_layernorm(out, int64_t(nb) * T, d, w.ln_g, w.ln_b, 1e-5f, nullptr, 0, out, s, nullptr, 0, nullptr,
@@ -859,6 +873,9 @@ static int make_plan(const lamp_model* m, int T, int want_attn, FwdPlan* pl) {
     // the plan's hand-off granules inside the merged plan + gather launch: 2 mb + 2 eight-byte words
     pl->per_sample_floats += 4;
     pl->fixed_floats += 4 + 64;
+    // the row -> (token, position) maps of the gathered residual (folded first encoder layer): 2 (mb T + 1) ints
+    pl->per_sample_floats += 2 * size_t(T);
+    pl->fixed_floats += 2 + 64;
     // K/V of all decoder layers' enc-attention, projected together right after the encoder when the batch fits
     pl->side_kv_floats = size_t(m->n_layers_dec) * T * (pl->hdk + pl->hdv);
     return 0;
@@ -897,6 +914,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
     const int Rq = want_enc_attn ? pl.R : L;
     float *H = nullptr, *Y = nullptr, *Xp = nullptr;
     int* plan_ints = nullptr;
+    int* row_maps = nullptr;   // [2][mb T + 1]: token / position index of every (packed) encoder row, for the gathered residual
     unsigned long long* granules = nullptr;
     float* Kahead[MAX_AHEAD_LAYERS] = {};
     float* Vahead[MAX_AHEAD_LAYERS] = {};
@@ -914,6 +932,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         Xp = c.take(size_t(mb) * T * d + d);
         plan_ints = reinterpret_cast<int*>(c.take(plan_int_count(mb, T)));
         granules = reinterpret_cast<unsigned long long*>(c.take(size_t(4) * mb + 4));
+        row_maps = reinterpret_cast<int*>(c.take(2 * (size_t(mb) * T + 1)));
         for (int i = 0; i < n_ahead; ++i) {
             Kahead[i] = c.take(size_t(mb) * T * pl.hdk);
             Vahead[i] = c.take(size_t(mb) * T * pl.hdv);
@@ -942,15 +961,22 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         const float* xk = x;  // what the decoder's K / V projections read
         // Encoder layer 0's W1 folded into the embedding tables (lamp_model::enc0_emb_w1): the gather writes that layer's
         // hidden rows into H beside the embedded rows, and its first GEMM is not launched.
+        // ... and the embedded rows themselves are not written either: their one reader, the residual of that layer's second
+        // GEMM, gathers them from the tables through the row maps the gather kernel leaves instead (8 bytes per row).
         const bool folded = m->enc0_emb_w1 && m->n_layers_enc > 0;
-        const EmbedFold fold{m->enc0_emb_w1, m->enc0_pos_w1, dff, folded ? H : nullptr};
+        int* row_tok = row_maps, *row_pos = row_maps + (size_t(mb) * T + 1);
+        // (padded layout = the dead self-attention's maps are wanted: layer 0's map reads the embedded rows, so they are written)
+        const bool gather_res = folded && packed;
+        const EmbedFold fold{m->enc0_emb_w1, m->enc0_pos_w1, dff, folded ? H : nullptr, gather_res ? row_tok : nullptr,
+                             gather_res ? row_pos : nullptr};
+        const ResGather rg{row_tok, row_pos, m->src_word_emb, m->position_enc};
         if (packed) {
             LAMP_CK(launch_embed_plan(seq, pos, m->position_enc != nullptr, nb, T, m->src_word_emb, m->n_src_vocab,
                                       m->position_enc, m->n_position, d, sp, granules, Xp, s, &fold));
             for (int i = 0; i < m->n_layers_enc; ++i) {
                 const bool last = i + 1 == m->n_layers_enc;
                 LAMP_CK(ffn_core(Xp, Me + 1, d, dff, m->enc_layers[i].pos_ffn, Xp, H, s, nullptr, 0, nullptr, sp.rows + 1,
-                                 last ? &sp : nullptr, nb, T, x, folded && i == 0));  // lamp/Layers.py:18
+                                 last ? &sp : nullptr, nb, T, x, folded && i == 0, folded && i == 0 ? &rg : nullptr));  // lamp/Layers.py:18
             }
             xk = Xp;
         } else {

@@ -126,7 +126,12 @@ __global__ __launch_bounds__(256, (PM == 0 && MK != LAMP_MASK_KEY_TOKENS_I64) ? 
     const int nt = PM == 0 ? (lk_b + 31) / 32 : (p.lk + 31) / 32;
     float4 kf[DKC];
     float vf[16][DVB];   // V[key_r(hi)][DVB*l31 + e]: block e of O^T holds dv columns {DVB*i + e}
-    unsigned mraw[16];   // raw mask bytes / token-is-PAD flags of the tile, loaded one tile ahead
+    unsigned mraw[16];   // token-is-PAD flags of the tile, loaded one tile ahead
+    // LAMP_MASK_U8: the tile's sixteen mask bytes of this lane, two per register (hipcc merges pairs of byte loads with
+    // v_perm_b32): eight registers instead of sixteen -- the 128-wide, maps-off, unsplit instantiation behind a bare
+    // lamp_sdpa_fwd with a byte mask was spilling 12 bytes per lane; four per register spills again
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 mpair[8];
     unsigned mword = 0;  // LAMP_MASK_BITS_U32: this row's 32 mask bits of the tile (one load instead of sixteen)
 
     auto load_k = [&](int kt) {
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256, (PM == 0 && MK != LAMP_MASK_KEY_TOKENS_I64) ? 
         } else if constexpr (MK == LAMP_MASK_U8) {
             const unsigned mo = unsigned(int64_t(qc) * p.m_sq) + unsigned(kbase);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mraw[r] = bload_u8(rsM, mo + (r & 3) + 8 * (r >> 2));
+            for (int r = 0; r < 16; ++r) mpair[r >> 1][r & 1] = static_cast<unsigned short>(bload_u8(rsM, mo + (r & 3) + 8 * (r >> 2)));
         } else if constexpr (MK == LAMP_MASK_KEY_TOKENS_I64) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)  // past lk: reads 0 == PAD == blocked (forced to -inf below anyway)
@@ -205,7 +210,8 @@ __global__ __launch_bounds__(256, (PM == 0 && MK != LAMP_MASK_KEY_TOKENS_I64) ? 
             const int key = kbase + (r & 3) + 8 * (r >> 2);
             bool blk = false;
             if constexpr (MK == LAMP_MASK_BITS_U32) blk = (mw & (1u << ((r & 3) + 8 * (r >> 2)))) != 0;
-            if constexpr (MK == LAMP_MASK_U8 || MK == LAMP_MASK_KEY_TOKENS_I64) blk = mraw[r] != 0;
+            if constexpr (MK == LAMP_MASK_U8) blk = mpair[r >> 1][r & 1] != 0;
+            if constexpr (MK == LAMP_MASK_KEY_TOKENS_I64) blk = mraw[r] != 0;
             if (key >= lk_b || blk) s[r] = -INFINITY;
         }
     };

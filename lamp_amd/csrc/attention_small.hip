@@ -232,6 +232,12 @@ __global__ __launch_bounds__(QB* KSPLIT * 64, 3) void attn16_kernel(AttnParams p
         unsigned word = tail;
         if constexpr (MK == LAMP_MASK_BITS_U32) word |= mbits >> ((kt & 1) * 16);
         const int mine = MK == LAMP_MASK_BITS_U32 || MK == LAMP_MASK_NONE ? int(word >> (4 * g)) : int(mbits | (tail >> (4 * g)));
+        // Blocked keys enter as the accumulator's INITIAL value (-inf; 0 elsewhere): two instructions per score and none behind
+        // the product.  DELIBERATE DEVIATION from masked_fill (lamp/SubLayers.py:32), which overwrites whatever the product was:
+        // -inf + x is -inf for every FINITE x, but NaN for x = +inf or NaN -- a non-finite K (or Q) row behind a BLOCKED key
+        // poisons that query's row here, while the reference stays finite.  Finite inputs (every model this path serves) are
+        // unaffected; attention_tile.hip does the same; attention_sparse.hip never touches a blocked key at all.  Pinned by
+        // tests/test_gpu_parity.py::test_non_finite_key_behind_a_blocked_key_is_a_documented_deviation.
         f32x4 s0, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

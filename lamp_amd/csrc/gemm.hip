@@ -96,7 +96,8 @@ __device__ __forceinline__ const float* uniform_ptr(const float* q) {
 // The whole tile program: one tile per workgroup, derived from blockIdx.  (Staging variants that lost their measurements --
 // LDS-DMA with compiler-scheduled / inline-assembly fragment reads, W fragments straight from global memory or from a packed
 // copy, two dependent GEMMs in one persistent launch -- are not carried here any more: csrc/experiments/README.md.)
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC>
+// RGATHER: the residual is gathered from two tables through per-row indices (GemmParams::rg_tok) instead of read from R.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC, bool RGATHER>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, int tiles_n, int tiles_m, int panel_split,
                                           FastDiv fd_group, FastDiv fd_seg) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
@@ -314,9 +315,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
     // Stores to rows past M fall outside the descriptor and are dropped by the hardware; columns past N are steered
     // to an out-of-range offset.  N, ldc (and ldr) not multiples of 4, or unaligned bases, take the scalar path.
     const int ldc = int(p.ldc), ldr = int(p.ldr);
-    const bool has_r = p.R != nullptr;
+    const bool has_r = RGATHER || p.R != nullptr;
+    const bool read_r = !RGATHER && p.R != nullptr;
     const __amdgpu_buffer_rsrc_t rsR =
-        make_rsrc(has_r ? p.R + m0 * p.ldr + n0 : p.A, has_r ? (uint64_t(rows_m - 1) * ldr + rows_n) * 4u : 0);
+        make_rsrc(read_r ? p.R + m0 * p.ldr + n0 : p.A, read_r ? (uint64_t(rows_m - 1) * ldr + rows_n) * 4u : 0);
     const float* bias = p.bias[seg];
     const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(bias ? bias + n0 : p.A, bias ? uint64_t(rows_n) * 4u : 0);
     constexpr int NQ = NACC / 4;  // register quads (= float4 of consecutive columns) per block
@@ -332,6 +334,31 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
         v.w = bload1(rs, lcol + 3 < rows_n ? (off + 3) * 4u : OOB);
         return v;
     };
+    // gathered residual: this lane's rows' table rows (row indices past the tile's rows read table row 0: their stores are dropped)
+    const float* ge[RGATHER ? T::MI : 1];
+    const float* gp[RGATHER ? T::MI : 1];
+    if constexpr (RGATHER) {
+#pragma unroll
+        for (int i = 0; i < T::MI; ++i) {
+            const int lrow = lrow0 + i * MF;
+            const bool in = lrow < rows_m;
+            const int tk = in ? p.rg_tok[m0 + lrow] : 0, ps = (in && p.rg_pos_table) ? p.rg_pos[m0 + lrow] : 0;
+            ge[i] = p.rg_emb + int64_t(tk) * p.N + n0;
+            gp[i] = p.rg_pos_table ? p.rg_pos_table + int64_t(ps) * p.N + n0 : nullptr;
+        }
+    }
+    auto gathered = [&](int i, int lcol) -> float4 {   // emb[tok][col] (+ pos[p][col]): the add the gather kernel would have done
+        if constexpr (RGATHER) {
+            if (lcol >= rows_n) return make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = *reinterpret_cast<const float4*>(ge[i] + lcol);
+            if (gp[i]) {
+                const float4 w = *reinterpret_cast<const float4*>(gp[i] + lcol);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            return v;
+        }
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    };
     constexpr int NPRE = RPRE ? T::MI * T::NI * NQ : 1;
     float4 pre_r[NPRE], pre_b[RPRE ? T::NI * NQ : 1];
     if constexpr (RPRE) {
@@ -343,7 +370,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
                 pre_b[j * NQ + q] = load4(rsBias, unsigned(lcol), lcol);
 #pragma unroll
                 for (int i = 0; i < T::MI; ++i)
-                    pre_r[(j * T::MI + i) * NQ + q] = load4(rsR, unsigned((lrow0 + i * MF) * ldr + lcol), lcol);
+                    pre_r[(j * T::MI + i) * NQ + q] = RGATHER ? gathered(i, lcol) : load4(rsR, unsigned((lrow0 + i * MF) * ldr + lcol), lcol);
             }
     }
 
@@ -400,7 +427,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
                         res = pre_r[(j * T::MI + i) * NQ + q];
                     } else {
                         bv = load4(rsBias, unsigned(lcol), lcol);
-                        if constexpr (WITH_R) res = load4(rsR, unsigned(lrow * ldr + lcol), lcol);
+                        if constexpr (WITH_R) res = RGATHER ? gathered(i, lcol) : load4(rsR, unsigned(lrow * ldr + lcol), lcol);
                     }
                     float4 v = make_float4(acc[i][j][4 * q + 0] + bv.x, acc[i][j][4 * q + 1] + bv.y,
                                            acc[i][j][4 * q + 2] + bv.z, acc[i][j][4 * q + 3] + bv.w);
@@ -437,12 +464,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, int tiles_n_seg, 
 #endif
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool RPRE, bool VEC, bool RGATHER = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (gemm_min_waves(BM, BN, BK, MF))) void gemm_nt_kernel(GemmParams p, int tiles_n_seg,
                                                                           int tiles_n, int tiles_m,
                                                                           int panel_split, FastDiv fd_group,
                                                                           FastDiv fd_seg) {
-    gemm_body<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC>(p, tiles_n_seg, tiles_n, tiles_m, panel_split, fd_group, fd_seg);
+    gemm_body<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC, RGATHER>(p, tiles_n_seg, tiles_n, tiles_m, panel_split, fd_group, fd_seg);
 }
 
 #ifdef LAMP_TUNING
@@ -453,11 +480,11 @@ static size_t g_extra_lds = 0;
 extern "C" __attribute__((visibility("default"))) void lamp_debug_set_gemm_extra_lds(int bytes) { g_extra_lds = size_t(bytes); }
 #endif
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool VEC>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool KTAIL, int MF, bool VEC, bool RGATHER = false>
 static int launch_cfg2(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<BM, BN, BK, WAVES_M, WAVES_N, MF>;
     constexpr bool RPRE = T::MI * T::NI * (MF == 32 ? 16 : 4) <= 16;
-    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC>;
+    auto kern = gemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, KTAIL, MF, RPRE, VEC, RGATHER>;
     size_t LDS = T::LDS_BYTES;
     static AttrOnce once;
 #ifdef LAMP_TUNING
@@ -502,6 +529,10 @@ static int launch_cfg2(const GemmParams& p, hipStream_t s) {
 // a K that is not a multiple of BK takes the KTAIL instantiation (columns past K read as zeros): same bits
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MF = 32>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
+    if (p.rg_tok) {   // gathered residual: the 16-byte epilogue of a whole-k-tile product (every shape the forward uses it on)
+        if (!p.vec_epilogue || (p.K % BK)) return LAMP_E_UNSUPPORTED;
+        return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF, true, true>(p, s);
+    }
     if (p.vec_epilogue) {
         if (p.K % BK) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, true, MF, true>(p, s);
         return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, false, MF, true>(p, s);
@@ -532,6 +563,8 @@ int launch_gemm(const GemmParams& p_in, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.nseg < 1 || p.nseg > GEMM_MAX_SEG) return LAMP_E_DIMS;
     if ((p.K & 3) || (p.lda & 3) || (p.ldw & 3)) return LAMP_E_ALIGN;
     if (!p.A || (p.A_dense && !p.m_dev)) return LAMP_E_NULL;
+    if (p.rg_tok && (p.R || !p.rg_emb || p.nseg != 1 || (p.rg_pos_table && !p.rg_pos))) return LAMP_E_UNSUPPORTED;
+    if (p.rg_tok && (!aligned16(p.rg_emb) || (p.rg_pos_table && !aligned16(p.rg_pos_table)))) return LAMP_E_ALIGN;
     if (!aligned16(p.A) || (p.A_dense && !aligned16(p.A_dense))) return LAMP_E_ALIGN;
     for (int i = 0; i < p.nseg; ++i) {
         if (!p.W[i] || !p.C[i]) return LAMP_E_NULL;
@@ -539,7 +572,7 @@ int launch_gemm(const GemmParams& p_in, hipStream_t s) {
     }
     const double flops = 2.0 * double(p.M) * p.N * p.nseg * p.K;
     const double bytes = 4.0 * (double(p.M) * p.K + double(p.N) * p.nseg * p.K +
-                                double(p.M) * p.N * p.nseg * (p.R ? 2 : 1));
+                                double(p.M) * p.N * p.nseg * ((p.R || p.rg_tok) ? 2 : 1));
     ProfScope prof(LAMP_K_GEMM, flops, bytes, s);
     p.trace = nullptr;
     bool vec = !(p.N & 3) && !(p.ldc & 3) && (!p.R || (!(p.ldr & 3) && aligned16(p.R)));

@@ -31,6 +31,14 @@ struct GemmParams {
     const float* R;  // residual, same for every segment (only meaningful with nseg == 1)
     int64_t ldr;
     int relu;
+    // Residual GATHERED in the epilogue instead of read from R (R must be NULL): row r adds rg_emb[rg_tok[r]][col] (+ rg_pos_table[
+    // rg_pos[r]][col]) -- the embedded input row of the encoder's first layer (lamp/Encoders.py:66,75), which then is never
+    // materialised: the gather kernel writes the two row -> index maps (8 bytes per row) instead of the row (4 d bytes).  The sum
+    // is the single fp32 add the gather kernel would have done: same bits as the residual read.  N must be the tables' width.
+    const int* rg_tok;            // nullable: [M] token index per row (already range-checked by the writer)
+    const int* rg_pos;            // [M] position index per row (unused without a position table)
+    const float* rg_emb;          // [n_vocab, N]
+    const float* rg_pos_table;    // [n_position, N] or NULL
     const int* m_dev;   // nullable: the live row count in DEVICE memory (<= M, which then only sizes the launch) -- the
                         // packed token rows of a ragged batch, counted on the device (pointwise.hip: seq_plan_kernel)
     const float* A_dense;  // nullable, with m_dev = SeqPlan::rows: read A_dense instead of A when m_dev[0] == m_dev[1], i.e. no
@@ -136,6 +144,9 @@ struct EmbedFold {
     const float* p1;   // [n_position, dff]  pos_table . W1^T + b1, or nullptr without a position table
     int dff;
     float* hid;        // [rows, dff]: same row index as the embedded rows
+    int* row_tok;      // nullable, with row_pos: instead of the embedded row (4 d bytes) the gather writes the row's token and
+    int* row_pos;      //   position index (8 bytes) -- the only reader of that row, the first layer's second GEMM, adds it as a
+                       //   gathered residual (GemmParams::rg_tok)
 };
 int launch_embed_packed(const int64_t* seq, const int64_t* pos, int nb, int T, const float* emb, int n_vocab,
                         const float* pos_table, int n_position, int d, const SeqPlan& sp, float* out, hipStream_t s,

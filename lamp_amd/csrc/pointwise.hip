@@ -36,7 +36,13 @@ __device__ __forceinline__ void gather_row(int64_t tok, int64_t ps, const float*
     const float4* e1 = reinterpret_cast<const float4*>(fold.e1 + (ok ? tok : 0) * fold.dff);
     const float4* q1 = fold.p1 ? reinterpret_cast<const float4*>(fold.p1 + (ok ? ps : 0) * fold.dff) : nullptr;
     float4* h = reinterpret_cast<float4*>(fold.hid + dst * fold.dff);
-    const int nx = d / 4, nh = fold.dff / 4;
+    // the embedded row itself is read by ONE consumer, the residual of the layer's second GEMM: with the row maps that GEMM
+    // gathers it in its epilogue and the row is not written at all (an out-of-range token's hidden row is NaN, so its output is)
+    const int nx = fold.row_tok ? 0 : d / 4, nh = fold.dff / 4;
+    if (fold.row_tok && lane == 0) {
+        fold.row_tok[dst] = ok ? int(tok) : 0;
+        fold.row_pos[dst] = ok ? int(ps) : 0;
+    }
     // Two plain passes, the embedded row then the hidden row.  Both "all table reads in flight before the first store"
     // forms (one fused loop; clamped loads into registers up front) measured SLOWER in the forward: 23.6-28 us against 21-22
     // (profiles/r06_rejected_experiments.txt #1); the plain form is kept because it measures fastest.
@@ -531,16 +537,18 @@ static inline int grid4(int64_t rows, unsigned* g) {
 
 // fold (nullable): also write the first encoder layer's hidden rows from the folded tables (gather_row)
 static int check_fold(const EmbedFold* fold, const float* pos_table, EmbedFold* out) {
-    *out = EmbedFold{nullptr, nullptr, 0, nullptr};
+    *out = EmbedFold{nullptr, nullptr, 0, nullptr, nullptr, nullptr};
     if (!fold || !fold->hid) return 0;
     if (!fold->e1 || (pos_table && !fold->p1)) return LAMP_E_NULL;
     if (fold->dff <= 0 || (fold->dff & 3)) return LAMP_E_UNSUPPORTED;
     if (!aligned16(fold->e1) || !aligned16(fold->hid) || (fold->p1 && !aligned16(fold->p1))) return LAMP_E_ALIGN;
+    if ((fold->row_tok == nullptr) != (fold->row_pos == nullptr)) return LAMP_E_NULL;
     *out = *fold;
     if (!pos_table) out->p1 = nullptr;
     return 0;
 }
 static inline double embed_bytes(int64_t n_tok, int d, bool pos, const EmbedFold& f) {
+    if (f.hid && f.row_tok) return double(n_tok) * (16.0 + 8.0 + 4.0 * f.dff * (pos ? 3 : 2));   // hidden rows + row maps only
     return double(n_tok) * (16.0 + 4.0 * d * (pos ? 3 : 2) + (f.hid ? 4.0 * f.dff * (pos ? 3 : 2) : 0.0));
 }
 

@@ -929,6 +929,56 @@ def test_model_takes_the_pair_kernel_on_a_sparse_unstructured_label_graph(dev):
     assert max_abs_diff(N.diag_logits(y, m.tgt_word_proj.linear.weight), pairs) < 2e-5
 
 
+def test_non_finite_key_behind_a_blocked_key_is_a_documented_deviation(dev):
+    """the small-shape and tile attention kernels enter blocked keys as a -inf INITIAL accumulator of the QK^T
+    chain (attention_small.hip, attention_tile.hip) instead of overwriting the finished score as masked_fill does
+    (lamp/SubLayers.py:32): -inf + (+inf or NaN) is NaN, so a non-finite K row behind a BLOCKED key turns the rows of the
+    queries that block it into NaN, where the reference stays finite.  Pinned here so that it cannot change unnoticed:
+    finite keys behind blocked positions never matter (bit-identical to the same call with those rows zeroed), queries that
+    may see the key are NaN in the reference too, and the pair kernel, which never touches a blocked key, matches the
+    reference exactly."""
+    import ctypes
+    from lamp_amd import _native as N
+    g = torch.Generator().manual_seed(5)
+    for lq, lk, sparse in ((90, 90, False), (1100, 1100, False), (1100, 1100, True)):
+        dk, B, H = 128, 1, 2
+        q = torch.randn(B, lq, H * dk, generator=g)
+        k = torch.randn(B, lk, H * dk, generator=g)
+        v = torch.randn(B, lk, H * dk, generator=g)
+        blocked = torch.rand(lq, lk, generator=g) < (0.9 if sparse else 0.5)
+        blocked[:, 0] = False
+        bad = 7
+        blocked[: lq // 2, bad] = True      # the first half of the queries block key 7, the second half may see it
+        blocked[lq // 2:, bad] = False
+        bits = N.pack_mask_bits(blocked.to(torch.uint8)).to(dev)
+        lay = N.AttnLayout(lq * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lk * H * dk, dk, H * dk, lq * H * dk, dk, H * dk)
+        flags = N.LAMP_MASK_SPARSE_ROWS if sparse else 0
+        ms = N.Mask(N.LAMP_MASK_BITS_U32, flags, bits.data_ptr(), 0, bits.size(1), None, 0, int((~blocked).sum()) if sparse else 0)
+
+        qd, vd = q.to(dev), v.to(dev)
+
+        def run(kk):
+            o = torch.empty(B, lq, H * dk, device=dev)
+            kd = kk.to(dev)      # (kept alive across the call: the ABI takes raw pointers)
+            N.check(N.lib().lamp_sdpa_fwd(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), None, B, H,
+                                          lq, lk, dk, dk, dk ** -0.5, ctypes.byref(ms), ctypes.byref(lay), N.stream()), 'sdpa')
+            torch.cuda.synchronize()
+            return o.cpu()
+        k_zero, k_big, k_inf = k.clone(), k.clone(), k.clone()
+        k_zero[:, bad] = 0.0
+        k_big[:, bad] = 1e30                    # finite: must not matter to the queries that block it
+        k_inf[:, bad] = float('inf')
+        base, big, inf = run(k_zero), run(k_big), run(k_inf)
+        half = lq // 2
+        assert torch.isfinite(base).all()
+        assert torch.equal(big[:, :half], base[:, :half])                    # a finite key behind a blocked position is invisible
+        assert torch.isnan(inf[:, half:]).all()                              # queries that SEE the key: inf - inf, as in the reference
+        if sparse:
+            assert torch.equal(inf[:, :half], base[:, :half])                # pair kernel == masked_fill semantics
+        else:
+            assert torch.isnan(inf[:, :half]).all()                          # the documented deviation of the dense kernels
+
+
 def test_layer0_query_cache_tracks_weight_updates(dev):
     """The hoisted label-table x W_q projection is bit-identical to projecting per call, and is refreshed
     when either operand is modified in place (load_state_dict / optimiser step keep data_ptr)."""

@@ -25,8 +25,8 @@ import count_loop_valu as CLV  # noqa: E402
 
 # kernels allowed to spill: (translation unit, name) -> max bytes per lane.  Neither uses inline-assembly loads.
 KNOWN_SCRATCH = {
-    ('attention.hip', 'lamp::attn_kernel<128, 1, 0, 1>'): 16,        # u8-mask variants of the large attention (cold path: the forward
-    ('attention.hip', 'lamp::attn_kernel<128, 2, 0, 1>'): 16,        # hands the label graph over bit-packed)
+    ('attention.hip', 'lamp::attn_kernel<128, 2, 0, 1>'): 16,        # u8-mask, two key shares: only d_v = 4 (mod 8) at <= 128 queries gets here
+                                                                      # (the unsplit variant behind a bare lamp_sdpa_fwd no longer spills)
     ('backward.hip', 'lamp::layernorm_bwd_kernel<16, true, 3>'): 160,  # training only
 }
 FORWARD_UNITS = ['gemm.hip', 'chain.hip', 'attention.hip', 'attention_tile.hip', 'attention_small.hip', 'attention_general.hip', 'pointwise.hip']
