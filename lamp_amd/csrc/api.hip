@@ -966,7 +966,8 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
         const bool folded = m->enc0_emb_w1 && m->n_layers_enc > 0;
         int* row_tok = row_maps, *row_pos = row_maps + (size_t(mb) * T + 1);
         // (padded layout = the dead self-attention's maps are wanted: layer 0's map reads the embedded rows, so they are written)
-        const bool gather_res = folded && packed;
+        const bool gather_res = folded && packed &&
+                                gemm_gathered_residual_ok(d, dff, d, m->enc_layers[0].pos_ffn.b2, Xp, m->src_word_emb, m->position_enc);
         const EmbedFold fold{m->enc0_emb_w1, m->enc0_pos_w1, dff, folded ? H : nullptr, gather_res ? row_tok : nullptr,
                              gather_res ? row_pos : nullptr};
         const ResGather rg{row_tok, row_pos, m->src_word_emb, m->position_enc};
@@ -976,7 +977,7 @@ static int forward_range(const lamp_model* m, const FwdPlan& pl, const int64_t* 
             for (int i = 0; i < m->n_layers_enc; ++i) {
                 const bool last = i + 1 == m->n_layers_enc;
                 LAMP_CK(ffn_core(Xp, Me + 1, d, dff, m->enc_layers[i].pos_ffn, Xp, H, s, nullptr, 0, nullptr, sp.rows + 1,
-                                 last ? &sp : nullptr, nb, T, x, folded && i == 0, folded && i == 0 ? &rg : nullptr));  // lamp/Layers.py:18
+                                 last ? &sp : nullptr, nb, T, x, folded && i == 0, gather_res && i == 0 ? &rg : nullptr));  // lamp/Layers.py:18
             }
             xk = Xp;
         } else {

@@ -558,6 +558,11 @@ extern "C" __attribute__((visibility("default"))) void lamp_debug_set_gemm_trace
 }
 #endif
 
+bool gemm_gathered_residual_ok(int N, int K, int64_t ldc, const float* bias, const float* C, const float* emb, const float* pos_table) {
+    return N > 0 && !(N & 3) && K > 0 && (K % 32) == 0 && !(ldc & 3) && aligned16(C) && (!bias || aligned16(bias)) && emb && aligned16(emb) &&
+           (!pos_table || aligned16(pos_table));
+}
+
 int launch_gemm(const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.nseg < 1 || p.nseg > GEMM_MAX_SEG) return LAMP_E_DIMS;

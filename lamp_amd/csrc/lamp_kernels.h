@@ -80,6 +80,9 @@ struct AttnParams {
 };
 
 int launch_gemm(const GemmParams& p, hipStream_t s);
+// whether launch_gemm takes a gathered residual (GemmParams::rg_tok) for this product: the 16-byte epilogue of whole k-tiles of
+// every tile of the menu (shape / alignment rule only: the caller decides BEFORE it leaves the embedded rows unwritten)
+bool gemm_gathered_residual_ok(int N, int K, int64_t ldc, const float* bias, const float* C, const float* emb, const float* pos_table);
 // slab.hip (tuning build only: measured slower than the tile kernel, profiles/r05_rejected_experiments.txt): the same product
 // from format-1 weight packs, one slab of rows per CU, bit-identical to launch_gemm
 bool slab_applies(int64_t M, int N, int K, int nseg, const float* const* Wq);

@@ -971,10 +971,13 @@ def test_non_finite_key_behind_a_blocked_key_is_a_documented_deviation(dev):
         base, big, inf = run(k_zero), run(k_big), run(k_inf)
         half = lq // 2
         assert torch.isfinite(base).all()
-        assert torch.equal(big[:, :half], base[:, :half])                    # a finite key behind a blocked position is invisible
+        if sparse:   # (the lazy rescale is taken per WAVE: a wave-mate that sees the huge key moves this row's rounding, not its value)
+            assert max_abs_diff(big[:, :half], base[:, :half]) < 1e-6
+        else:
+            assert torch.equal(big[:, :half], base[:, :half])                # a finite key behind a blocked position is invisible
         assert torch.isnan(inf[:, half:]).all()                              # queries that SEE the key: inf - inf, as in the reference
         if sparse:
-            assert torch.equal(inf[:, :half], base[:, :half])                # pair kernel == masked_fill semantics
+            assert max_abs_diff(inf[:, :half], base[:, :half]) < 1e-6        # pair kernel == masked_fill semantics
         else:
             assert torch.isnan(inf[:, :half]).all()                          # the documented deviation of the dense kernels
 
