@@ -53,6 +53,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from lamp_amd import hostcpu  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
@@ -300,7 +301,8 @@ def cpu_baseline(w, sd, adj, seq, pos, budget_s=20.0):
     # torch's default thread count (all physical cores of a big host) is usually NOT the fastest for these
     # small ops: probe a few counts on the as-written / autograd-on path and report the best one.
     default_threads = torch.get_num_threads()
-    candidates = sorted({t for t in (default_threads, 64, 32, 16, 8) if t <= max(default_threads, 1)}, reverse=True)
+    usable = hostcpu.usable_cores()      # min(affinity, cgroup quota): more threads than this only burn the quota
+    candidates = sorted({t for t in (default_threads, usable, 64, 32, 16, 8) if t <= max(default_threads, 1)}, reverse=True)
     probe = {}
     for t in candidates:
         torch.set_num_threads(t)
@@ -321,7 +323,7 @@ def cpu_baseline(w, sd, adj, seq, pos, budget_s=20.0):
                   (n_aw, B, sorted(probe)),
         'no_grad_value': B / t_ng, 'dead_code_eliminated_no_grad_value': B / t_dce,
         'threads_probe_samples_per_s': {str(k): v for k, v in sorted(probe.items())},
-        'default_torch_threads': default_threads, 'host_cpu_count': os.cpu_count(),
+        'default_torch_threads': default_threads, 'host_cpu_count': os.cpu_count(), 'usable_cores_under_cgroup_quota': usable,
     }
 
 
@@ -596,7 +598,7 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0',
                    LAMP_BENCH_SPAWNED='1')
-        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+        env.setdefault('OMP_NUM_THREADS', str(max(1, hostcpu.usable_cores() // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0

@@ -17,6 +17,8 @@ alternate.  Here they overlap (round 6):
 The only host-side wait is the final synchronize.  With ``streams=n`` consecutive batches are issued round-robin on n HIP
 streams, so one batch's kernel ramps / tails are filled by the other batches' kernels (tools/bench_eval_epoch.py).
 Each sample's numbers are identical in every mode.
+
+The epoch's host work is small-tensor work; torch's intra-op pool is fitted to the container's CPU quota first (hostcpu.py).
 """
 import queue
 import threading
@@ -25,6 +27,7 @@ import numpy as np
 import torch
 
 from . import _native as N
+from . import hostcpu
 from . import sharding
 from .data import get_gold_binary
 
@@ -36,7 +39,7 @@ class _Stage(object):
 
 
 class _Slot(object):
-    """One of the producer's pinned staging buffers (a ring of four, grown on demand, allocated ONCE per epoch: hipHostMalloc
+    """One of the producer's pinned staging buffers (a ring of four, grown on demand, allocated once and kept across epochs: hipHostMalloc
     is not something to call per stage next to a busy device).  `uploaded` = the event behind the stage's host-to-device copies:
     the producer waits for it before it overwrites the buffers -- four slots, because stage k - 3 may have been taken off the
     queue without its copies being issued yet, while stage k - 4 certainly has been."""
@@ -51,9 +54,28 @@ class _Slot(object):
             self.uploaded = None
         if self.ids is None or self.ids.numel() < n_ids:
             self.ids = torch.empty(max(n_ids, 1) * 3 // 2, dtype=torch.int64, pin_memory=pin)
-        if self.gold is None or self.gold.size(0) < n_rows:
+        if self.gold is None or self.gold.size(0) < n_rows or self.gold.size(1) != n_labels:
             self.gold = torch.empty((max(n_rows, 1) * 3 // 2, n_labels), dtype=torch.float32, pin_memory=pin)
         return self.ids[:n_ids], self.gold[:n_rows]
+
+
+# Pinned staging rings outlive an epoch: hipHostMalloc page-locks memory (tens of milliseconds now and then, next to a busy
+# device), so an epoch borrows a ring of this process and gives it back; concurrent epochs each get their own.
+_RINGS = []
+_RINGS_LOCK = threading.Lock()
+
+
+def _borrow_ring():
+    with _RINGS_LOCK:
+        return _RINGS.pop() if _RINGS else [_Slot() for _ in range(4)]
+
+
+def _return_ring(ring):
+    for slot in ring:
+        slot.uploaded = None      # the epoch has synchronised: nothing of it is in flight
+    with _RINGS_LOCK:
+        if len(_RINGS) < 4:
+            _RINGS.append(ring)
 
 
 def _hand_over(out_q, item, stop):
@@ -66,12 +88,12 @@ def _hand_over(out_q, item, stop):
     return False
 
 
-def _produce(it, n_labels, batch_size, prefetch, all_targets, out_q, pin, device, stop, merge=False):
+def _produce(it, n_labels, batch_size, prefetch, all_targets, out_q, pin, device, stop, merge=False, ring=None):
     """Producer thread: the host side of utils/data_loader.py:242-312 + utils/utils.py:205-216 for stage after stage."""
     try:
         if pin:
             torch.cuda.set_device(device)    # pinned allocations belong to THIS rank's device context, not to device 0's
-        ring, n_stage = [_Slot() for _ in range(4)], 0
+        ring, n_stage = ring if ring is not None else [_Slot() for _ in range(4)], 0
         while not stop.is_set():
             host = []
             for _ in range(prefetch):
@@ -149,6 +171,7 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
     the issuing thread makes one call per stage instead of one per batch and the kernels see `prefetch` times the rows."""
     import time
     t_start = time.perf_counter()
+    hostcpu.fit_intra_op_threads(world_size)   # a 256-thread OpenMP pool under a 16-core cgroup quota stalls the whole process (hostcpu.py)
     model.eval()
     n = batches.n_insts
     pin = torch.cuda.is_available()
@@ -167,8 +190,9 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
     for lane in lanes:
         lane.wait_stream(main)    # the buffers (and the model's weights) are ready on every lane
     stages, stop = queue.Queue(maxsize=2), threading.Event()
+    ring = _borrow_ring()
     producer = threading.Thread(target=_produce, name='lamp-eval-producer', daemon=True,
-                                args=(it, n_labels, batch_size, max(int(prefetch), 1), all_targets, stages, pin, device, stop, bool(merge_stage)))
+                                args=(it, n_labels, batch_size, max(int(prefetch), 1), all_targets, stages, pin, device, stop, bool(merge_stage), ring))
     producer.start()
     try:
         _issue(model, stages, lanes, device, batch_size, pad_last_batch, int_preds, probs_d, row_loss_d, r_lo)
@@ -190,6 +214,7 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
         for lo in range(r_lo, r_hi, batch_size):
             real = min(lo + batch_size, r_hi) - lo
             bce_total += float(row_loss[lo - r_lo:lo - r_lo + real].sum()) / (real * n_labels)
+    _return_ring(ring)    # (after the copies above: the device has consumed every upload of this epoch)
     return _combine_ranks(all_predictions, all_targets, bce_total, n, n_labels, world_size, device, group)
 
 

@@ -53,6 +53,9 @@ def parse(argv=None):
     ap.add_argument('-streams', type=int, default=4, choices=[1, 2, 3, 4],
                     help='batches in flight (HIP streams); 4 measured best: 36.6 k / 43.3 k / 46.2 k samples/s with 1 / 2 / 4 on a '
                          'reuters-sized split (tools/bench_eval_epoch.py)')
+    ap.add_argument('-prefetch', type=int, default=8, help='batches per stage of the evaluation epoch (padded by the producer thread while the device runs the previous stage)')
+    ap.add_argument('-merge_stages', action='store_true',
+                    help='one forward per stage instead of one per batch (same predictions, targets and losses bit for bit)')
     ap.add_argument('-seed', type=int, default=0, help='weight init seed when no checkpoint is given')
     ap.add_argument('-gpus', type=int, default=1, help='processes (one per GPU) the batches are sharded over')
     opt = ap.parse_args(argv)
@@ -167,6 +170,7 @@ def main(argv=None):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     preds, targets, bce_total = test_epoch(model, batches, n_labels, opt.batch_size, device, streams=opt.streams,
+                                           prefetch=opt.prefetch, merge_stage=opt.merge_stages,
                                            world_size=world, rank=rank, group=plane.group)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

@@ -344,3 +344,23 @@ def test_bench_kernel_trace_parsing_and_roofline_split(monkeypatch, tmp_path):
     # a profiled parent never starts a nested profiler
     monkeypatch.setenv('ROCPROFILER_TOOL', '1')
     assert 'skipped' in bench.live_kernel_trace(args)
+
+
+def test_intra_op_threads_follow_the_cgroup_quota_not_nproc():
+    """lamp_amd/hostcpu.py: a container's CPU quota (cgroup cpu.max), not the host's core count, sizes torch's OpenMP pool
+    for the evaluation epoch's host work (profiles/r06_eval_epoch_threads.txt: 20 throttled periods vs 0)."""
+    from lamp_amd import hostcpu as H
+    assert H.parse_cpu_max('1600000 100000') == 16.0
+    assert H.parse_cpu_max('max 100000') is None
+    assert H.parse_cpu_max('-1 100000') is None            # cgroup v1 spelling of "no limit"
+    assert H.parse_cpu_max('garbage') is None and H.parse_cpu_max('') is None
+    assert H.parse_cpu_max('50000 100000') == 0.5
+    assert H.fitted_threads(16, 128) == 8                  # half the quota; the rest is for the issuing / producer / HIP threads
+    assert H.fitted_threads(16, 128, share=8) == 1         # eight ranks in one cgroup
+    assert H.fitted_threads(256, 4) == 4                   # never raises what the user set
+    assert H.fitted_threads(1, 128) == 1
+    assert H.usable_cores() >= 1
+    before = torch.get_num_threads()
+    n = H.fit_intra_op_threads()
+    assert 1 <= n <= before and torch.get_num_threads() == n
+    assert H.fit_intra_op_threads() == n                   # once per process

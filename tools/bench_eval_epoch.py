@@ -6,6 +6,7 @@ labels, batch 32 -> 95 batches, model reuters d512 2+2 layers 4 heads label_mask
 
     python tools/bench_eval_epoch.py            # samples/s = documents / wall time of the whole call, 1 / 2 / 4 streams
 """
+import gc
 import json
 import os
 import sys
@@ -37,6 +38,16 @@ def main():
     m.load_state_dict(sd)
     m = m.to(dev).eval()
     out = {'documents': n_docs, 'batch': bs, 'mean_length': sum(lengths) / n_docs + 2}
+    # LAMP_EVAL_GC: 'default' = CPython's collector as it comes; 'freeze' = gc.freeze() once the model and the split are loaded
+    # (what lamp_amd/run_eval.py does: a full collection walks every object torch created at import, tens of milliseconds,
+    # in the middle of a 60 ms epoch); 'off' = gc.disable() for the measurement
+    gc_mode = os.environ.get('LAMP_EVAL_GC', 'freeze')
+    out['gc'] = gc_mode
+    if gc_mode == 'freeze':
+        gc.collect()
+        gc.freeze()
+    elif gc_mode == 'off':
+        gc.disable()
     prefetch = int(os.environ.get('LAMP_EVAL_PREFETCH', '8'))
     ref = None
     out['prefetch'] = prefetch
