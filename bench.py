@@ -55,6 +55,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from lamp_amd import hostcpu  # noqa: E402
 
+TORCH_DEFAULT_THREADS = torch.get_num_threads()   # before main() fits the intra-op pool to the container's CPU quota
+
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
 DEVICE_WARMUP_S = 0.5           # fixed device warm-up before every timed region (clock ramp), stated in `config`
@@ -300,9 +302,9 @@ def cpu_baseline(w, sd, adj, seq, pos, budget_s=20.0):
     B = seq.size(0)
     # torch's default thread count (all physical cores of a big host) is usually NOT the fastest for these
     # small ops: probe a few counts on the as-written / autograd-on path and report the best one.
-    default_threads = torch.get_num_threads()
+    default_threads = torch.get_num_threads()   # (fitted to the CPU quota by main(): the probe below goes up to torch's own default)
     usable = hostcpu.usable_cores()      # min(affinity, cgroup quota): more threads than this only burn the quota
-    candidates = sorted({t for t in (default_threads, usable, 64, 32, 16, 8) if t <= max(default_threads, 1)}, reverse=True)
+    candidates = sorted({t for t in (TORCH_DEFAULT_THREADS, usable, 64, 32, 16, 8) if t <= max(TORCH_DEFAULT_THREADS, 1)}, reverse=True)
     probe = {}
     for t in candidates:
         torch.set_num_threads(t)
@@ -323,7 +325,7 @@ def cpu_baseline(w, sd, adj, seq, pos, budget_s=20.0):
                   (n_aw, B, sorted(probe)),
         'no_grad_value': B / t_ng, 'dead_code_eliminated_no_grad_value': B / t_dce,
         'threads_probe_samples_per_s': {str(k): v for k, v in sorted(probe.items())},
-        'default_torch_threads': default_threads, 'host_cpu_count': os.cpu_count(), 'usable_cores_under_cgroup_quota': usable,
+        'default_torch_threads': TORCH_DEFAULT_THREADS, 'host_cpu_count': os.cpu_count(), 'usable_cores_under_cgroup_quota': usable,
     }
 
 
@@ -648,6 +650,7 @@ def main():
                          'graph as sparse and unstructured (LAMP.use_sparse_label_attention; synthetic4096)')
     ap.add_argument('--mask', default=None, choices=['prior', 'none', 'inveye'], help='override the workload label mask')
     args = ap.parse_args()
+    hostcpu.fit_intra_op_threads(int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1'))))   # lamp_amd/hostcpu.py
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
@@ -858,6 +861,8 @@ def main():
                    'device_warmup_s': DEVICE_WARMUP_S, 'device_warmup_steps': m['device_warmup_steps'],
                    'weights_only_precomputation': weights_only,
                    'csrc_fingerprint': csrc_fingerprint(), 'hipcc': _built_toolchain(),
+                   'host_threads': {'torch_default': TORCH_DEFAULT_THREADS, 'intra_op_fitted_to_cpu_quota': torch.get_num_threads(),
+                                    'usable_cores': hostcpu.usable_cores()},
                    },
         'roofline': roof,
         'forward': {

@@ -35,6 +35,8 @@ def main():
     ap.add_argument('--fused-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of the reference's call (main.py:99)")
     a = ap.parse_args()
     from lamp_amd import _native as N
+    from lamp_amd import hostcpu
+    hostcpu.fit_intra_op_threads()   # a 128-thread OpenMP pool under the boxes' 16-core quota gets the issuing thread throttled
     dev = torch.device('cuda:0')
     w = bench.WORKLOADS[a.workload]
     model, sd, adj, seq, pos = bench.build(w, a.batch, dev)
