@@ -88,6 +88,12 @@ def _hand_over(out_q, item, stop):
     return False
 
 
+def stage_batches(n_stage, prefetch):
+    """Batches in stage number `n_stage`: 1, 2, 4, ... up to `prefetch` -- the first forward is issued after ONE batch has been
+    padded instead of after `prefetch` of them (the device idles while the first stage is prepared)."""
+    return min(prefetch, 1 << min(n_stage, 30))
+
+
 def _produce(it, n_labels, batch_size, prefetch, all_targets, out_q, pin, device, stop, merge=False, ring=None):
     """Producer thread: the host side of utils/data_loader.py:242-312 + utils/utils.py:205-216 for stage after stage."""
     try:
@@ -96,7 +102,7 @@ def _produce(it, n_labels, batch_size, prefetch, all_targets, out_q, pin, device
         ring, n_stage = ring if ring is not None else [_Slot() for _ in range(4)], 0
         while not stop.is_set():
             host = []
-            for _ in range(prefetch):
+            for _ in range(stage_batches(n_stage, prefetch)):
                 nxt = next(it, None)
                 if nxt is None:
                     break
@@ -160,8 +166,8 @@ def test_epoch(model, batches, n_labels, batch_size, device, pad_last_batch=True
     prediction / target rows and BCE sums are combined once (all_reduce over disjoint rows), so every rank returns the
     full matrices.  A sample's numbers do not depend on world_size.
 
-    `prefetch` = batches per stage (module docstring): the first forward is issued after ONE stage has been padded, and
-    at most two further stages wait in the producer's queue.  `timeline` (a dict, optional) receives host timestamps in
+    `prefetch` = batches per stage (module docstring; the first stages ramp 1, 2, 4, ... up to it: stage_batches): the first
+    forward is issued after ONE batch has been padded, and at most two further stages wait in the producer's queue.  `timeline` (a dict, optional) receives host timestamps in
     seconds from the call's start: 'issued' = the last batch was enqueued, 'done' = the device finished
     (tools/bench_eval_epoch.py: issued ~ done means the issuing thread, not the GPU, bounds the epoch).
 

@@ -91,7 +91,7 @@ for i in range(n_eval):
     except Exception as e:
         bad += 1; print('EVAL ERROR', i, c, repr(e)); traceback.print_exc()
 print('eval cases', n_eval, 'bad', bad)
-bad_t = 0
+bad_t = flips = 0
 for i in range(n_train):
     c = case(10000 + i)
     c['L'] = min(c['L'], 95); c['T'] = min(c['T'], 97)
@@ -114,6 +114,16 @@ for i in range(n_train):
             scale = ref.abs().max().item()
             rel = mad(p.grad, ref) / (scale + 1e-12) if scale > 0 else mad(p.grad, ref)
             if scale > 1e-9 and rel > worst: worst, worst_name = rel, n
+        if not (worst < 2e-3) and worst_name.endswith(('w_1.weight', 'w_1.bias')):
+            # ONE hidden unit of a position-wise FFN carrying the whole error (every other unit at rounding level) is a ReLU whose
+            # pre-activation sits within fp32 rounding of zero for one row: fp32 and fp64 take different sides of the kink, the
+            # function is discontinuous there and no summation order is "right" (campaign of round 6: cases 336 and 390, unit 7 /
+            # unit 88, all other units <= 1e-6 of the scale; the CPU fp32 oracle happens to fall on the fp64 side).  Counted apart.
+            g, r_ = dict(m.named_parameters())[worst_name].grad.detach().double().cpu(), sd64[worst_name].grad
+            per_unit = (g - r_).abs().reshape(g.shape[0], -1).max(1).values / r_.abs().max().item()
+            if torch.sort(per_unit, descending=True).values[1].item() < 1e-5:
+                flips += 1; print('RELU FLIP', i, c, worst, worst_name, 'unit', int(per_unit.argmax()), 'logits', mad(lg, rl))
+                continue
         if not (worst < 2e-3):
             bad_t += 1; print('TRAIN MISMATCH', i, c, worst, worst_name, 'logits', mad(lg, rl))
             for n, p in m.named_parameters():   # where the gradient departs: per parameter, relative to its own maximum
@@ -122,4 +132,4 @@ for i in range(n_train):
                     if sc_ > 1e-9 and mad(p.grad, sd64[n].grad) / sc_ > 2e-4: print('     ', n, mad(p.grad, sd64[n].grad) / sc_)
     except Exception as e:
         bad_t += 1; print('TRAIN ERROR', i, c, repr(e)); traceback.print_exc()
-print('train cases', n_train, 'bad', bad_t)
+print('train cases', n_train, 'bad', bad_t, 'relu flips (single hidden unit, see above)', flips)

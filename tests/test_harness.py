@@ -83,7 +83,12 @@ def test_eval_producer_stages_hold_exactly_the_batches(fx):
                 break
             assert not isinstance(st, BaseException), st
             stages.append(st)
-        assert len(stages) == (len(b) + prefetch - 1) // prefetch and q.empty()
+        want_stages, left = 0, len(b)      # stages ramp 1, 2, 4, ... up to `prefetch` batches (evaluate.stage_batches)
+        while left > 0:
+            left -= E.stage_batches(want_stages, prefetch)
+            want_stages += 1
+        assert len(stages) == want_stages and q.empty()
+        assert [len(st.items) for st in stages[:-1]] == [E.stage_batches(i, prefetch) for i in range(want_stages - 1)]
         seen = 0
         for st in stages:
             for bi, lo, real, T, off, row, adj in st.items:
