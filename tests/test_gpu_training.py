@@ -23,6 +23,7 @@ CASES = {
     'tiny_none_h1': (40, 20, 17, 32, 48, 1, 'none', False, 2, 0.0, [17, 9]),
     'inveye_h8': (60, 70, 33, 128, 256, 8, 'inveye', True, 3, 0.0, [33, 1, 20]),
     'reuters_like': (300, 90, 60, 512, 512, 4, 'prior', True, 2, 0.1, [60, 41]),
+    'heads8_d512': (200, 50, 40, 512, 512, 8, 'prior', True, 2, 0.15, [40, 33]),     # d_k = 64 (bibtex-like heads)
 }
 
 
