@@ -51,6 +51,10 @@ def main():
     prefetch = int(os.environ.get('LAMP_EVAL_PREFETCH', '8'))
     ref = None
     out['prefetch'] = prefetch
+    if os.environ.get('LAMP_EVAL_NO_RAMP'):   # A/B leg: every stage `prefetch` batches from the start (the round's first version)
+        from lamp_amd import evaluate as E
+        E.stage_batches = lambda n_stage, prefetch: prefetch
+        out['stage_ramp'] = False
     for streams, merge in ((1, False), (2, False), (4, False), (1, True)):
         rates, rates_all, lines = [], [], []
         for rep in range(6):   # first repetition warms the allocator and the clocks
